@@ -1,0 +1,472 @@
+// ddmpc_api.hip -- C ABI (include/ddmpc.h) over the gfx950 kernels in ddmpc_kernels.hpp.
+// Host-side responsibilities: parameter validation with the reference's error
+// conditions (direct_data_driven_mpc_controller.py:165-168,211-222,298-343,664-670),
+// device buffer ownership, kernel-instance selection, launch.
+#define DDMPC_WITH_AUX_KERNELS 1
+#include "ddmpc_kernels.hpp"
+#include "../../include/ddmpc.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace ddmpc;
+
+// The kernels are instantiated in their own translation units (ddmpc_inst.hip).
+namespace ddmpc {
+#define DDMPC_INSTANCE(NT, W)                                                                        \
+  extern template __global__ void ddmpc_cold_solve_kernel<NT, W>(                                    \
+      KParams, const double*, const double*, const double*, const double*, double*, double*, int*,  \
+      int*, double*, signed char*);
+#include "ddmpc_instances.inc"
+#undef DDMPC_INSTANCE
+}  // namespace ddmpc
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e__ = (expr);                                                            \
+    if (e__ != hipSuccess)                                                              \
+      return fail(DDMPC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                  __FILE__, __LINE__);                                                  \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return DDMPC_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    HIP_TRY(hipMalloc(&p, need));
+    bytes = need;
+    return DDMPC_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+typedef void (*cold_kernel_t)(KParams, const double*, const double*, const double*, const double*, double*,
+                              double*, int*, int*, double*, signed char*);
+
+struct KernelChoice {
+  int NT, W;
+  cold_kernel_t fn;
+  const char* name;
+  size_t reserved;
+};
+
+// Instantiated (tile rows, waves) pairs.  A problem uses the smallest NT that
+// holds rE+1 rows; larger problems are rejected as unsupported.
+const KernelChoice kKernels[] = {
+#define DDMPC_INSTANCE(NT, W) \
+  {NT, W, &ddmpc_cold_solve_kernel<NT, W>, "ddmpc_cold_solve_kernel<" #NT "," #W ">", sizeof(double) * 0},
+#include "ddmpc_instances.inc"
+#undef DDMPC_INSTANCE
+};
+
+size_t lds_doubles_for(int NT, int xs_len) {
+  switch (NT) {
+#define DDMPC_INSTANCE(NT_, W_) \
+  case NT_: return (size_t)Lds<NT_>(xs_len).total;
+#include "ddmpc_instances.inc"
+#undef DDMPC_INSTANCE
+    default: return 0;
+  }
+}
+
+}  // namespace
+
+struct ddmpc_handle {
+  ddmpc_params prm{};
+  std::vector<double> Qh, Rh, us_h, ys_h;
+  int64_t batch = 0;
+  int device = 0;
+  KParams kp{};
+  KernelChoice kc{};
+  size_t lds_bytes = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool have_data = false, solved = false;
+  // parameter tables on device
+  DevBuf d_q, d_r, d_us, d_ys;
+  // data (owned copies when the caller passed host memory)
+  DevBuf d_ud, d_yd;
+  const double* ud = nullptr;
+  const double* yd = nullptr;
+  // staging for host-memory solves + workspace for get_solution
+  DevBuf d_up, d_yp, d_uopt, d_cost, d_status, d_iters, d_beta, d_act, d_out;
+  const double* last_up = nullptr;
+  const double* last_yp = nullptr;
+};
+
+extern "C" {
+
+int ddmpc_version(void) { return DDMPC_ABI_VERSION; }
+
+const char* ddmpc_last_error(void) { return g_err.c_str(); }
+
+int ddmpc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static int upload_params(ddmpc_handle* h) {
+  const ddmpc_params& p = h->prm;
+  int rc;
+  if ((rc = h->d_us.ensure(sizeof(double) * p.m))) return rc;
+  if ((rc = h->d_ys.ensure(sizeof(double) * p.p))) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_us.p, h->us_h.data(), sizeof(double) * p.m, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_ys.p, h->ys_h.data(), sizeof(double) * p.p, hipMemcpyHostToDevice, h->stream));
+  if (p.weight_kind == DDMPC_WEIGHT_DIAG) {
+    if ((rc = h->d_q.ensure(sizeof(double) * h->Qh.size()))) return rc;
+    if ((rc = h->d_r.ensure(sizeof(double) * h->Rh.size()))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_q.p, h->Qh.data(), sizeof(double) * h->Qh.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_r.p, h->Rh.data(), sizeof(double) * h->Rh.size(), hipMemcpyHostToDevice, h->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->kp.u_s = (const double*)h->d_us.p;
+  h->kp.y_s = (const double*)h->d_ys.p;
+  h->kp.qdiag = (const double*)h->d_q.p;
+  h->kp.rdiag = (const double*)h->d_r.p;
+  return DDMPC_OK;
+}
+
+int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_handle** out) {
+  if (!params || !out) return fail(DDMPC_ERR_INVALID, "params/out must not be null");
+  *out = nullptr;
+  if (params->struct_size != (int32_t)sizeof(ddmpc_params))
+    return fail(DDMPC_ERR_INVALID, "ddmpc_params.struct_size mismatch (%d != %zu)", params->struct_size,
+                sizeof(ddmpc_params));
+  const ddmpc_params& p = *params;
+  if (batch <= 0) return fail(DDMPC_ERR_INVALID, "batch must be positive");
+  if (p.m <= 0 || p.p <= 0 || p.n <= 0 || p.L <= 0 || p.N <= 0)
+    return fail(DDMPC_ERR_INVALID, "m, p, n, L, N must be positive");
+  // controller.py:165-168
+  if (p.controller_type != DDMPC_NOMINAL && p.controller_type != DDMPC_ROBUST)
+    return fail(DDMPC_ERR_INVALID, "Unsupported controller type.");
+  // controller.py:211-215
+  if (p.slack_type != DDMPC_SLACK_NON_CONVEX && p.slack_type != DDMPC_SLACK_CONVEX &&
+      p.slack_type != DDMPC_SLACK_NONE)
+    return fail(DDMPC_ERR_INVALID, "Unsupported slack variable constraint type.");
+  // controller.py:664-670 (raised while defining the constraints of a robust controller)
+  if (p.controller_type == DDMPC_ROBUST && p.slack_type == DDMPC_SLACK_NON_CONVEX)
+    return fail(DDMPC_ERR_UNSUPPORTED,
+                "Robust Data-Driven MPC with a Non-Convex slack variable constraint is not currently "
+                "implemented, since it cannot be efficiently solved.");
+  // controller.py:316-325
+  if (p.controller_type == DDMPC_NOMINAL && p.L < p.n)
+    return fail(DDMPC_ERR_INVALID,
+                "The prediction horizon (`L`) must be greater than or equal to the estimated system order `n`.");
+  if (p.controller_type == DDMPC_ROBUST && p.L < 2 * p.n)
+    return fail(DDMPC_ERR_INVALID,
+                "The prediction horizon (`L`) must be greater than or equal to two times the estimated "
+                "system order `n`.");
+  if (p.N < p.L + p.n) return fail(DDMPC_ERR_INVALID, "N must be greater than or equal to L.");  // hankel_matrix.py:43-44
+  if (!p.Q || !p.R || !p.u_s || !p.y_s) return fail(DDMPC_ERR_INVALID, "Q, R, u_s, y_s must not be null");
+  if (p.weight_kind != DDMPC_WEIGHT_SCALAR && p.weight_kind != DDMPC_WEIGHT_DIAG)
+    return fail(DDMPC_ERR_UNSUPPORTED, "weight_kind must be DDMPC_WEIGHT_SCALAR or DDMPC_WEIGHT_DIAG");
+  const size_t nq = p.weight_kind == DDMPC_WEIGHT_DIAG ? (size_t)p.p * p.L : 1;
+  const size_t nr = p.weight_kind == DDMPC_WEIGHT_DIAG ? (size_t)p.m * p.L : 1;
+  for (size_t i = 0; i < nq; ++i)
+    if (!(p.Q[i] > 0.0)) return fail(DDMPC_ERR_UNSUPPORTED, "Q must have a strictly positive diagonal on the HIP path");
+  for (size_t i = 0; i < nr; ++i)
+    if (!(p.R[i] > 0.0)) return fail(DDMPC_ERR_UNSUPPORTED, "R must have a strictly positive diagonal on the HIP path");
+  if (p.controller_type == DDMPC_ROBUST) {
+    if (!(p.eps_max > 0.0) || !(p.lamb_alpha > 0.0) || !(p.lamb_sigma > 0.0))
+      return fail(DDMPC_ERR_INVALID, "robust controller needs eps_max, lamb_alpha, lamb_sigma > 0");
+    if (p.slack_type == DDMPC_SLACK_CONVEX && !(p.c > 0.0))
+      return fail(DDMPC_ERR_INVALID, "slack CONVEX needs c > 0");
+  }
+  if (ddmpc_device_count() <= 0) return fail(DDMPC_ERR_NO_DEVICE, "no HIP device visible (the engine has no CPU fallback)");
+  if (device < 0 || device >= ddmpc_device_count()) return fail(DDMPC_ERR_NO_DEVICE, "device %d out of range", device);
+
+  ddmpc_handle* h = new (std::nothrow) ddmpc_handle();
+  if (!h) return fail(DDMPC_ERR_INVALID, "out of host memory");
+  h->prm = p;
+  h->Qh.assign(p.Q, p.Q + nq);
+  h->Rh.assign(p.R, p.R + nr);
+  h->us_h.assign(p.u_s, p.u_s + p.m);
+  h->ys_h.assign(p.y_s, p.y_s + p.p);
+  h->prm.Q = h->Qh.data();
+  h->prm.R = h->Rh.data();
+  h->prm.u_s = h->us_h.data();
+  h->prm.y_s = h->ys_h.data();
+  h->batch = batch;
+  h->device = device;
+
+  KParams& k = h->kp;
+  k.m = p.m; k.p = p.p; k.n = p.n; k.L = p.L; k.N = p.N;
+  k.nch = p.m + p.p;
+  k.Ln = p.L + p.n;
+  k.r = k.nch * k.Ln;
+  k.rE = (k.r + 3) & ~3;
+  k.c = p.N - k.Ln + 1;
+  k.robust = p.controller_type == DDMPC_ROBUST;
+  k.convex = k.robust && p.slack_type == DDMPC_SLACK_CONVEX;
+  k.tec = p.use_terminal_constraint != 0;
+  k.weight_diag = p.weight_kind == DDMPC_WEIGHT_DIAG;
+  k.q_scalar = h->Qh[0];
+  k.r_scalar = h->Rh[0];
+  k.lam = k.robust ? p.lamb_alpha * p.eps_max : 0.0;
+  k.lamb_sigma = k.robust ? p.lamb_sigma : 1.0;
+  k.bound = k.convex ? p.c * p.eps_max : 0.0;
+  k.max_iter = p.max_iter > 0 ? p.max_iter : 50;
+
+  const int rows_needed = k.rE + 1;
+  const KernelChoice* kc = nullptr;
+  for (const KernelChoice& cand : kKernels)
+    if (16 * cand.NT >= rows_needed) { kc = &cand; break; }
+  if (!kc) {
+    delete h;
+    return fail(DDMPC_ERR_UNSUPPORTED, "problem too large for the single-workgroup kernels: (m+p)(L+n) = %d rows", k.r);
+  }
+  h->kc = *kc;
+  k.xs_len = ((p.N - k.Ln + 3) * k.nch + 16 * kc->NT + 1) & ~1;
+  if (k.xs_len < p.N * k.nch) k.xs_len = (p.N * k.nch + 1) & ~1;
+  const size_t lds_doubles = lds_doubles_for(kc->NT, k.xs_len);
+  h->lds_bytes = lds_doubles * sizeof(double);
+  if (h->lds_bytes > 160 * 1024) {
+    delete h;
+    return fail(DDMPC_ERR_UNSUPPORTED, "trajectory too long for LDS staging: needs %zu bytes of LDS", h->lds_bytes);
+  }
+
+  if (hipSetDevice(device) != hipSuccess) { delete h; return fail(DDMPC_ERR_HIP, "hipSetDevice(%d) failed", device); }
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return fail(DDMPC_ERR_HIP, "hipStreamCreate failed");
+  }
+  h->own_stream = true;
+  if (h->lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(h->kc.fn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+    if (e != hipSuccess) { ddmpc_destroy(h); return fail(DDMPC_ERR_HIP, "hipFuncSetAttribute(LDS=%zu) failed: %s", h->lds_bytes, hipGetErrorString(e)); }
+  }
+  int rc = upload_params(h);
+  if (rc) { ddmpc_destroy(h); return rc; }
+  *out = h;
+  return DDMPC_OK;
+}
+
+int ddmpc_destroy(ddmpc_handle* h) {
+  if (!h) return DDMPC_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  DevBuf* bufs[] = {&h->d_q, &h->d_r, &h->d_us, &h->d_ys, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
+                    &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out};
+  for (DevBuf* b : bufs) b->release();
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return DDMPC_OK;
+}
+
+int ddmpc_set_stream(ddmpc_handle* h, void* hip_stream) {
+  if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
+  (void)hipSetDevice(h->device);
+  if (h->stream) HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  h->stream = (hipStream_t)hip_stream;
+  h->own_stream = false;
+  return DDMPC_OK;
+}
+
+int ddmpc_synchronize(ddmpc_handle* h) {
+  if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
+  (void)hipSetDevice(h->device);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return DDMPC_OK;
+}
+
+int ddmpc_set_data(ddmpc_handle* h, const double* u_d, const double* y_d, int mem) {
+  if (!h || !u_d || !y_d) return fail(DDMPC_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t nu = (size_t)h->batch * h->prm.N * h->prm.m * sizeof(double);
+  const size_t ny = (size_t)h->batch * h->prm.N * h->prm.p * sizeof(double);
+  if (mem == DDMPC_MEM_HOST) {
+    int rc;
+    if ((rc = h->d_ud.ensure(nu))) return rc;
+    if ((rc = h->d_yd.ensure(ny))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_ud.p, u_d, nu, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_yd.p, y_d, ny, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->ud = (const double*)h->d_ud.p;
+    h->yd = (const double*)h->d_yd.p;
+  } else if (mem == DDMPC_MEM_DEVICE) {
+    h->ud = u_d;
+    h->yd = y_d;
+  } else {
+    return fail(DDMPC_ERR_INVALID, "mem must be DDMPC_MEM_HOST or DDMPC_MEM_DEVICE");
+  }
+  h->have_data = true;
+  h->solved = false;
+  return DDMPC_OK;
+}
+
+static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
+                       int32_t* status, int32_t* iters) {
+  int rc;
+  if ((rc = h->d_beta.ensure((size_t)h->batch * h->kp.rE * sizeof(double)))) return rc;
+  if ((rc = h->d_act.ensure((size_t)h->batch * h->kp.rE))) return rc;
+  dim3 grid((unsigned)h->batch), block(64 * h->kc.W);
+  hipLaunchKernelGGL(h->kc.fn, grid, block, h->lds_bytes, h->stream, h->kp, h->ud, h->yd, up, yp, uo, cost,
+                     (int*)status, (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p);
+  HIP_TRY(hipGetLastError());
+  return DDMPC_OK;
+}
+
+int ddmpc_solve(ddmpc_handle* h, const double* u_past, const double* y_past, double* u_opt, double* cost,
+                int32_t* status, int32_t* iters, int mem) {
+  if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
+  if (!h->have_data) return fail(DDMPC_ERR_NOT_READY, "ddmpc_set_data must be called before ddmpc_solve");
+  if (!u_past || !y_past || !u_opt || !cost || !status) return fail(DDMPC_ERR_INVALID, "null argument");
+  if (h->batch > 0x7fffffffLL) return fail(DDMPC_ERR_INVALID, "batch too large for one launch");
+  HIP_TRY(hipSetDevice(h->device));
+  const ddmpc_params& p = h->prm;
+  const size_t n_up = (size_t)h->batch * p.n * p.m * sizeof(double);
+  const size_t n_yp = (size_t)h->batch * p.n * p.p * sizeof(double);
+  const size_t n_uo = (size_t)h->batch * p.L * p.m * sizeof(double);
+  int rc;
+  if (mem == DDMPC_MEM_DEVICE) {
+    if ((rc = launch_cold(h, u_past, y_past, u_opt, cost, status, iters))) return rc;
+    h->last_up = u_past;
+    h->last_yp = y_past;
+    h->solved = true;
+    return DDMPC_OK;
+  }
+  if (mem != DDMPC_MEM_HOST) return fail(DDMPC_ERR_INVALID, "mem must be DDMPC_MEM_HOST or DDMPC_MEM_DEVICE");
+  if ((rc = h->d_up.ensure(n_up))) return rc;
+  if ((rc = h->d_yp.ensure(n_yp))) return rc;
+  if ((rc = h->d_uopt.ensure(n_uo))) return rc;
+  if ((rc = h->d_cost.ensure((size_t)h->batch * sizeof(double)))) return rc;
+  if ((rc = h->d_status.ensure((size_t)h->batch * sizeof(int32_t)))) return rc;
+  if ((rc = h->d_iters.ensure((size_t)h->batch * sizeof(int32_t)))) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_up.p, u_past, n_up, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_yp.p, y_past, n_yp, hipMemcpyHostToDevice, h->stream));
+  if ((rc = launch_cold(h, (const double*)h->d_up.p, (const double*)h->d_yp.p, (double*)h->d_uopt.p,
+                        (double*)h->d_cost.p, (int32_t*)h->d_status.p, (int32_t*)h->d_iters.p)))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(u_opt, h->d_uopt.p, n_uo, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(cost, h->d_cost.p, (size_t)h->batch * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(status, h->d_status.p, (size_t)h->batch * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  if (iters)
+    HIP_TRY(hipMemcpyAsync(iters, h->d_iters.p, (size_t)h->batch * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->last_up = (const double*)h->d_up.p;
+  h->last_yp = (const double*)h->d_yp.p;
+  h->solved = true;
+  return DDMPC_OK;
+}
+
+int ddmpc_set_setpoints(ddmpc_handle* h, const double* u_s, const double* y_s) {
+  if (!h || !u_s || !y_s) return fail(DDMPC_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  h->us_h.assign(u_s, u_s + h->prm.m);
+  h->ys_h.assign(y_s, y_s + h->prm.p);
+  h->prm.u_s = h->us_h.data();
+  h->prm.y_s = h->ys_h.data();
+  h->solved = false;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return upload_params(h);
+}
+
+int ddmpc_get_solution(ddmpc_handle* h, int what, double* out, int mem) {
+  if (!h || !out) return fail(DDMPC_ERR_INVALID, "null argument");
+  if (!h->solved) return fail(DDMPC_ERR_NOT_READY, "no solve to read a solution from");
+  HIP_TRY(hipSetDevice(h->device));
+  const KParams& k = h->kp;
+  size_t per = 0;
+  switch (what) {
+    case DDMPC_SOL_ALPHA: per = k.c; break;
+    case DDMPC_SOL_UBAR: per = (size_t)k.Ln * k.m; break;
+    case DDMPC_SOL_YBAR: per = (size_t)k.Ln * k.p; break;
+    case DDMPC_SOL_SIGMA:
+      if (!k.robust) return fail(DDMPC_ERR_INVALID, "sigma exists only for a robust controller");
+      per = (size_t)k.Ln * k.p;
+      break;
+    default: return fail(DDMPC_ERR_INVALID, "unknown solution selector %d", what);
+  }
+  const size_t bytes = per * h->batch * sizeof(double);
+  double* dst = out;
+  if (mem == DDMPC_MEM_HOST) {
+    int rc = h->d_out.ensure(bytes);
+    if (rc) return rc;
+    dst = (double*)h->d_out.p;
+  }
+  hipLaunchKernelGGL(ddmpc_reconstruct_kernel, dim3((unsigned)h->batch), dim3(256), 0, h->stream, k, what, h->ud,
+                     h->yd, h->last_up, h->last_yp, (const double*)h->d_beta.p, (const signed char*)h->d_act.p, dst);
+  HIP_TRY(hipGetLastError());
+  if (mem == DDMPC_MEM_HOST) {
+    HIP_TRY(hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  return DDMPC_OK;
+}
+
+int ddmpc_hankel(const double* X, int64_t batch, int32_t N, int32_t nch, int32_t L, double* H, int mem,
+                 int device) {
+  if (!X || !H) return fail(DDMPC_ERR_INVALID, "null argument");
+  if (batch <= 0 || N <= 0 || nch <= 0 || L <= 0) return fail(DDMPC_ERR_INVALID, "sizes must be positive");
+  if (N < L) return fail(DDMPC_ERR_INVALID, "N must be greater than or equal to L.");   // hankel_matrix.py:43-44
+  if (ddmpc_device_count() <= 0) return fail(DDMPC_ERR_NO_DEVICE, "no HIP device visible (the engine has no CPU fallback)");
+  HIP_TRY(hipSetDevice(device));
+  const size_t nx = (size_t)batch * N * nch * sizeof(double);
+  const size_t nh = (size_t)batch * L * nch * (N - L + 1) * sizeof(double);
+  const long long total = (long long)(nh / sizeof(double));
+  unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  if (mem == DDMPC_MEM_DEVICE) {
+    hipLaunchKernelGGL(ddmpc_hankel_kernel, dim3(blocks), dim3(256), 0, 0, X, H, N, nch, L, (long long)batch);
+    HIP_TRY(hipGetLastError());
+    return DDMPC_OK;
+  }
+  double *dX = nullptr, *dH = nullptr;
+  HIP_TRY(hipMalloc((void**)&dX, nx));
+  if (hipMalloc((void**)&dH, nh) != hipSuccess) { (void)hipFree(dX); return fail(DDMPC_ERR_HIP, "hipMalloc(%zu) failed", nh); }
+  hipError_t e = hipMemcpy(dX, X, nx, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(ddmpc_hankel_kernel, dim3(blocks), dim3(256), 0, 0, dX, dH, N, nch, L, (long long)batch);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(H, dH, nh, hipMemcpyDeviceToHost);
+  (void)hipFree(dX);
+  (void)hipFree(dH);
+  if (e != hipSuccess) return fail(DDMPC_ERR_HIP, "ddmpc_hankel: %s", hipGetErrorString(e));
+  return DDMPC_OK;
+}
+
+int ddmpc_cost_model(ddmpc_handle* h, double* flops_per_solve, double* bytes_per_solve) {
+  if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
+  const KParams& k = h->kp;
+  const double r = k.r, c = k.c;
+  // Dense symmetric Gram (multiply-add = 2 flops, half the entries) + Cholesky of the
+  // r x r reduced system + forward/back substitution (DESIGN.md "Roofline accounting").
+  if (flops_per_solve) *flops_per_solve = r * r * c + r * r * r / 3.0 + 2.0 * r * r;
+  // compulsory HBM traffic: trajectories in, past window in, optimal_u + cost + status out
+  if (bytes_per_solve)
+    *bytes_per_solve = 8.0 * ((double)k.N * k.nch + (double)k.n * k.nch + (double)k.L * k.m + 1.0) + 4.0;
+  return DDMPC_OK;
+}
+
+const char* ddmpc_kernel_name(ddmpc_handle* h) { return h ? h->kc.name : ""; }
+
+}  // extern "C"

@@ -1,0 +1,221 @@
+"""Batched Data-Driven MPC QP engine: Python host side over the C ABI.
+
+`BatchedDDMPC` owns one `ddmpc_handle` = one batch of independent controller
+instances that share the controller parameters and differ in their data
+trajectories (u_d, y_d) and past windows.  This is the data-parallel axis the
+reference does not have (one `DirectDataDrivenMPCController` = one instance,
+direct_data_driven_mpc_controller.py:22).
+
+Buffers may be numpy arrays (host; the library stages them, calls are
+synchronous) or torch CUDA tensors (device resident; calls are asynchronous on
+the current torch stream).  torch is plumbing only and is imported lazily.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _weights(W, size: int, name: str) -> Tuple[int, np.ndarray]:
+    """Accept scalar / 1-D diagonal / 2-D diagonal matrix; return (kind, values)."""
+    W = np.asarray(W, dtype=np.float64)
+    if W.ndim == 0:
+        return L.WEIGHT_SCALAR, W.reshape(1).copy()
+    if W.ndim == 1:
+        if W.shape[0] != size:
+            raise ValueError("%s diagonal must have %d entries" % (name, size))
+        d = W
+    elif W.ndim == 2:
+        if W.shape != (size, size):
+            raise ValueError("%s must be %dx%d" % (name, size, size))
+        d = np.diag(W)
+        if np.any(W != np.diag(d)):
+            raise NotImplementedError(
+                "%s is not diagonal: dense weighting matrices are not supported by the HIP path yet" % name)
+    else:
+        raise ValueError("%s has too many dimensions" % name)
+    if np.all(d == d[0]):
+        return L.WEIGHT_SCALAR, np.array([d[0]], dtype=np.float64)
+    return L.WEIGHT_DIAG, np.ascontiguousarray(d, dtype=np.float64)
+
+
+class BatchedDDMPC:
+    def __init__(self, n: int, m: int, p: int, L_: int, N: int, Q, R, u_s, y_s, batch: int,
+                 controller_type: int = L.ROBUST, slack_type: int = L.SLACK_NONE,
+                 eps_max: Optional[float] = None, lamb_alpha: Optional[float] = None,
+                 lamb_sigma: Optional[float] = None, c: Optional[float] = None,
+                 use_terminal_constraint: bool = True, device: int = 0, max_iter: int = 0,
+                 gram_mode: int = L.GRAM_AUTO):
+        self._lib = L.load()
+        self.n, self.m, self.p, self.L, self.N, self.batch = int(n), int(m), int(p), int(L_), int(N), int(batch)
+        self.device = int(device)
+        self.controller_type, self.slack_type = int(controller_type), int(slack_type)
+        wk_q, q = _weights(Q, self.p * self.L, "Q")
+        wk_r, r = _weights(R, self.m * self.L, "R")
+        if wk_q != wk_r:      # mixed: expand the scalar one
+            if wk_q == L.WEIGHT_SCALAR:
+                q = np.full(self.p * self.L, q[0])
+            else:
+                r = np.full(self.m * self.L, r[0])
+            wk_q = wk_r = L.WEIGHT_DIAG
+        self._q, self._r = q, r
+        self._us = np.ascontiguousarray(np.asarray(u_s, dtype=np.float64).reshape(-1))
+        self._ys = np.ascontiguousarray(np.asarray(y_s, dtype=np.float64).reshape(-1))
+        if self._us.size != self.m or self._ys.size != self.p:
+            raise ValueError("u_s / y_s must have m / p entries")
+        prm = L.Params()
+        prm.struct_size = C.sizeof(L.Params)
+        prm.m, prm.p, prm.n, prm.L, prm.N = self.m, self.p, self.n, self.L, self.N
+        prm.controller_type, prm.slack_type = self.controller_type, self.slack_type
+        prm.use_terminal_constraint = 1 if use_terminal_constraint else 0
+        prm.weight_kind = wk_q
+        prm.Q = self._q.ctypes.data_as(L.c_double_p)
+        prm.R = self._r.ctypes.data_as(L.c_double_p)
+        prm.eps_max = float(eps_max) if eps_max is not None else 0.0
+        prm.lamb_alpha = float(lamb_alpha) if lamb_alpha is not None else 0.0
+        prm.lamb_sigma = float(lamb_sigma) if lamb_sigma is not None else 0.0
+        prm.c = float(c) if c is not None else 0.0
+        prm.u_s = self._us.ctypes.data_as(L.c_double_p)
+        prm.y_s = self._ys.ctypes.data_as(L.c_double_p)
+        prm.max_iter = int(max_iter)
+        prm.gram_mode = int(gram_mode)
+        self._h = C.c_void_p()
+        L.check(self._lib.ddmpc_create(C.byref(prm), self.batch, self.device, C.byref(self._h)))
+        self._keep = {}
+
+    # ---- lifetime ------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.ddmpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- helpers -----------------------------------------------------------
+    def _ptr(self, x, shape, name, dtype=np.float64, writable=False):
+        """Return (pointer, mem, keepalive) for a numpy array or a torch CUDA tensor."""
+        if _is_torch(x):
+            import torch
+            want = {np.float64: torch.float64, np.int32: torch.int32}[dtype]
+            if not x.is_cuda or x.dtype != want or not x.is_contiguous():
+                raise ValueError("%s must be a contiguous CUDA tensor of dtype %s" % (name, want))
+            if tuple(x.shape) != tuple(shape):
+                raise ValueError("%s must have shape %s, got %s" % (name, tuple(shape), tuple(x.shape)))
+            return C.c_void_p(x.data_ptr()), L.MEM_DEVICE, x
+        a = np.asarray(x)
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError("%s must have shape %s, got %s" % (name, tuple(shape), tuple(a.shape)))
+        if writable:
+            if a.dtype != dtype or not a.flags.c_contiguous or not a.flags.writeable:
+                raise ValueError("%s must be a writable C-contiguous %s array" % (name, np.dtype(dtype)))
+        else:
+            a = np.ascontiguousarray(a, dtype=dtype)
+        return C.c_void_p(a.ctypes.data), L.MEM_HOST, a
+
+    def _use_torch_stream(self):
+        import torch
+        self._lib.ddmpc_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+
+    # ---- API ---------------------------------------------------------------
+    def set_data(self, u_d, y_d) -> None:
+        """u_d [batch,N,m], y_d [batch,N,p] (controller.py:177-179)."""
+        pu, mu, ku = self._ptr(u_d, (self.batch, self.N, self.m), "u_d")
+        py, my, ky = self._ptr(y_d, (self.batch, self.N, self.p), "y_d")
+        if mu != my:
+            raise ValueError("u_d and y_d must live in the same memory space")
+        if mu == L.MEM_DEVICE:
+            self._use_torch_stream()
+        L.check(self._lib.ddmpc_set_data(self._h, pu, py, mu))
+        self._keep["data"] = (ku, ky)
+
+    def solve(self, u_past, y_past, u_opt=None, cost=None, status=None, iters=None):
+        """One cold QP solve per instance.  Returns (u_opt, cost, status, iters)."""
+        B = self.batch
+        dev = _is_torch(u_past)
+        if u_opt is None:
+            if dev:
+                import torch
+                kw = dict(device=u_past.device)
+                u_opt = torch.empty((B, self.L * self.m), dtype=torch.float64, **kw)
+                cost = torch.empty((B,), dtype=torch.float64, **kw)
+                status = torch.empty((B,), dtype=torch.int32, **kw)
+                iters = torch.empty((B,), dtype=torch.int32, **kw)
+            else:
+                u_opt = np.empty((B, self.L * self.m))
+                cost = np.empty((B,))
+                status = np.empty((B,), dtype=np.int32)
+                iters = np.empty((B,), dtype=np.int32)
+        p1, m1, k1 = self._ptr(u_past, (B, self.n * self.m), "u_past")
+        p2, m2, k2 = self._ptr(y_past, (B, self.n * self.p), "y_past")
+        p3, m3, k3 = self._ptr(u_opt, (B, self.L * self.m), "u_opt", writable=True)
+        p4, m4, k4 = self._ptr(cost, (B,), "cost", writable=True)
+        p5, m5, k5 = self._ptr(status, (B,), "status", dtype=np.int32, writable=True)
+        if iters is not None:
+            p6, m6, k6 = self._ptr(iters, (B,), "iters", dtype=np.int32, writable=True)
+        else:
+            p6, m6, k6 = C.c_void_p(), m1, None
+        if len({m1, m2, m3, m4, m5, m6}) != 1:
+            raise ValueError("all solve buffers must live in the same memory space")
+        if m1 == L.MEM_DEVICE:
+            self._use_torch_stream()
+        L.check(self._lib.ddmpc_solve(self._h, p1, p2, p3, p4, p5, p6, m1))
+        self._keep["solve"] = (k1, k2, k3, k4, k5, k6)
+        return u_opt, cost, status, iters
+
+    def set_setpoints(self, u_s, y_s) -> None:
+        us = np.ascontiguousarray(np.asarray(u_s, dtype=np.float64).reshape(-1))
+        ys = np.ascontiguousarray(np.asarray(y_s, dtype=np.float64).reshape(-1))
+        if us.size != self.m or ys.size != self.p:
+            raise ValueError("u_s / y_s must have m / p entries")
+        L.check(self._lib.ddmpc_set_setpoints(self._h, C.c_void_p(us.ctypes.data), C.c_void_p(ys.ctypes.data)))
+        self._us, self._ys = us, ys
+
+    def get_solution(self, what: str) -> np.ndarray:
+        """`.value` of alpha / ubar / ybar / sigma after the last solve (host array)."""
+        sel = {"alpha": L.SOL_ALPHA, "ubar": L.SOL_UBAR, "ybar": L.SOL_YBAR, "sigma": L.SOL_SIGMA}[what]
+        Ln = self.L + self.n
+        per = {"alpha": self.N - Ln + 1, "ubar": Ln * self.m, "ybar": Ln * self.p, "sigma": Ln * self.p}[what]
+        out = np.empty((self.batch, per))
+        L.check(self._lib.ddmpc_get_solution(self._h, sel, C.c_void_p(out.ctypes.data), L.MEM_HOST))
+        return out
+
+    def synchronize(self) -> None:
+        L.check(self._lib.ddmpc_synchronize(self._h))
+
+    def cost_model(self) -> Tuple[float, float]:
+        f, b = C.c_double(), C.c_double()
+        L.check(self._lib.ddmpc_cost_model(self._h, C.byref(f), C.byref(b)))
+        return f.value, b.value
+
+    def kernel_name(self) -> str:
+        return self._lib.ddmpc_kernel_name(self._h).decode()
+
+
+def hankel_matrix_batched(X: np.ndarray, L_: int, device: int = 0) -> np.ndarray:
+    """Batched hankel_matrix on the GPU: X [B,N,nch] -> [B, L*nch, N-L+1]."""
+    lib = L.load()
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    B, N, nch = X.shape
+    if N < L_:
+        raise ValueError("N must be greater than or equal to L.")
+    H = np.empty((B, L_ * nch, N - L_ + 1))
+    L.check(lib.ddmpc_hankel(C.c_void_p(X.ctypes.data), B, N, nch, L_, C.c_void_p(H.ctypes.data), L.MEM_HOST, device))
+    return H

@@ -1,0 +1,156 @@
+/*
+ * ddmpc.h -- C ABI of the MI355X-native batched Data-Driven MPC QP engine.
+ *
+ * This is the drop-in boundary for the per-timestep QP path of
+ * pavelacamposp/direct_data_driven_mpc.  The reference has no FFI of its own
+ * (it is pure Python on CVXPY); each entry point below names the reference
+ * interface it replaces (file:line relative to the reference repository root).
+ * A Python `ctypes` shim (direct_data_driven_mpc_amd/_lib.py) binds exactly
+ * these symbols and re-creates the `DirectDataDrivenMPCController` class
+ * surface on top of them; INTEGRATION.md shows the binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 (DDMPC_OK) or a negative DDMPC_ERR_* code and
+ *     never throws; `ddmpc_last_error()` returns a thread-local message;
+ *   - plain pointers and sizes only; all arrays are C-order fp64 unless noted;
+ *   - `mem` says where the caller's buffers live: DDMPC_MEM_HOST (the library
+ *     stages them through its own device buffers and the call is synchronous)
+ *     or DDMPC_MEM_DEVICE (HIP device pointers, the call is asynchronous on
+ *     the handle's stream);
+ *   - one handle = one batch of `batch` independent controller instances that
+ *     share the controller parameters and differ in their data trajectories
+ *     and past windows.  A bad instance never fails a call: it gets a
+ *     per-instance status code.
+ *   - there is NO CPU fallback: without a HIP device every call fails with
+ *     DDMPC_ERR_NO_DEVICE.
+ */
+#ifndef DDMPC_H
+#define DDMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDMPC_ABI_VERSION 1
+
+/* return codes */
+#define DDMPC_OK                 0
+#define DDMPC_ERR_INVALID       -1  /* bad argument (message says which)            */
+#define DDMPC_ERR_UNSUPPORTED   -2  /* valid request the HIP path does not cover     */
+#define DDMPC_ERR_NO_DEVICE     -3  /* no usable HIP device                          */
+#define DDMPC_ERR_HIP           -4  /* a HIP runtime call failed                     */
+#define DDMPC_ERR_NOT_READY     -5  /* e.g. solve before set_data                    */
+
+/* DataDrivenMPCType, direct_data_driven_mpc_controller.py:11-14 */
+#define DDMPC_NOMINAL 0
+#define DDMPC_ROBUST  1
+/* SlackVarConstraintTypes, direct_data_driven_mpc_controller.py:16-20 */
+#define DDMPC_SLACK_NON_CONVEX 0    /* rejected, controller.py:664-670 */
+#define DDMPC_SLACK_CONVEX     1
+#define DDMPC_SLACK_NONE       2
+
+/* per-instance solve status; maps 1:1 onto the CVXPY strings the reference
+ * tests for in get_optimal_control_input (controller.py:804-808) */
+#define DDMPC_STATUS_OPTIMAL            0   /* "optimal"            */
+#define DDMPC_STATUS_OPTIMAL_INACCURATE 1   /* "optimal_inaccurate" */
+#define DDMPC_STATUS_INFEASIBLE         2   /* "infeasible"         */
+#define DDMPC_STATUS_UNBOUNDED          3   /* "unbounded"          */
+#define DDMPC_STATUS_SOLVER_ERROR       4   /* "solver_error"       */
+
+#define DDMPC_WEIGHT_SCALAR 0       /* Q = q*I, R = r*I (what the reference loader builds,
+                                       utilities/controller/controller_creation.py:125-127) */
+#define DDMPC_WEIGHT_DIAG   1       /* Q = diag(q[0..p*L)), R = diag(r[0..m*L)) */
+
+#define DDMPC_MEM_HOST   0
+#define DDMPC_MEM_DEVICE 1
+
+#define DDMPC_GRAM_AUTO       0
+#define DDMPC_GRAM_DENSE      1     /* H H' by fp64 MFMA over the implicit Hankel operand */
+#define DDMPC_GRAM_STRUCTURED 2     /* Hankel sliding-window recurrence                 */
+
+/* ddmpc_get_solution selectors: the `.value` of the reference's cp.Variables
+ * (controller.py:434-445) */
+#define DDMPC_SOL_ALPHA 0           /* [batch, N-L-n+1]   */
+#define DDMPC_SOL_UBAR  1           /* [batch, (L+n)*m]   */
+#define DDMPC_SOL_YBAR  2           /* [batch, (L+n)*p]   */
+#define DDMPC_SOL_SIGMA 3           /* [batch, (L+n)*p], robust only */
+
+typedef struct ddmpc_handle ddmpc_handle;
+
+/* Controller parameters = the constructor arguments of
+ * DirectDataDrivenMPCController.__init__ (controller.py:95-116) minus the
+ * per-instance data.  All pointers are HOST pointers, copied at create. */
+typedef struct ddmpc_params {
+  int32_t struct_size;              /* sizeof(ddmpc_params), ABI guard              */
+  int32_t m, p, n, L, N;            /* inputs, outputs, est. order, horizon, data length */
+  int32_t controller_type;          /* DDMPC_NOMINAL | DDMPC_ROBUST                  */
+  int32_t slack_type;               /* DDMPC_SLACK_*                                 */
+  int32_t use_terminal_constraint;  /* controller.py:229,489-492                     */
+  int32_t weight_kind;              /* DDMPC_WEIGHT_*                                */
+  const double* Q;                  /* 1 value (scalar) or p*L values (diag)         */
+  const double* R;                  /* 1 value (scalar) or m*L values (diag)         */
+  double eps_max, lamb_alpha, lamb_sigma, c;   /* robust parameters, controller.py:197-205 */
+  const double* u_s;                /* [m]                                           */
+  const double* y_s;                /* [p]                                           */
+  int32_t max_iter;                 /* active-set iteration cap for slack CONVEX (0 -> 50) */
+  int32_t gram_mode;                /* DDMPC_GRAM_*                                  */
+} ddmpc_params;
+
+int ddmpc_version(void);
+const char* ddmpc_last_error(void);
+
+/* Number of visible HIP devices (0 if none); never fails. */
+int ddmpc_device_count(void);
+
+/* Replaces DirectDataDrivenMPCController.__init__ parameter validation
+ * (controller.py:165-168,211-222,298-343,664-670) for a batch of instances on
+ * HIP device `device`.  Does not solve. */
+int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_handle** out);
+int ddmpc_destroy(ddmpc_handle* h);
+
+/* Use an existing hipStream_t (passed as void*) instead of the handle's own. */
+int ddmpc_set_stream(ddmpc_handle* h, void* hip_stream);
+int ddmpc_synchronize(ddmpc_handle* h);
+
+/* Per-instance data trajectories u_d [batch,N,m], y_d [batch,N,p]
+ * (controller.py:177-179).  HOST: copied; DEVICE: borrowed, must stay valid. */
+int ddmpc_set_data(ddmpc_handle* h, const double* u_d, const double* y_d, int mem);
+
+/* One control step for every instance = update_and_solve_data_driven_mpc +
+ * get_optimal_control_input (+ get_optimal_cost_value / get_problem_solve_status),
+ * controller.py:389-407,739-808.  "Cold" solve: implicit Hankel -> Gram ->
+ * reduced KKT -> Cholesky -> solve (-> active-set iterations for slack CONVEX).
+ *   u_past [batch, n*m], y_past [batch, n*p]   (controller.py:184-185,577-581)
+ *   u_opt  [batch, L*m]  = ubar[n*m:]          (controller.py:799-805)
+ *   cost   [batch]       = problem.value       (controller.py:778)
+ *   status [batch] int32 DDMPC_STATUS_*        (controller.py:755)
+ *   iters  [batch] int32 factorisations used (may be NULL) */
+int ddmpc_solve(ddmpc_handle* h, const double* u_past, const double* y_past,
+                double* u_opt, double* cost, int32_t* status, int32_t* iters, int mem);
+
+/* set_input_output_setpoints (controller.py:945-982); takes effect at the next solve. */
+int ddmpc_set_setpoints(ddmpc_handle* h, const double* u_s, const double* y_s);
+
+/* Values of the optimisation variables after the last ddmpc_solve
+ * (controller.py:434-445 `.value`); `out` sized as listed at DDMPC_SOL_*. */
+int ddmpc_get_solution(ddmpc_handle* h, int what, double* out, int mem);
+
+/* hankel_matrix(X, L) for a batch (direct_data_driven_mpc/utilities/hankel_matrix.py:5-53):
+ * X [batch,N,nch] -> H [batch, L*nch, N-L+1].  Stand-alone (no handle). */
+int ddmpc_hankel(const double* X, int64_t batch, int32_t N, int32_t nch, int32_t L,
+                 double* H, int mem, int device);
+
+/* Kernel facts for benchmarking: algorithmic flops and bytes of one cold solve
+ * with this handle's configuration (see DESIGN.md "Roofline accounting"). */
+int ddmpc_cost_model(ddmpc_handle* h, double* flops_per_solve, double* bytes_per_solve);
+
+/* Name of the dominant kernel as it appears in rocprofv3 traces. */
+const char* ddmpc_kernel_name(ddmpc_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDMPC_H */

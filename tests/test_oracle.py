@@ -1,0 +1,136 @@
+"""CPU tests: the oracle against the reference-derived golden vectors, the
+third-party cross-check, and its own second formulation.  No GPU."""
+import numpy as np
+import pytest
+
+from oracle import ddmpc_oracle as orc
+from oracle.reduced_form import solve_reduced
+
+N, L, n, m, p = 400, 30, 4, 2, 2
+
+
+def test_hankel_docstring_known_answer(golden):
+    # direct_data_driven_mpc/utilities/hankel_matrix.py:26-37
+    H = orc.hankel_matrix(golden["kat_X"], 2)
+    assert H.shape == (4, 3)
+    assert np.array_equal(H, golden["kat_H"])
+    expect = np.array([[0.27392337, -0.91805295, 0.62654048],
+                       [-0.46042657, -0.96694473, 0.82551115],
+                       [-0.91805295, 0.62654048, 0.21327155],
+                       [-0.96694473, 0.82551115, 0.45899312]])
+    assert np.allclose(H, expect, atol=5e-9)
+
+
+def test_hankel_matches_reference_on_generated_data(golden):
+    wts = None
+    for s in range(5):
+        Hu = orc.hankel_matrix(golden[f"s{s}_u_d"], L + n)
+        Hy = orc.hankel_matrix(golden[f"s{s}_y_d"], L + n)
+        assert Hu.shape == (m * (L + n), N - L - n + 1)
+        if wts is None:
+            wts = np.cos(np.arange(Hu.size, dtype=float)).reshape(Hu.shape)
+        for H, key in ((Hu, "Hu"), (Hy, "Hy")):
+            fp = np.array([H.sum(), (H * wts).sum(), H[5, 7], H[-1, -1]])
+            assert np.array_equal(fp, golden[f"s{s}_{key}_fp"])
+    assert np.array_equal(orc.hankel_matrix(golden["s0_u_d"], L + n), golden["s0_Hu"])
+
+
+def test_hankel_rejects_short_input():
+    with pytest.raises(ValueError, match="N must be greater than or equal to L"):
+        orc.hankel_matrix(np.zeros((3, 2)), 4)
+
+
+def test_persistent_excitation_ranks(golden):
+    for s in range(5):
+        rank, ok = orc.evaluate_persistent_excitation(golden[f"s{s}_u_d"], L + 2 * n)
+        assert [rank, int(ok)] == golden[f"s{s}_pe_rank"].tolist() == [76, 1]
+    rank, ok = orc.evaluate_persistent_excitation(np.ones((N, m)), L + 2 * n)
+    assert [rank, int(ok)] == golden["const_pe_rank"].tolist()
+    assert not ok
+
+
+def test_data_generation_matches_reference(golden):
+    for s in range(5):
+        inst = orc.generate_instance(s)
+        assert np.array_equal(inst["u_d"], golden[f"s{s}_u_d"])
+        assert np.array_equal(inst["y_d"], golden[f"s{s}_y_d"])
+        assert np.array_equal(inst["x_0"], golden[f"s{s}_x0"])
+    plant = orc.Plant(**orc.FOUR_TANK)
+    assert np.allclose(plant.equilibrium_input_from_output(np.array([0.4, 0.4])), golden["eq_u"], atol=1e-14)
+
+
+@pytest.mark.parametrize("tag,kw", [("none", {}), ("convex", dict(slack_var_constraint_type=1)),
+                                    ("ucon", dict(tec=False))])
+def test_oracle_solutions_pinned(golden, tag, kw):
+    spec = orc.spec_from_params(**kw)
+    for s in range(5):
+        u_d, y_d = golden[f"s{s}_u_d"], golden[f"s{s}_y_d"]
+        sol = orc.solve_fullspace(spec, u_d, y_d, u_d[-n:].reshape(-1), y_d[-n:].reshape(-1))
+        assert sol.status == "optimal"
+        assert np.allclose(sol.optimal_u, golden[f"s{s}_{tag}_u"], rtol=0, atol=1e-10)
+        assert abs(sol.cost - golden[f"s{s}_{tag}_cost"][0]) < 1e-11
+
+
+def test_survey_known_answers(golden):
+    # SURVEY.md section 6 / BASELINE.md section 2 (seed 0, robust, slack NONE, TEC)
+    spec = orc.spec_from_params()
+    u_d, y_d = golden["s0_u_d"], golden["s0_y_d"]
+    sol = orc.solve_fullspace(spec, u_d, y_d, u_d[-n:].reshape(-1), y_d[-n:].reshape(-1))
+    assert np.allclose(sol.optimal_u[:2], [21.22188171, 20.30350327], atol=5e-9)
+    assert abs(sol.cost - 4.543214030) < 5e-10
+    assert abs(np.max(np.abs(sol.sigma[n * p:])) - 2.1368e-3) < 5e-8
+    assert abs(np.sum(np.abs(sol.alpha)) - 53.34) < 5e-3
+
+
+@pytest.mark.parametrize("tag", ["none", "convex"])
+def test_third_party_solver_agrees(golden, tag):
+    # scipy.optimize trust-constr on the same full-space QP (tests/golden/make_golden.py)
+    u_ref, c_ref = golden[f"scipy_s0_{tag}_u"], golden[f"scipy_s0_{tag}_cost"][0]
+    u, c = golden[f"s0_{tag}_u"], golden[f"s0_{tag}_cost"][0]
+    assert abs(c - c_ref) / abs(c_ref) < 1e-9
+    assert np.max(np.abs(u - u_ref)) / np.max(np.abs(u_ref)) < 1e-7
+
+
+@pytest.mark.parametrize("kw", [{}, dict(slack_var_constraint_type=1), dict(tec=False),
+                                dict(tec=False, slack_var_constraint_type=1)])
+def test_kkt_certificate_and_second_formulation(kw):
+    spec = orc.spec_from_params(**kw)
+    for s in (0, 7):
+        inst = orc.generate_instance(s)
+        u_d, y_d = inst["u_d"], inst["y_d"]
+        up, yp = u_d[-n:].reshape(-1), y_d[-n:].reshape(-1)
+        sol = orc.solve_fullspace(spec, u_d, y_d, up, yp)
+        cert = orc.kkt_certificate(spec, u_d, y_d, up, yp, sol.x)
+        assert cert["res_eq"] < 1e-11 and cert["res_box"] < 1e-15
+        assert cert["res_stat"] < 1e-10 * max(1.0, cert["grad_scale"]) and cert["dual_sign"] == 0.0
+        red = solve_reduced(spec, u_d, y_d, up, yp)
+        assert red["status"] == "optimal"
+        assert np.max(np.abs(red["optimal_u"] - sol.optimal_u)) / np.max(np.abs(sol.optimal_u)) < 1e-10
+        assert abs(red["cost"] - sol.cost) / abs(sol.cost) < 1e-10
+        assert np.max(np.abs(red["sigma"] - sol.sigma)) < 1e-11
+        if spec.slack == "convex":
+            assert np.array_equal(red["act"], sol.active)
+
+
+def test_nominal_full_row_rank_known_answer():
+    # noisy Hankel has full row rank => optimal_u == tile(u_s, L), cost 0
+    spec = orc.spec_from_params(controller_type=0)
+    inst = orc.generate_instance(0)
+    u_d, y_d = inst["u_d"], inst["y_d"]
+    sol = orc.solve_fullspace(spec, u_d, y_d, u_d[-n:].reshape(-1), y_d[-n:].reshape(-1))
+    assert np.allclose(sol.optimal_u, np.tile(spec.u_s, L), atol=1e-7)
+    assert abs(sol.cost) < 1e-9
+    red = solve_reduced(spec, u_d, y_d, u_d[-n:].reshape(-1), y_d[-n:].reshape(-1))
+    assert np.allclose(red["optimal_u"], np.tile(spec.u_s, L), atol=1e-12)
+
+
+def test_closed_loop_converges_to_setpoint():
+    # seed 0 example closes at y ~ (0.65, 0.77), u ~ (1, 1); n-step scheme n_mpc_step = n
+    spec = orc.spec_from_params()
+    inst = orc.generate_instance(0)
+    n_steps = 161
+    w = inst["plant"].eps_max * inst["rng"].uniform(-1.0, 1.0, (n_steps, p))
+    u_sys, y_sys = orc.closed_loop(spec, inst["u_d"], inst["y_d"], inst["plant"], w, n_mpc_step=4)
+    assert np.allclose(u_sys[0], [21.22188171, 20.30350327], atol=5e-9)
+    assert np.all(np.abs(y_sys[-1] - spec.y_s) < 0.03)
+    assert np.all(np.abs(u_sys[-1] - spec.u_s) < 0.2)
