@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""bench.py -- QP solves/sec of the batched Data-Driven MPC cold solve on MI355X.
+
+Workload (BASELINE.json configs[1]): four-tank robust DD-MPC, L=30, N=400, slack
+NONE (the reference YAML default), batch = 4096 noise seeds per GPU, inputs
+resident in HBM.  One "step" = one cold QP solve (implicit Hankel -> Gram ->
+reduced KKT -> Cholesky -> solve) for every instance of the batch.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  See DESIGN.md "Measurement".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 2.4 GHz x 2048 flop / 64 clk (v_mfma_f64_16x16x4_f64),
+                               # measured 64 clk/instr/SIMD in profiles/r01_mfma_f64_probe.log
+
+
+def cpu_baseline(cfg, u_d, y_d, up, yp, u_gpu, cost_gpu, n_sample):
+    """Time the CPU oracle (full-space KKT restatement of the reference QP) on a bounded
+    sample of the same workload and check the GPU results against it."""
+    from oracle import ddmpc_oracle as orc
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:       # pragma: no cover
+        threadpool_limits = None
+    cores = min(16, os.cpu_count() or 1)
+    spec = orc.QPSpec(n=cfg["n"], m=cfg["m"], p=cfg["p"], L=cfg["L"], Q=cfg["Q"] * np.eye(cfg["p"] * cfg["L"]),
+                      R=cfg["R"] * np.eye(cfg["m"] * cfg["L"]), u_s=cfg["u_s"], y_s=cfg["y_s"], robust=cfg["robust"],
+                      eps_max=cfg["eps_max"], lamb_alpha=cfg["lamb_alpha"], lamb_sigma=cfg["lamb_sigma"], c=cfg["c"],
+                      slack=cfg["slack"], tec=cfg["tec"])
+
+    def run():
+        t0 = time.perf_counter()
+        sols = [orc.solve_fullspace(spec, u_d[b], y_d[b], up[b], yp[b]) for b in range(n_sample)]
+        return time.perf_counter() - t0, sols
+
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=cores):
+            run_t, sols = run()
+    else:
+        run_t, sols = run()
+    eu = max(np.max(np.abs(u_gpu[b] - s.optimal_u)) / np.max(np.abs(s.optimal_u)) for b, s in enumerate(sols))
+    ec = max(abs(cost_gpu[b] - s.cost) / abs(s.cost) for b, s in enumerate(sols))
+    return dict(value=n_sample / run_t, unit="QP solves/s", cores=cores, kind="port",
+                sample="%d cold solves (first %d instances of the batch), full-space dense KKT in numpy/LAPACK, "
+                       "%.1f s" % (n_sample, n_sample, run_t)), dict(max_rel_err_u=eu, max_rel_err_cost=ec,
+                                                                     checked=n_sample, tol_u=1e-8, tol_cost=1e-9)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=4096)
+    ap.add_argument("--slack", choices=["none", "convex"], default="none")
+    ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from direct_data_driven_mpc_amd import _lib as L
+    from direct_data_driven_mpc_amd.distributed import gather_results, shard_bounds
+    from direct_data_driven_mpc_amd.engine import BatchedDDMPC
+    from direct_data_driven_mpc_amd.harness import controller_params, generate_batch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    cfg = controller_params(dict(slack_var_constraint_type=1 if a.slack == "convex" else 0))
+    total = a.batch_per_gpu * world
+    lo, hi = shard_bounds(total, rank, world)
+    B = hi - lo
+    data = generate_batch(range(lo, hi), N=cfg["N"])           # seeds = global instance ids
+    u_d_h, y_d_h = data["u_d"], data["y_d"]
+    n, m, p = cfg["n"], cfg["m"], cfg["p"]
+    up_h = u_d_h[:, -n:, :].reshape(B, -1).copy()
+    yp_h = y_d_h[:, -n:, :].reshape(B, -1).copy()
+
+    eng = BatchedDDMPC(n=n, m=m, p=p, L_=cfg["L"], N=cfg["N"], Q=cfg["Q"], R=cfg["R"], u_s=cfg["u_s"], y_s=cfg["y_s"],
+                       batch=B, controller_type=L.ROBUST, slack_type=L.SLACK_CONVEX if a.slack == "convex" else L.SLACK_NONE,
+                       eps_max=cfg["eps_max"], lamb_alpha=cfg["lamb_alpha"], lamb_sigma=cfg["lamb_sigma"], c=cfg["c"],
+                       use_terminal_constraint=cfg["tec"], device=local_rank)
+    u_d = torch.from_numpy(u_d_h).to(dev); y_d = torch.from_numpy(y_d_h).to(dev)
+    up = torch.from_numpy(up_h).to(dev); yp = torch.from_numpy(yp_h).to(dev)
+    u_opt = torch.empty((B, cfg["L"] * m), dtype=torch.float64, device=dev)
+    cost = torch.empty((B,), dtype=torch.float64, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    iters = torch.empty((B,), dtype=torch.int32, device=dev)
+    eng.set_data(u_d, y_d)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        eng.solve(up, yp, u_opt, cost, status, iters)
+    torch.cuda.synchronize()
+    # ---- timed region: exactly K steps + the final gather ------------------------
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        ev[k][0].record()                       # same stream the kernel is launched on
+        eng.solve(up, yp, u_opt, cost, status, iters)
+        ev[k][1].record()
+    if world > 1:
+        g_u, g_c, g_s = gather_results(u_opt, cost, status, total)
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    st = status.cpu().numpy()
+    n_bad = int(np.count_nonzero(st != 0))
+    if world > 1:
+        n_bad = int(np.count_nonzero(g_s.cpu().numpy() != 0))
+
+    if rank == 0:
+        flops, bytes_ = eng.cost_model()
+        achieved = flops * B / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "QP solves/sec (batched), four-tank robust DD-MPC L=30 N=400",
+            "value": total * a.steps / dt, "unit": "QP solves/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "four-tank robust DD-MPC cold solve, L=30 N=400 n=4 m=p=2, slack %s, TEC, "
+                                   "batch=%d noise seeds per GPU (BASELINE configs[1])" % (a.slack.upper(), a.batch_per_gpu),
+                       "global_batch": total, "parallelism": "instances sharded dp%d, no data-path collective, one final all-gather" % world,
+                       "kernel": eng.kernel_name(), "non_optimal_instances": n_bad},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel_ms": kern_ms, "flops_per_solve": flops, "hbm_bytes_per_solve": bytes_,
+                         "hbm_GBps_algorithmic": bytes_ * B / (kern_ms * 1e-3) / 1e9},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            ns = min(a.cpu_sample, B)
+            base, parity = cpu_baseline(cfg, u_d_h, y_d_h, up_h, yp_h, u_opt.cpu().numpy(), cost.cpu().numpy(), ns)
+            out["cpu_baseline"] = base
+            out["parity"] = parity
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

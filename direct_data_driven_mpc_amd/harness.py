@@ -1,0 +1,99 @@
+"""Host-side harness: benchmark parameters and batched synthetic-input generation.
+
+Not part of the QP hot path.  It reproduces, vectorised over a batch of seeds,
+the reference's RNG draw order for one controller instance
+(utilities/controller/controller_operation.py:59-75,126-133 and
+examples/direct_data_driven_mpc_example.py:282-287) so that instance `i` of a
+batch is the same problem the reference example would build with `--seed i`.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+# examples/config/models/four_tank_system_params.yaml:10-26
+FOUR_TANK = dict(
+    A=np.array([[0.921, 0, 0.041, 0], [0, 0.918, 0, 0.033], [0, 0, 0.924, 0], [0, 0, 0, 0.937]], float),
+    B=np.array([[0.017, 0.001], [0.001, 0.023], [0, 0.061], [0.072, 0]], float),
+    C=np.array([[1, 0, 0, 0], [0, 1, 0, 0]], float),
+    D=np.zeros((2, 2)),
+    eps_max=0.002,
+)
+
+# examples/config/controllers/data_driven_mpc_example_params.yaml:10-22
+EXAMPLE_PARAMS = dict(
+    N=400, u_d_range=(-1.0, 1.0), epsilon_bar=0.002, L=30, Q_scalar=3.0, R_scalar=1e-4,
+    lambda_sigma=1000.0, lambda_alpha_epsilon_bar=0.1, slack_var_constraint_type=0,
+    controller_type=1, n=4, u_s=(1.0, 1.0), y_s=(0.65, 0.77),
+)
+
+
+def controller_params(overrides: Optional[Dict] = None) -> Dict:
+    """Parameter derivation of utilities/controller/controller_creation.py:105-168:
+    Q = q*I, R = r*I, lamb_alpha = lambda_alpha_eps / eps (1000 if eps == 0), c = 1,
+    n_mpc_step = n; slack map {0: NONE, 1: CONVEX, 2: NON_CONVEX}, type map {0: NOMINAL, 1: ROBUST}."""
+    d = dict(EXAMPLE_PARAMS)
+    if overrides:
+        d.update(overrides)
+    eps = d["epsilon_bar"]
+    m, p = len(d["u_s"]), len(d["y_s"])
+    return dict(
+        n=d["n"], m=m, p=p, L=d["L"], N=d["N"], u_range=tuple(d["u_d_range"]),
+        Q=d["Q_scalar"], R=d["R_scalar"], eps_max=eps,
+        lamb_alpha=(d["lambda_alpha_epsilon_bar"] / eps if eps != 0 else 1000.0),
+        lamb_sigma=d["lambda_sigma"], c=1.0,
+        u_s=np.array(d["u_s"], float), y_s=np.array(d["y_s"], float),
+        robust=bool(d["controller_type"]), slack={0: "none", 1: "convex", 2: "non_convex"}[d["slack_var_constraint_type"]],
+        n_mpc_step=d["n"], tec=d.get("tec", True),
+    )
+
+
+def _observer(A, B, C, D):
+    """pinv(O) and T of the least-squares initial-state observer
+    (utilities/initial_state_estimation.py:3-24,72-93,131)."""
+    ns, m, p = A.shape[0], B.shape[1], C.shape[0]
+    O = np.vstack([C @ np.linalg.matrix_power(A, i) for i in range(ns)])
+    T = np.zeros((p * ns, m * ns))
+    for i in range(ns):
+        for j in range(i + 1):
+            blk = D if i == j else C @ np.linalg.matrix_power(A, i - j - 1) @ B
+            T[i * p:(i + 1) * p, j * m:(j + 1) * m] = blk
+    return np.linalg.pinv(O), T
+
+
+def simulate_batch(A, B, C, D, x, U, W):
+    """x+ = Ax + Bu, y = Cx + Du + w with the output taken before the state update
+    (utilities/model_simulation.py:93-98), for a batch: x [Bt,ns], U [Bt,T,m], W [Bt,T,p]."""
+    Bt, T = U.shape[0], U.shape[1]
+    Y = np.empty((Bt, T, C.shape[0]))
+    for k in range(T):
+        Y[:, k] = x @ C.T + U[:, k] @ D.T + W[:, k]
+        x = x @ A.T + U[:, k] @ B.T
+    return Y, x
+
+
+def generate_batch(seeds: Sequence[int], N: int = 400, plant: Optional[Dict] = None,
+                   u_range=(-1.0, 1.0)) -> Dict[str, np.ndarray]:
+    """Per-seed draws in the reference order, plant simulation batched.
+    Returns u_d [B,N,m], y_d [B,N,p], x_0 [B,ns], x_end [B,ns] (state after the data run)."""
+    pl = plant or FOUR_TANK
+    A, Bm, C, D, eps = pl["A"], pl["B"], pl["C"], pl["D"], pl["eps_max"]
+    ns, m, p = A.shape[0], Bm.shape[1], C.shape[0]
+    nb = len(seeds)
+    x_i0 = np.empty((nb, ns)); u_i = np.empty((nb, ns, m)); w_i = np.empty((nb, ns, p))
+    u_d = np.empty((nb, N, m)); w_d = np.empty((nb, N, p))
+    rngs = []
+    for b, s in enumerate(seeds):
+        rng = np.random.default_rng(int(s))
+        x_i0[b] = rng.uniform(-1.0, 1.0, size=ns)
+        u_i[b] = rng.uniform(*u_range, (ns, m))
+        w_i[b] = eps * rng.uniform(-1.0, 1.0, (ns, p))
+        u_d[b] = rng.uniform(*u_range, (N, m))
+        w_d[b] = eps * rng.uniform(-1.0, 1.0, (N, p))
+        rngs.append(rng)
+    y_i, _ = simulate_batch(A, Bm, C, D, x_i0, u_i, w_i)
+    Opinv, T = _observer(A, Bm, C, D)
+    x_0 = (y_i.reshape(nb, -1) - u_i.reshape(nb, -1) @ T.T) @ Opinv.T
+    y_d, x_end = simulate_batch(A, Bm, C, D, x_0, u_d, w_d)
+    return dict(u_d=u_d, y_d=y_d, x_0=x_0, x_end=x_end, rngs=rngs)

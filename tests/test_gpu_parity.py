@@ -1,0 +1,317 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle
+on identical inputs.  Tolerances (fp64): relative error of
+optimal_u <= 1e-8 (w.r.t. max|u|), relative error of the cost <= 1e-9, identical
+status; Hankel gather bit-exact."""
+import numpy as np
+import pytest
+
+from direct_data_driven_mpc_amd import _lib as L
+from direct_data_driven_mpc_amd.engine import BatchedDDMPC, hankel_matrix_batched
+from direct_data_driven_mpc_amd.harness import controller_params, generate_batch
+from oracle import ddmpc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL_U, TOL_COST = 1e-8, 1e-9
+
+
+def _engine(spec, N, B, **kw):
+    Q = np.diag(spec.Q) if kw.pop("diag", False) else spec.Q
+    R = np.diag(spec.R) if Q.ndim == 1 else spec.R
+    return BatchedDDMPC(n=spec.n, m=spec.m, p=spec.p, L_=spec.L, N=N, Q=Q, R=R, u_s=spec.u_s, y_s=spec.y_s, batch=B,
+                        controller_type=L.ROBUST if spec.robust else L.NOMINAL,
+                        slack_type=L.SLACK_CONVEX if spec.slack == "convex" else L.SLACK_NONE,
+                        eps_max=spec.eps_max, lamb_alpha=spec.lamb_alpha, lamb_sigma=spec.lamb_sigma, c=spec.c,
+                        use_terminal_constraint=spec.tec, **kw)
+
+
+def _instances(B, N=400, seed0=0):
+    d = generate_batch(range(seed0, seed0 + B), N=N)
+    n = 4
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy()
+    yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    return d["u_d"], d["y_d"], up, yp
+
+
+def _check(spec, u_d, y_d, up, yp, u, cost, status, rows):
+    for b in rows:
+        sol = orc.solve_fullspace(spec, u_d[b], y_d[b], up[b], yp[b])
+        assert L.STATUS_STRINGS[int(status[b])] == sol.status == "optimal"
+        eu = np.max(np.abs(u[b] - sol.optimal_u)) / np.max(np.abs(sol.optimal_u))
+        ec = abs(cost[b] - sol.cost) / max(abs(sol.cost), 1e-300)
+        assert eu < TOL_U, (b, eu)
+        assert ec < TOL_COST, (b, ec)
+
+
+# ---------------------------------------------------------------------------- a1
+def test_hankel_bit_exact(gpu, golden):
+    assert np.array_equal(hankel_matrix_batched(golden["kat_X"][None], 2)[0], golden["kat_H"])
+    X = np.stack([golden[f"s{s}_u_d"] for s in range(5)])
+    H = hankel_matrix_batched(X, 34)
+    assert np.array_equal(H[0], golden["s0_Hu"])
+    for s in range(5):
+        assert np.array_equal(H[s], orc.hankel_matrix(X[s], 34))
+    # ragged/edge shapes: single column (N == L), single channel, L == 1
+    for (N, nch, Lh) in ((7, 3, 7), (9, 1, 4), (5, 2, 1)):
+        Xr = np.random.default_rng(3).normal(size=(2, N, nch))
+        Hr = hankel_matrix_batched(Xr, Lh)
+        for b in range(2):
+            assert np.array_equal(Hr[b], orc.hankel_matrix(Xr[b], Lh))
+    with pytest.raises(ValueError, match="N must be greater than or equal to L"):
+        hankel_matrix_batched(np.zeros((1, 3, 2)), 4)
+
+
+def test_hankel_module_functions(gpu, golden):
+    from direct_data_driven_mpc.utilities.hankel_matrix import evaluate_persistent_excitation, hankel_matrix
+    assert np.array_equal(hankel_matrix(golden["kat_X"], 2), golden["kat_H"])
+    rank, ok = evaluate_persistent_excitation(golden["s0_u_d"], 38)
+    assert (rank, ok) == (76, True)
+    rank, ok = evaluate_persistent_excitation(np.ones((400, 2)), 38)
+    assert (rank, bool(ok)) == (int(golden["const_pe_rank"][0]), False)
+
+
+# ------------------------------------------------------------------ cold solves
+@pytest.mark.parametrize("kw", [dict(), dict(slack_var_constraint_type=1), dict(tec=False),
+                                dict(tec=False, slack_var_constraint_type=1)],
+                         ids=["robust-none-tec", "robust-convex-tec", "robust-none-ucon", "robust-convex-ucon"])
+def test_cold_solve_matches_oracle(gpu, kw):
+    spec = orc.spec_from_params(**kw)
+    B = 24
+    u_d, y_d, up, yp = _instances(B)
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(u_d, y_d)
+        u, cost, status, iters = eng.solve(up, yp)
+        assert np.all(status == 0)
+        _check(spec, u_d, y_d, up, yp, u, cost, status, range(B))
+        if spec.slack == "convex":
+            sol = orc.solve_fullspace(spec, u_d[0], y_d[0], up[0], yp[0])
+            assert int(iters[0]) == sol.iters >= 2          # the box binds at the first step (SURVEY hard parts)
+            sig = eng.get_solution("sigma")
+            assert np.max(np.abs(sig[:, 8:])) <= spec.c * spec.eps_max * (1 + 1e-12)
+        else:
+            assert np.all(iters == 1)
+
+
+def test_golden_fixture_solutions(gpu, golden):
+    for tag, kw in (("none", {}), ("convex", dict(slack_var_constraint_type=1)), ("ucon", dict(tec=False))):
+        spec = orc.spec_from_params(**kw)
+        u_d = np.stack([golden[f"s{s}_u_d"] for s in range(5)])
+        y_d = np.stack([golden[f"s{s}_y_d"] for s in range(5)])
+        up = u_d[:, -4:, :].reshape(5, -1).copy(); yp = y_d[:, -4:, :].reshape(5, -1).copy()
+        with _engine(spec, 400, 5) as eng:
+            eng.set_data(u_d, y_d)
+            u, cost, status, _ = eng.solve(up, yp)
+        for s in range(5):
+            ref = golden[f"s{s}_{tag}_u"]
+            assert np.max(np.abs(u[s] - ref)) / np.max(np.abs(ref)) < TOL_U
+            assert abs(cost[s] - golden[f"s{s}_{tag}_cost"][0]) / golden[f"s{s}_{tag}_cost"][0] < TOL_COST
+    # survey known answer + third-party solver (scipy trust-constr), looser by that solver's own accuracy
+    assert np.allclose(u[0][:2], golden["s0_ucon_u"][:2])
+    spec = orc.spec_from_params()
+    with _engine(spec, 400, 1) as eng:
+        eng.set_data(golden["s0_u_d"][None], golden["s0_y_d"][None])
+        u, cost, _, _ = eng.solve(golden["s0_u_d"][-4:].reshape(1, -1), golden["s0_y_d"][-4:].reshape(1, -1))
+    assert np.allclose(u[0, :2], [21.22188171, 20.30350327], atol=5e-9) and abs(cost[0] - 4.543214030) < 5e-10
+    assert np.max(np.abs(u[0] - golden["scipy_s0_none_u"])) / np.max(np.abs(u[0])) < 1e-7
+
+
+def test_nominal_known_answer(gpu):
+    # BASELINE configs[0]: nominal + noisy (full-row-rank) Hankel => optimal_u == tile(u_s, L), cost == 0
+    spec = orc.spec_from_params(controller_type=0)
+    B = 6
+    u_d, y_d, up, yp = _instances(B)
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(u_d, y_d)
+        u, cost, status, _ = eng.solve(up, yp)
+        ub = eng.get_solution("ubar"); yb = eng.get_solution("ybar")
+    assert np.all(status == 0)
+    assert np.max(np.abs(u - np.tile(spec.u_s, spec.L))) < 1e-12
+    assert np.max(np.abs(cost)) < 1e-12
+    assert np.max(np.abs(ub[:, :8] - up)) < 1e-12 and np.max(np.abs(yb[:, :8] - yp)) < 1e-12
+    for b in range(B):   # oracle's min-norm solve is the less accurate side here
+        sol = orc.solve_fullspace(spec, u_d[b], y_d[b], up[b], yp[b])
+        assert np.max(np.abs(u[b] - sol.optimal_u)) < 1e-7
+
+
+def test_diagonal_weights_and_setpoint_change(gpu):
+    spec = orc.spec_from_params()
+    rng = np.random.default_rng(5)
+    spec.Q = np.diag(rng.uniform(1.0, 5.0, spec.p * spec.L))
+    spec.R = np.diag(rng.uniform(5e-5, 5e-4, spec.m * spec.L))
+    B = 6
+    u_d, y_d, up, yp = _instances(B, seed0=100)
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(u_d, y_d)
+        u, cost, status, _ = eng.solve(up, yp)
+        _check(spec, u_d, y_d, up, yp, u, cost, status, range(B))
+        spec.u_s = np.array([0.8, 1.1]); spec.y_s = np.array([0.5, 0.9])
+        eng.set_setpoints(spec.u_s, spec.y_s)                      # controller.py:945-982
+        u, cost, status, _ = eng.solve(up, yp)
+        _check(spec, u_d, y_d, up, yp, u, cost, status, range(B))
+
+
+@pytest.mark.parametrize("Lh,N,slack", [(10, 120, 0), (10, 120, 1), (16, 200, 0), (22, 300, 1), (8, 60, 0)])
+def test_other_sizes(gpu, Lh, N, slack):
+    # exercises the 5-, 7- and 9-tile-row kernel instances and ragged last k-steps
+    spec = orc.spec_from_params(L=Lh, N=N, slack_var_constraint_type=slack)
+    B = 5
+    u_d, y_d, up, yp = _instances(B, N=N, seed0=40)
+    with _engine(spec, N, B) as eng:
+        eng.set_data(u_d, y_d)
+        u, cost, status, _ = eng.solve(up, yp)
+    _check(spec, u_d, y_d, up, yp, u, cost, status, range(B))
+
+
+def test_siso_system_with_padded_rows(gpu):
+    # m = p = 1, n = 2, L = 5: r = 14 is not a multiple of 4 -> dummy identity rows, smallest kernels
+    A = np.array([[0.9, 0.2], [0.0, 0.7]]); Bm = np.array([[0.0], [1.0]]); C = np.array([[1.0, 0.0]]); D = np.zeros((1, 1))
+    plant = dict(A=A, B=Bm, C=C, D=D, eps_max=0.001)
+    for Lh, n in ((5, 2), (9, 2), (4, 2)):
+        spec = orc.QPSpec(n=n, m=1, p=1, L=Lh, Q=2.0 * np.eye(Lh), R=0.01 * np.eye(Lh), u_s=np.array([0.3]),
+                          y_s=np.array([1.0]), robust=True, eps_max=0.001, lamb_alpha=100.0, lamb_sigma=500.0, c=1.0,
+                          slack="convex", tec=True)
+        B, N = 4, 80
+        d = generate_batch(range(B), N=N, plant=plant)
+        up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+        with _engine(spec, N, B) as eng:
+            eng.set_data(d["u_d"], d["y_d"])
+            u, cost, status, _ = eng.solve(up, yp)
+        _check(spec, d["u_d"], d["y_d"], up, yp, u, cost, status, range(B))
+
+
+def test_variables_and_kkt_certificate(gpu):
+    # alpha/ubar/ybar/sigma read back from the GPU must themselves satisfy the KKT
+    # conditions of the reference's full-space QP (solver-independent check)
+    for kw in (dict(), dict(slack_var_constraint_type=1)):
+        spec = orc.spec_from_params(**kw)
+        B = 3
+        u_d, y_d, up, yp = _instances(B, seed0=7)
+        with _engine(spec, 400, B) as eng:
+            eng.set_data(u_d, y_d)
+            eng.solve(up, yp)
+            al, ub, yb, sg = (eng.get_solution(k) for k in ("alpha", "ubar", "ybar", "sigma"))
+        for b in range(B):
+            x = np.concatenate([al[b], ub[b], yb[b], sg[b]])
+            cert = orc.kkt_certificate(spec, u_d[b], y_d[b], up[b], yp[b], x, act_tol=1e-12)
+            assert cert["res_eq"] < 1e-9 and cert["res_box"] < 1e-15, cert
+            assert cert["res_stat"] < 1e-8 * max(1.0, cert["grad_scale"]) and cert["dual_sign"] < 1e-9, cert
+            sol = orc.solve_fullspace(spec, u_d[b], y_d[b], up[b], yp[b])
+            assert np.max(np.abs(al[b] - sol.alpha)) < 1e-9 and np.max(np.abs(sg[b] - sol.sigma)) < 1e-10
+
+
+def test_bad_instance_gets_status_not_exception(gpu):
+    # a constant (non-exciting) trajectory makes G singular: that instance must come back
+    # "solver_error" while its batch neighbours are solved normally
+    spec = orc.spec_from_params(controller_type=0)
+    B = 4
+    u_d, y_d, up, yp = _instances(B)
+    u_d = u_d.copy(); y_d = y_d.copy()
+    u_d[2] = 1.0; y_d[2] = 0.5
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(u_d, y_d)
+        u, cost, status, _ = eng.solve(up, yp)
+    assert L.STATUS_STRINGS[int(status[2])] == "solver_error"
+    assert [int(s) for s in status[[0, 1, 3]]] == [0, 0, 0]
+    assert np.max(np.abs(u[[0, 1, 3]] - 1.0)) < 1e-12
+
+
+# ----------------------------------------------- full-size, size-independent properties
+def test_full_batch_properties(gpu):
+    """BASELINE configs[1] size (B = 4096): all optimal; batch-composition independence
+    (bit-exact); device-pointer path == host-pointer path (bit-exact); affine dependence
+    of optimal_u on the past window for slack NONE."""
+    torch = pytest.importorskip("torch")
+    spec = orc.spec_from_params()
+    B = 4096
+    u_d, y_d, up, yp = _instances(B)
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(u_d, y_d)
+        u, cost, status, iters = eng.solve(up, yp)
+        assert np.all(status == 0) and np.all(iters == 1) and np.all(np.isfinite(u)) and np.all(cost > 0)
+        _check(spec, u_d, y_d, up, yp, u, cost, status, [0, 1, 2047, 4095])
+        # affine in (u_past, y_past)
+        rng = np.random.default_rng(0)
+        up2 = up + 0.1 * rng.normal(size=up.shape); yp2 = yp + 0.01 * rng.normal(size=yp.shape)
+        u2, _, _, _ = eng.solve(up2, yp2)
+        um, _, _, _ = eng.solve(0.5 * (up + up2), 0.5 * (yp + yp2))
+        assert np.max(np.abs(um - 0.5 * (u + u2))) / np.max(np.abs(u)) < 1e-9
+        # device-resident buffers (torch) give the same bits as the host path
+        dev = torch.device("cuda", 0)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        eng.set_data(t(u_d), t(y_d))
+        ud_, cd_, sd_, _ = eng.solve(t(up), t(yp))
+        torch.cuda.synchronize()
+        assert np.array_equal(ud_.cpu().numpy(), u) and np.array_equal(cd_.cpu().numpy(), cost)
+    sub = slice(1000, 1016)
+    with _engine(spec, 400, 16) as eng:
+        eng.set_data(u_d[sub], y_d[sub])
+        us, cs, _, _ = eng.solve(up[sub], yp[sub])
+    assert np.array_equal(us, u[sub]) and np.array_equal(cs, cost[sub])
+
+
+# -------------------------------------------------------- the class mirror (batch = 1)
+def _controller(kind="robust", slack="none", seed=0, **over):
+    from direct_data_driven_mpc.direct_data_driven_mpc_controller import (
+        DataDrivenMPCType, DirectDataDrivenMPCController, SlackVarConstraintTypes)
+    cfg = controller_params()
+    inst = orc.generate_instance(seed)
+    kw = dict(n=cfg["n"], m=cfg["m"], p=cfg["p"], u_d=inst["u_d"], y_d=inst["y_d"], L=cfg["L"],
+              Q=cfg["Q"] * np.eye(cfg["p"] * cfg["L"]), R=cfg["R"] * np.eye(cfg["m"] * cfg["L"]),
+              u_s=cfg["u_s"].reshape(-1, 1), y_s=cfg["y_s"].reshape(-1, 1), eps_max=cfg["eps_max"],
+              lamb_alpha=cfg["lamb_alpha"], lamb_sigma=cfg["lamb_sigma"], c=cfg["c"],
+              slack_var_constraint_type={"none": SlackVarConstraintTypes.NONE, "convex": SlackVarConstraintTypes.CONVEX,
+                                         "non_convex": SlackVarConstraintTypes.NON_CONVEX}[slack],
+              controller_type=DataDrivenMPCType.ROBUST if kind == "robust" else DataDrivenMPCType.NOMINAL,
+              n_mpc_step=cfg["n_mpc_step"])
+    kw.update(over)
+    return DirectDataDrivenMPCController(**kw), inst
+
+
+def test_controller_class_construct_and_errors(gpu):
+    ctrl, inst = _controller()
+    assert ctrl.get_problem_solve_status() == "optimal"
+    assert ctrl.optimal_u.shape == (60,)
+    assert np.allclose(ctrl.get_optimal_control_input_at_step(0), [21.22188171, 20.30350327], atol=5e-9)
+    assert abs(ctrl.get_optimal_cost_value() - 4.543214030) < 5e-10
+    assert ctrl.HLn_ud.shape == (68, 367) and np.array_equal(ctrl.HLn_yd, orc.hankel_matrix(inst["y_d"], 34))
+    assert ctrl.alpha.value.shape == (367, 1) and ctrl.sigma.value.shape == (68, 1)
+    assert np.allclose(ctrl.ubar.value[8:, 0], ctrl.optimal_u)
+    with pytest.raises(ValueError, match=r"out of range. It should be within \[0, 29\]"):
+        ctrl.get_optimal_control_input_at_step(30)
+    with pytest.raises(ValueError, match="Incorrect dimensions"):
+        ctrl.store_input_output_measurement(np.zeros(2), np.zeros((2, 1)))
+    with pytest.raises(ValueError, match="u_past must be shaped"):
+        ctrl.set_past_input_output_data(np.zeros((7, 1)), np.zeros((8, 1)))
+    with pytest.raises(ValueError, match="u_s must have shape"):
+        ctrl.set_input_output_setpoints(np.zeros(2), np.zeros((2, 1)))
+    with pytest.raises(NotImplementedError, match="Non-Convex slack variable"):
+        _controller(slack="non_convex")
+    with pytest.raises(ValueError, match="not persistently exciting"):
+        _controller(u_d=np.ones((400, 2)))
+    with pytest.raises(ValueError, match="two times the estimated"):
+        _controller(L=6, Q=3 * np.eye(12), R=1e-4 * np.eye(12))
+    with pytest.raises(ValueError, match="Output weighting square matrix Q"):
+        _controller(Q=np.eye(10))
+    nom, _ = _controller(kind="nominal")
+    assert np.allclose(nom.optimal_u, 1.0, atol=1e-12) and abs(nom.get_optimal_cost_value()) < 1e-12
+
+
+@pytest.mark.parametrize("slack,n_mpc_step", [("none", 4), ("convex", 1)])
+def test_controller_closed_loop_matches_oracle(gpu, slack, n_mpc_step):
+    # the loop of utilities/controller/controller_operation.py:259-305 driven through the class
+    # mirror on the GPU vs the same loop on the CPU oracle, identical noise
+    ctrl, inst = _controller(slack=slack, n_mpc_step=n_mpc_step)
+    plant_gpu = orc.Plant(**orc.FOUR_TANK); plant_gpu.x = inst["plant"].x.copy()
+    n_steps = 24
+    w = plant_gpu.eps_max * inst["rng"].uniform(-1.0, 1.0, (n_steps, 2))
+    u_sys = np.zeros((n_steps, 2)); y_sys = np.zeros((n_steps, 2))
+    for t in range(0, n_steps, ctrl.n_mpc_step):
+        ctrl.update_and_solve_data_driven_mpc()
+        for k in range(t, min(t + ctrl.n_mpc_step, n_steps)):
+            u_sys[k] = ctrl.get_optimal_control_input_at_step(n_step=k - t)
+            y_sys[k] = plant_gpu.step(u_sys[k], w[k])
+            ctrl.store_input_output_measurement(u_sys[k].reshape(-1, 1), y_sys[k].reshape(-1, 1))
+    spec = orc.spec_from_params(slack_var_constraint_type=1 if slack == "convex" else 0)
+    u_ref, y_ref = orc.closed_loop(spec, inst["u_d"], inst["y_d"], inst["plant"], w, n_mpc_step=n_mpc_step)
+    assert np.max(np.abs(u_sys - u_ref)) / np.max(np.abs(u_ref)) < 1e-8
+    assert np.max(np.abs(y_sys - y_ref)) < 1e-9

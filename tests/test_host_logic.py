@@ -1,0 +1,87 @@
+"""CPU tests of the host-side logic that needs no device: argument checks of the
+class mirror that run before any GPU call, weight handling, sharding, harness."""
+import numpy as np
+import pytest
+
+from direct_data_driven_mpc_amd import _lib as L
+from direct_data_driven_mpc_amd.direct_data_driven_mpc_controller import (
+    DataDrivenMPCType, DirectDataDrivenMPCController, SlackVarConstraintTypes)
+from direct_data_driven_mpc_amd.distributed import shard_bounds
+from direct_data_driven_mpc_amd.engine import _weights
+from direct_data_driven_mpc_amd.harness import controller_params, generate_batch
+
+
+def _kw(**over):
+    rng = np.random.default_rng(1)
+    kw = dict(n=4, m=2, p=2, u_d=rng.uniform(-1, 1, (400, 2)), y_d=rng.uniform(-1, 1, (400, 2)), L=30,
+              Q=3 * np.eye(60), R=1e-4 * np.eye(60), u_s=np.ones((2, 1)), y_s=np.array([[0.65], [0.77]]),
+              eps_max=0.002, lamb_alpha=50.0, lamb_sigma=1000.0, c=1.0,
+              slack_var_constraint_type=SlackVarConstraintTypes.NONE, controller_type=DataDrivenMPCType.ROBUST)
+    kw.update(over)
+    return kw
+
+
+def test_enum_quirks_match_reference():
+    # direct_data_driven_mpc_controller.py:11-20 (trailing commas make tuple values)
+    assert DataDrivenMPCType.NOMINAL.value == (0,) and DataDrivenMPCType.ROBUST.value == 1
+    assert SlackVarConstraintTypes.NON_CONVEX.value == (0,) and SlackVarConstraintTypes.CONVEX.value == (1,)
+    assert SlackVarConstraintTypes.NONE.value == 2
+
+
+def test_constructor_rejections_before_any_device_work():
+    with pytest.raises(ValueError, match="Unsupported controller type."):
+        DirectDataDrivenMPCController(**_kw(controller_type="robust"))
+    with pytest.raises(ValueError, match="Unsupported slack variable constraint type."):
+        DirectDataDrivenMPCController(**_kw(slack_var_constraint_type=2))
+    with pytest.raises(ValueError, match="All robust MPC parameters"):
+        DirectDataDrivenMPCController(**_kw(lamb_sigma=None))
+    with pytest.raises(ValueError, match="should match the number of inputs"):
+        DirectDataDrivenMPCController(**_kw(m=3))
+    with pytest.raises(ValueError, match="required minimum N is 113, but got 100"):
+        kw = _kw()
+        kw["u_d"], kw["y_d"] = kw["u_d"][:100], kw["y_d"][:100]
+        DirectDataDrivenMPCController(**kw)
+
+
+def test_compat_import_paths():
+    from direct_data_driven_mpc.direct_data_driven_mpc_controller import DirectDataDrivenMPCController as C2
+    from direct_data_driven_mpc.utilities.hankel_matrix import evaluate_persistent_excitation, hankel_matrix
+    assert C2 is DirectDataDrivenMPCController
+    assert callable(hankel_matrix) and callable(evaluate_persistent_excitation)
+
+
+def test_weight_handling():
+    assert _weights(3.0, 60, "Q")[0] == L.WEIGHT_SCALAR
+    k, v = _weights(3 * np.eye(60), 60, "Q")
+    assert k == L.WEIGHT_SCALAR and v.tolist() == [3.0]
+    d = np.linspace(1, 2, 60)
+    k, v = _weights(np.diag(d), 60, "Q")
+    assert k == L.WEIGHT_DIAG and np.array_equal(v, d)
+    with pytest.raises(NotImplementedError):
+        _weights(np.eye(60) + 0.1, 60, "Q")
+    with pytest.raises(ValueError):
+        _weights(np.eye(59), 60, "Q")
+
+
+def test_shard_bounds_cover_batch_exactly():
+    for total in (1, 7, 4096, 262144, 10):
+        for world in (1, 2, 3, 8):
+            edges = [shard_bounds(total, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == total
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+
+
+def test_harness_parameters_and_batched_generation(golden):
+    cfg = controller_params()
+    assert cfg["lamb_alpha"] == pytest.approx(50.0) and cfg["c"] == 1.0 and cfg["n_mpc_step"] == 4
+    assert cfg["robust"] and cfg["slack"] == "none"
+    assert controller_params(dict(epsilon_bar=0.0))["lamb_alpha"] == 1000.0
+    d = generate_batch(range(5))
+    for s in range(5):
+        assert np.array_equal(d["u_d"][s], golden[f"s{s}_u_d"])          # RNG stream identical
+        assert np.max(np.abs(d["y_d"][s] - golden[f"s{s}_y_d"])) < 1e-14  # batched matmul: last-ulp only
+        assert np.max(np.abs(d["x_0"][s] - golden[f"s{s}_x0"])) < 1e-14
