@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=4096)
     ap.add_argument("--slack", choices=["none", "convex"], default="none")
-    ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
