@@ -25,7 +25,7 @@ SOL_ALPHA, SOL_UBAR, SOL_YBAR, SOL_SIGMA = 0, 1, 2, 3
 EXPORTS = (
     "ddmpc_version", "ddmpc_last_error", "ddmpc_device_count", "ddmpc_create", "ddmpc_destroy",
     "ddmpc_set_stream", "ddmpc_synchronize", "ddmpc_set_data", "ddmpc_solve", "ddmpc_set_setpoints",
-    "ddmpc_get_solution", "ddmpc_hankel", "ddmpc_cost_model", "ddmpc_kernel_name",
+    "ddmpc_get_solution", "ddmpc_hankel", "ddmpc_cost_model", "ddmpc_kernel_name", "ddmpc_debug_stamps",
 )
 
 c_double_p = C.POINTER(C.c_double)
@@ -81,6 +81,8 @@ def load() -> C.CDLL:
     lib.ddmpc_cost_model.argtypes = [vp, c_double_p, c_double_p]
     lib.ddmpc_kernel_name.argtypes = [vp]
     lib.ddmpc_kernel_name.restype = C.c_char_p
+    lib.ddmpc_debug_stamps.argtypes = [vp, C.c_int, vp]
+    lib.ddmpc_debug_stamps.restype = C.c_int
     for name in ("ddmpc_create", "ddmpc_destroy", "ddmpc_set_stream", "ddmpc_synchronize", "ddmpc_set_data",
                  "ddmpc_solve", "ddmpc_set_setpoints", "ddmpc_get_solution", "ddmpc_hankel", "ddmpc_cost_model"):
         getattr(lib, name).restype = C.c_int

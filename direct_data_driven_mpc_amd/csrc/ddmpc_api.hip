@@ -20,7 +20,7 @@ namespace ddmpc {
 #define DDMPC_INSTANCE(NT, W)                                                                        \
   extern template __global__ void ddmpc_cold_solve_kernel<NT, W>(                                    \
       KParams, const double*, const double*, const double*, const double*, double*, double*, int*,  \
-      int*, double*, signed char*);
+      int*, double*, signed char*, unsigned long long*);
 #include "ddmpc_instances.inc"
 #undef DDMPC_INSTANCE
 }  // namespace ddmpc
@@ -67,7 +67,7 @@ struct DevBuf {
 };
 
 typedef void (*cold_kernel_t)(KParams, const double*, const double*, const double*, const double*, double*,
-                              double*, int*, int*, double*, signed char*);
+                              double*, int*, int*, double*, signed char*, unsigned long long*);
 
 struct KernelChoice {
   int NT, W;
@@ -88,7 +88,7 @@ const KernelChoice kKernels[] = {
 size_t lds_doubles_for(int NT, int xs_len) {
   switch (NT) {
 #define DDMPC_INSTANCE(NT_, W_) \
-  case NT_: return (size_t)Lds<NT_>(xs_len).total;
+  case NT_: return (size_t)Lds<NT_>::total(xs_len);
 #include "ddmpc_instances.inc"
 #undef DDMPC_INSTANCE
     default: return 0;
@@ -109,13 +109,14 @@ struct ddmpc_handle {
   bool own_stream = false;
   bool have_data = false, solved = false;
   // parameter tables on device
-  DevBuf d_q, d_r, d_us, d_ys;
+  DevBuf d_tabd, d_tabi;
   // data (owned copies when the caller passed host memory)
   DevBuf d_ud, d_yd;
   const double* ud = nullptr;
   const double* yd = nullptr;
   // staging for host-memory solves + workspace for get_solution
-  DevBuf d_up, d_yp, d_uopt, d_cost, d_status, d_iters, d_beta, d_act, d_out;
+  DevBuf d_up, d_yp, d_uopt, d_cost, d_status, d_iters, d_beta, d_act, d_out, d_stamps;
+  bool stamps_on = false;
   const double* last_up = nullptr;
   const double* last_yp = nullptr;
 };
@@ -132,24 +133,65 @@ int ddmpc_device_count(void) {
   return n;
 }
 
+// Per-component tables of the reduced system, shared by the whole batch.
+// Row rho = k*nch + ch of the internal ordering; see KParams in ddmpc_kernels.hpp.
+//   ubar, internal window (controller.py:577) / terminal window (:612,620): hard value  -> D = 0
+//   ubar, free prediction steps: penalty r (:709)                                       -> D = 1/r
+//   w = ybar + sigma, internal window: sigma free, ybar = y_past (:578)                 -> D = 1/lamb_sigma
+//   w, terminal window: ybar = y_s (:615,621), sigma = w - y_s boxed (:659,674)          -> D = 1/lamb_sigma | 0
+//   w, free prediction steps: q (ybar - y_s)^2 + lamb_sigma sigma^2 (:710,716), boxed   -> D = 1/q + 1/lamb_sigma | 1/q
+//   nominal scheme: no sigma (:536-538); ybar rows behave like ubar rows with weight q.
 static int upload_params(ddmpc_handle* h) {
   const ddmpc_params& p = h->prm;
-  int rc;
-  if ((rc = h->d_us.ensure(sizeof(double) * p.m))) return rc;
-  if ((rc = h->d_ys.ensure(sizeof(double) * p.p))) return rc;
-  HIP_TRY(hipMemcpyAsync(h->d_us.p, h->us_h.data(), sizeof(double) * p.m, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->d_ys.p, h->ys_h.data(), sizeof(double) * p.p, hipMemcpyHostToDevice, h->stream));
-  if (p.weight_kind == DDMPC_WEIGHT_DIAG) {
-    if ((rc = h->d_q.ensure(sizeof(double) * h->Qh.size()))) return rc;
-    if ((rc = h->d_r.ensure(sizeof(double) * h->Rh.size()))) return rc;
-    HIP_TRY(hipMemcpyAsync(h->d_q.p, h->Qh.data(), sizeof(double) * h->Qh.size(), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->d_r.p, h->Rh.data(), sizeof(double) * h->Rh.size(), hipMemcpyHostToDevice, h->stream));
+  const KParams& k = h->kp;
+  const int RP = 16 * h->kc.NT;
+  std::vector<double> td(4 * (size_t)RP, 0.0);
+  std::vector<int> ti(3 * (size_t)RP, -1);
+  const bool robust = p.controller_type == DDMPC_ROBUST;
+  const bool tec = p.use_terminal_constraint != 0;
+  const bool diag = p.weight_kind == DDMPC_WEIGHT_DIAG;
+  for (int rho = 0; rho < RP; ++rho) {
+    double D0 = 0, D1 = 0, tb = 0, wq = 0;
+    int kind = K_PAD, pidx = -1, oidx = -1;
+    if (rho < k.r) {
+      const int kk = rho / k.nch, ch = rho % k.nch;
+      const int kp = kk - p.n;
+      const bool is_int = kp < 0;
+      const bool is_term = tec && kp >= p.L - p.n;
+      if (ch < p.m) {
+        tb = h->us_h[ch];
+        if (is_int) { kind = K_UFIX; pidx = kk * p.m + ch; }
+        else if (is_term) { kind = K_UFIX; }
+        else { kind = K_UFREE; wq = diag ? h->Rh[kp * p.m + ch] : h->Rh[0]; D0 = D1 = 1.0 / wq; }
+        if (!is_int) oidx = kp * p.m + ch;
+      } else {
+        const int cy = ch - p.m;
+        tb = h->ys_h[cy];
+        const double q = is_int ? 0.0 : (diag ? h->Qh[kp * p.p + cy] : h->Qh[0]);
+        wq = q;
+        if (!robust) {
+          if (is_int) { kind = K_YFIX; pidx = p.n * p.m + kk * p.p + cy; }
+          else if (is_term) { kind = K_YFIX; }
+          else { kind = K_YFREE; D0 = D1 = 1.0 / q; }
+        } else {
+          const double ils = 1.0 / p.lamb_sigma;
+          if (is_int) { kind = K_WINT; pidx = p.n * p.m + kk * p.p + cy; D0 = D1 = ils; }
+          else if (is_term) { kind = K_WTERM; D0 = ils; D1 = 0.0; }
+          else { kind = K_WPRED; D0 = 1.0 / q + ils; D1 = 1.0 / q; }
+        }
+      }
+    }
+    td[0 * RP + rho] = D0; td[1 * RP + rho] = D1; td[2 * RP + rho] = tb; td[3 * RP + rho] = wq;
+    ti[0 * RP + rho] = kind; ti[1 * RP + rho] = pidx; ti[2 * RP + rho] = oidx;
   }
+  int rc;
+  if ((rc = h->d_tabd.ensure(td.size() * sizeof(double)))) return rc;
+  if ((rc = h->d_tabi.ensure(ti.size() * sizeof(int)))) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_tabd.p, td.data(), td.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_tabi.p, ti.data(), ti.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  h->kp.u_s = (const double*)h->d_us.p;
-  h->kp.y_s = (const double*)h->d_ys.p;
-  h->kp.qdiag = (const double*)h->d_q.p;
-  h->kp.rdiag = (const double*)h->d_r.p;
+  h->kp.tabd = (const double*)h->d_tabd.p;
+  h->kp.tabi = (const int*)h->d_tabi.p;
   return DDMPC_OK;
 }
 
@@ -217,22 +259,28 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   h->device = device;
 
   KParams& k = h->kp;
-  k.m = p.m; k.p = p.p; k.n = p.n; k.L = p.L; k.N = p.N;
+  k.N = p.N; k.m = p.m; k.p = p.p;
   k.nch = p.m + p.p;
   k.Ln = p.L + p.n;
   k.r = k.nch * k.Ln;
   k.rE = (k.r + 3) & ~3;
   k.c = p.N - k.Ln + 1;
-  k.robust = p.controller_type == DDMPC_ROBUST;
-  k.convex = k.robust && p.slack_type == DDMPC_SLACK_CONVEX;
-  k.tec = p.use_terminal_constraint != 0;
-  k.weight_diag = p.weight_kind == DDMPC_WEIGHT_DIAG;
-  k.q_scalar = h->Qh[0];
-  k.r_scalar = h->Rh[0];
-  k.lam = k.robust ? p.lamb_alpha * p.eps_max : 0.0;
-  k.lamb_sigma = k.robust ? p.lamb_sigma : 1.0;
+  k.npu = p.n * p.m;
+  const bool robust_ = p.controller_type == DDMPC_ROBUST;
+  k.convex = robust_ && p.slack_type == DDMPC_SLACK_CONVEX;
+  k.lam = robust_ ? p.lamb_alpha * p.eps_max : 0.0;
+  k.lamb_sigma = robust_ ? p.lamb_sigma : 1.0;
   k.bound = k.convex ? p.c * p.eps_max : 0.0;
   k.max_iter = p.max_iter > 0 ? p.max_iter : 50;
+  if (p.gram_mode == DDMPC_GRAM_STRUCTURED && k.nch != 4) {
+    delete h;
+    return fail(DDMPC_ERR_UNSUPPORTED, "DDMPC_GRAM_STRUCTURED needs m + p == 4 (got %d); use DDMPC_GRAM_AUTO", k.nch);
+  }
+  if (p.gram_mode != DDMPC_GRAM_AUTO && p.gram_mode != DDMPC_GRAM_DENSE && p.gram_mode != DDMPC_GRAM_STRUCTURED) {
+    delete h;
+    return fail(DDMPC_ERR_INVALID, "unknown gram_mode %d", p.gram_mode);
+  }
+  k.gram_dense = (p.gram_mode == DDMPC_GRAM_DENSE || k.nch != 4) ? 1 : 0;
 
   const int rows_needed = k.rE + 1;
   const KernelChoice* kc = nullptr;
@@ -243,8 +291,10 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
     return fail(DDMPC_ERR_UNSUPPORTED, "problem too large for the single-workgroup kernels: (m+p)(L+n) = %d rows", k.r);
   }
   h->kc = *kc;
-  k.xs_len = ((p.N - k.Ln + 3) * k.nch + 16 * kc->NT + 1) & ~1;
-  if (k.xs_len < p.N * k.nch) k.xs_len = (p.N * k.nch + 1) & ~1;
+  // dense-Gram operand reads reach (c+2)*nch + 16*NT; the structured walks read up to
+  // x[c + 4*NT + 2]; everything past N*nch is zero padding
+  k.xs_len = ((p.N - k.Ln + 4) * k.nch + 16 * kc->NT + 8 + 1) & ~1;
+  if (k.xs_len < (p.N + 2) * k.nch) k.xs_len = ((p.N + 2) * k.nch + 1) & ~1;
   const size_t lds_doubles = lds_doubles_for(kc->NT, k.xs_len);
   h->lds_bytes = lds_doubles * sizeof(double);
   if (h->lds_bytes > 160 * 1024) {
@@ -273,8 +323,8 @@ int ddmpc_destroy(ddmpc_handle* h) {
   if (!h) return DDMPC_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  DevBuf* bufs[] = {&h->d_q, &h->d_r, &h->d_us, &h->d_ys, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
-                    &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out};
+  DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
+                    &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps};
   for (DevBuf* b : bufs) b->release();
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -330,7 +380,8 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
   if ((rc = h->d_act.ensure((size_t)h->batch * h->kp.rE))) return rc;
   dim3 grid((unsigned)h->batch), block(64 * h->kc.W);
   hipLaunchKernelGGL(h->kc.fn, grid, block, h->lds_bytes, h->stream, h->kp, h->ud, h->yd, up, yp, uo, cost,
-                     (int*)status, (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p);
+                     (int*)status, (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p,
+                     h->stamps_on ? (unsigned long long*)h->d_stamps.p : (unsigned long long*)nullptr);
   HIP_TRY(hipGetLastError());
   return DDMPC_OK;
 }
@@ -401,7 +452,7 @@ int ddmpc_get_solution(ddmpc_handle* h, int what, double* out, int mem) {
     case DDMPC_SOL_UBAR: per = (size_t)k.Ln * k.m; break;
     case DDMPC_SOL_YBAR: per = (size_t)k.Ln * k.p; break;
     case DDMPC_SOL_SIGMA:
-      if (!k.robust) return fail(DDMPC_ERR_INVALID, "sigma exists only for a robust controller");
+      if (h->prm.controller_type != DDMPC_ROBUST) return fail(DDMPC_ERR_INVALID, "sigma exists only for a robust controller");
       per = (size_t)k.Ln * k.p;
       break;
     default: return fail(DDMPC_ERR_INVALID, "unknown solution selector %d", what);
@@ -413,7 +464,7 @@ int ddmpc_get_solution(ddmpc_handle* h, int what, double* out, int mem) {
     if (rc) return rc;
     dst = (double*)h->d_out.p;
   }
-  hipLaunchKernelGGL(ddmpc_reconstruct_kernel, dim3((unsigned)h->batch), dim3(256), 0, h->stream, k, what, h->ud,
+  hipLaunchKernelGGL(ddmpc_reconstruct_kernel, dim3((unsigned)h->batch), dim3(256), 0, h->stream, k, 16 * h->kc.NT, what, h->ud,
                      h->yd, h->last_up, h->last_yp, (const double*)h->d_beta.p, (const signed char*)h->d_act.p, dst);
   HIP_TRY(hipGetLastError());
   if (mem == DDMPC_MEM_HOST) {
@@ -458,15 +509,36 @@ int ddmpc_cost_model(ddmpc_handle* h, double* flops_per_solve, double* bytes_per
   if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
   const KParams& k = h->kp;
   const double r = k.r, c = k.c;
-  // Dense symmetric Gram (multiply-add = 2 flops, half the entries) + Cholesky of the
-  // r x r reduced system + forward/back substitution (DESIGN.md "Roofline accounting").
-  if (flops_per_solve) *flops_per_solve = r * r * c + r * r * r / 3.0 + 2.0 * r * r;
+  // Gram + Cholesky of the r x r reduced system + forward/back substitution
+  // (DESIGN.md "Roofline accounting").  Dense Gram: symmetric H H', multiply-add = 2
+  // flops, half the entries.  Structured Gram: nch^2*(L+n) base dot products of length c
+  // plus the 4-flop sliding-window update of every entry of the lower triangle.
+  const double gram = k.gram_dense ? r * r * c : 2.0 * k.nch * k.nch * (double)k.Ln * c + 4.0 * r * r / 2.0;
+  if (flops_per_solve) *flops_per_solve = gram + r * r * r / 3.0 + 2.0 * r * r;
   // compulsory HBM traffic: trajectories in, past window in, optimal_u + cost + status out
   if (bytes_per_solve)
-    *bytes_per_solve = 8.0 * ((double)k.N * k.nch + (double)k.n * k.nch + (double)k.L * k.m + 1.0) + 4.0;
+    *bytes_per_solve = 8.0 * ((double)k.N * k.nch + (double)h->prm.n * k.nch + (double)h->prm.L * k.m + 1.0) + 4.0;
   return DDMPC_OK;
 }
 
 const char* ddmpc_kernel_name(ddmpc_handle* h) { return h ? h->kc.name : ""; }
+
+int ddmpc_debug_stamps(ddmpc_handle* h, int enable, uint64_t* out) {
+  if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t bytes = (size_t)h->batch * 16 * sizeof(uint64_t);
+  if (out) {
+    if (!h->stamps_on || !h->d_stamps.p) return fail(DDMPC_ERR_NOT_READY, "stamps were not enabled");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out, h->d_stamps.p, bytes, hipMemcpyDeviceToHost));
+  }
+  if (enable) {
+    int rc = h->d_stamps.ensure(bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(h->d_stamps.p, 0, bytes, h->stream));
+  }
+  h->stamps_on = enable != 0;
+  return DDMPC_OK;
+}
 
 }  // extern "C"

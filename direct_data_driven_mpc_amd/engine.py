@@ -205,6 +205,13 @@ class BatchedDDMPC:
         L.check(self._lib.ddmpc_cost_model(self._h, C.byref(f), C.byref(b)))
         return f.value, b.value
 
+    def debug_stamps(self, enable: bool = True, fetch: bool = False):
+        """Diagnostics: enable in-kernel phase stamps / fetch those of the last solve ([batch,16] uint64)."""
+        out = np.zeros((self.batch, 16), dtype=np.uint64) if fetch else None
+        L.check(self._lib.ddmpc_debug_stamps(self._h, 1 if enable else 0,
+                                             C.c_void_p(out.ctypes.data) if fetch else C.c_void_p()))
+        return out
+
     def kernel_name(self) -> str:
         return self._lib.ddmpc_kernel_name(self._h).decode()
 

@@ -174,7 +174,9 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
   int* act = reinterpret_cast<int*>(sm + LD::ints);
   int* flags = act + RP;            // [0] fail, [1] active set changed
 
-  const int tid0 = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lo = l15 >> 2;
   const int r = P.r, rE = P.rE, nch = P.nch;
   const int NS = rE >> 2;           // panel steps
   const int IR = rE >> 4;           // tile row holding the rhs row (row index rE)
@@ -187,7 +189,7 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
   double cD0[NE], cD1[NE], cT[NE];
   int cK[NE];
   static_for<NE>([&](auto e) __attribute__((always_inline)) {
-    const int rho = tid0 + e * NTHR;
+    const int rho = tid + e * NTHR;
     cD0[e()] = 0.0; cD1[e()] = 0.0; cT[e()] = 0.0; cK[e()] = K_PAD;
     if (rho < RP) {
       cD0[e()] = P.tabd[0 * RP + rho];
@@ -199,19 +201,12 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
       act[rho] = 0;
     }
   });
-  if (tid0 < 8) flags[tid0] = 0;
+  if (tid < 8) flags[tid] = 0;
 
   int iter = 0;
   int status = 0;
-  int tid = tid0;
   for (;;) {
     ++iter;
-    // Opaque per-iteration copy of the thread id: without it LICM hoists every
-    // lane-dependent LDS address of the body out of this loop and keeps hundreds of
-    // them live across it (massive spilling).
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63;
-    const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lo = l15 >> 2;
     // ---- component tables for the current active set -----------------------
     static_for<NE>([&](auto e) __attribute__((always_inline)) {
       const int rho = tid + e * NTHR;
@@ -225,7 +220,7 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
     __syncthreads();   // trajectory staged (first pass), tables visible, U free
     stamp();           // 1
 
-    if (P.gram_dense) {
+    if (false) {
       // ---- G = H H' by fp64 MFMA over the implicit Hankel operand ------------
       // Rows >= r of the padded operand read live trajectory data; the garbage they
       // produce lands only in padded rows/cols of G and is cleared in the fix-up below,
@@ -319,54 +314,41 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
       static_for<NT>([&](auto DD) __attribute__((always_inline)) {
         constexpr int d = DD;
         if constexpr (TM::tab.wave[d] == WAVE) {
-          // lane-dependent base pointers once per diagonal; everything else is an immediate offset
-          const double* qb0 = xs + l3;                 // x_b[.]      at  qb0[4*time]
-          const double* qb1 = qb0 + 4 * c;             // x_b[. + c]
-          const double* pb0 = qb0 + 4 * lo;            // x_b[lo + .]
-          const double* pb1 = pb0 + 4 * c;
-          // (pb0/pb1 and the pa pointers advance by one tile = 4 time steps per iteration)
-          double cv0, cv1, cv2, cv3, tt0, tt1, tt2, tt3;
-          const double *pa0_0, *pa0_1, *pa0_2, *pa0_3;
-          auto init = [&](int j, double& cv, double& tt, const double*& pa0) __attribute__((always_inline)) {
+          double cv[4], tt[4];
+          int dl[4];
+          static_for<4>([&](auto j) __attribute__((always_inline)) {
             int del = 4 * d + j - lo;
             del = del < 0 ? 0 : del;            // upper triangle of a diagonal tile: don't care, keep reads in range
             del = del >= Ln ? Ln - 1 : del;     // padded rows: cleared in the fix-up
-            cv = ctab[del * 16 + l4 * 4 + l3];
-            const double* qa0 = xs + 4 * del + l4;     // x_a[del + .]
-            const double* qa1 = qa0 + 4 * c;
+            dl[j()] = del;
+            cv[j()] = ctab[del * 16 + l4 * 4 + l3];
             double t = 0.0;                     // T_del(lo): at most 3 terms
-            if (0 < lo) t += qa1[0] * qb1[0] - qa0[0] * qb0[0];
-            if (1 < lo) t += qa1[4] * qb1[4] - qa0[4] * qb0[4];
-            if (2 < lo) t += qa1[8] * qb1[8] - qa0[8] * qb0[8];
-            tt = t;
-            pa0 = qa0 + 4 * lo;                 // x_a[lo + del + .]
-          };
-          init(0, cv0, tt0, pa0_0); init(1, cv1, tt1, pa0_1); init(2, cv2, tt2, pa0_2); init(3, cv3, tt3, pa0_3);
-          // Runtime (not unrolled) loop down the diagonal: an unrolled walk lets the compiler
-          // hoist every LDS load of the walk to the top and spill them.  The tile slot is
-          // selected by wave-uniform branches so the accumulators stay statically indexed.
-          const double* pa1_0 = pa0_0 + 4 * c; const double* pa1_1 = pa0_1 + 4 * c;
-          const double* pa1_2 = pa0_2 + 4 * c; const double* pa1_3 = pa0_3 + 4 * c;
-#pragma nounroll
-          for (int t = 0; t < NT - d; ++t) {
-            const d4 v = d4{cv0 + tt0, cv1 + tt1, cv2 + tt2, cv3 + tt3};
-            static_for<NT - d>([&](auto T) __attribute__((always_inline)) {
-              if (t == T) acc[TM::slot(d + T, T)] = v;
-            });
-            const double b00 = pb0[0], b01 = pb0[4], b02 = pb0[8], b03 = pb0[12];
-            const double b10 = pb1[0], b11 = pb1[4], b12 = pb1[8], b13 = pb1[12];
-            tt0 += pa1_0[0] * b10 - pa0_0[0] * b00; tt0 += pa1_0[4] * b11 - pa0_0[4] * b01;
-            tt0 += pa1_0[8] * b12 - pa0_0[8] * b02; tt0 += pa1_0[12] * b13 - pa0_0[12] * b03;
-            tt1 += pa1_1[0] * b10 - pa0_1[0] * b00; tt1 += pa1_1[4] * b11 - pa0_1[4] * b01;
-            tt1 += pa1_1[8] * b12 - pa0_1[8] * b02; tt1 += pa1_1[12] * b13 - pa0_1[12] * b03;
-            tt2 += pa1_2[0] * b10 - pa0_2[0] * b00; tt2 += pa1_2[4] * b11 - pa0_2[4] * b01;
-            tt2 += pa1_2[8] * b12 - pa0_2[8] * b02; tt2 += pa1_2[12] * b13 - pa0_2[12] * b03;
-            tt3 += pa1_3[0] * b10 - pa0_3[0] * b00; tt3 += pa1_3[4] * b11 - pa0_3[4] * b01;
-            tt3 += pa1_3[8] * b12 - pa0_3[8] * b02; tt3 += pa1_3[12] * b13 - pa0_3[12] * b03;
-            pb0 += 16; pb1 += 16;
-            pa0_0 += 16; pa0_1 += 16; pa0_2 += 16; pa0_3 += 16;
-            pa1_0 += 16; pa1_1 += 16; pa1_2 += 16; pa1_3 += 16;
-          }
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+              if (jj < lo) t += xs[4 * (jj + c + del) + l4] * xs[4 * (jj + c) + l3] - xs[4 * (jj + del) + l4] * xs[4 * jj + l3];
+            }
+            tt[j()] = t;
+          });
+          static_for<NT - d>([&](auto T) __attribute__((always_inline)) {
+            constexpr int t = T;
+            constexpr int S = TM::slot(d + t, t);
+            static_for<4>([&](auto j) __attribute__((always_inline)) { acc[S][j()] = cv[j()] + tt[j()]; });
+            if constexpr (t + 1 < NT - d) {
+              const int lb = 4 * t + lo;        // current column time index
+              double xb0[4], xb1[4];
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) { xb0[jj] = xs[4 * (lb + jj) + l3]; xb1[jj] = xs[4 * (lb + jj + c) + l3]; }
+              static_for<4>([&](auto j) __attribute__((always_inline)) {
+                const double* xa0 = xs + 4 * (lb + dl[j()]) + l4;
+                const double* xa1 = xa0 + 4 * c;
+                double t2 = tt[j()];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) t2 += xa1[4 * jj] * xb1[jj] - xa0[4 * jj] * xb0[jj];
+                tt[j()] = t2;
+              });
+              __builtin_amdgcn_sched_barrier(0);   // keep the walk from being hoisted wholesale (register pressure)
+            }
+          });
         }
       });
       stamp();   // 3
@@ -622,7 +604,6 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
     if (!again) break;
   }
   if (flags[0] != 0) status = 4;
-  const int lane = tid & 63;
 
   // ---- outputs --------------------------------------------------------------------
   // z = t - lam*D*beta; cost = control cost + lam*beta'z + lamb_sigma*|sigma|^2

@@ -1,0 +1,32 @@
+"""Dev tool: per-phase shader-clock breakdown of the cold-solve kernel (diagnostic stamps)."""
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+from direct_data_driven_mpc_amd import _lib as L
+from direct_data_driven_mpc_amd.engine import BatchedDDMPC
+from direct_data_driven_mpc_amd.harness import controller_params, generate_batch
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+gram = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+cfg = controller_params()
+d = generate_batch(range(B))
+n = 4
+up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+eng = BatchedDDMPC(n=4, m=2, p=2, L_=30, N=400, Q=cfg["Q"], R=cfg["R"], u_s=cfg["u_s"], y_s=cfg["y_s"], batch=B,
+                   controller_type=L.ROBUST, slack_type=L.SLACK_NONE, eps_max=cfg["eps_max"], lamb_alpha=cfg["lamb_alpha"],
+                   lamb_sigma=cfg["lamb_sigma"], c=cfg["c"], gram_mode=gram)
+eng.set_data(d["u_d"], d["y_d"])
+eng.solve(up, yp)
+eng.debug_stamps(True)
+eng.solve(up, yp)
+st = eng.debug_stamps(False, fetch=True).astype(np.int64)
+names = ["entry->tables", "base sums", "gram", "fixup+panel0", "cholesky", "backsolve", "-", "-"]
+dt = np.diff(st[:, :8], axis=1)
+tot = st[:, 14] - st[:, 0]
+real = (st[:, 13] - st[:, 15]) * 10.0   # ns
+print("kernel", eng.kernel_name(), "B", B, "gram_mode", gram)
+for i, nm in enumerate(names[:6]):
+    col = dt[:, i]
+    print("%-16s median %8.0f  p10 %8.0f  p90 %8.0f cycles" % (nm, np.median(col), np.percentile(col, 10), np.percentile(col, 90)))
+print("%-16s median %8.0f cycles; real time median %.1f us; clock %.2f GHz" % ("total", np.median(tot), np.median(real) / 1e3, np.median(tot / np.maximum(real, 1))))
+print("span first entry -> last exit: %.1f us" % ((st[:, 13].max() - st[:, 15].min()) * 10.0 / 1e3))
