@@ -29,7 +29,7 @@
 
 // minimum waves per SIMD requested from the register allocator (keeps MFMA in VGPR form)
 #ifndef DDMPC_MIN_WAVES
-#define DDMPC_MIN_WAVES(W) ((W) <= 4 ? 2 : 4)
+#define DDMPC_MIN_WAVES(W) ((W) <= 4 ? 3 : 4)
 #endif
 
 namespace ddmpc {
@@ -107,6 +107,14 @@ __device__ __forceinline__ double sel4(int k, double a, double b, double c, doub
   v = (k == 1) ? b : v;
   v = (k == 0) ? a : v;
   return v;
+}
+
+// 1/sqrt(x): hardware seed (v_rsq_f64) + one third-order correction step (full fp64
+// accuracy for the ~2^-26 seed); no special-case handling -- pivots are checked separately.
+__device__ __forceinline__ double rsq_nr(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y0, y0, 1.0);
+  return fma(y0 * e, fma(e, 0.375, 0.5), y0);
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -263,156 +271,134 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
       stamp();   // 2
       stamp();   // 3
     } else {
-      // ---- structured Gram (nch == 4): Hankel sliding-window recurrence --------
-      //   G(l+d, l)(a,b) = C_d(a,b) + T_d(l)(a,b),   C_d = G(d,0) = sum_{i<c} x_a[i+d] x_b[i],
-      //   T_d(l) = sum_{j<l} ( x_a[j+c+d] x_b[j+c] - x_a[j+d] x_b[j] ).
-      // (1) base sums C_d: work item (slice, d) accumulates a 4x4 block over a slice of i;
-      //     slices are combined in a fixed order (bit-reproducible).
-      const int Ln = P.Ln, c = P.c;
-      int CHA = RP / Ln;                       // slices that fit the scratch region
-      if (CHA < 1) CHA = 1;
-      int CH = NTHR / Ln;
-      if (CH > 2 * CHA) CH = 2 * CHA;
-      if (CH < 1) CH = 1;
-      if (CH < CHA) CHA = CH;
-      const int JC = (c + CH - 1) / CH;
-      double s[16];
-      const bool worker = tid < Ln * CH;
-      const int wd = tid % Ln, wsl = tid / Ln;
-      if (worker) {
-        static_for<16>([&](auto q) __attribute__((always_inline)) { s[q()] = 0.0; });
-        const int j0 = wsl * JC, j1 = (j0 + JC < c) ? j0 + JC : c;
-        const d2* xb = reinterpret_cast<const d2*>(xs + 4 * j0);
-        const d2* xa = reinterpret_cast<const d2*>(xs + 4 * (j0 + wd));
-        d2 a01 = xa[0], a23 = xa[1], b01 = xb[0], b23 = xb[1];
-        for (int j = j0; j < j1; ++j) {
-          xa += 2; xb += 2;
-          const d2 na01 = xa[0], na23 = xa[1], nb01 = xb[0], nb23 = xb[1];   // prefetch (zero pad past the end)
-          s[0] += a01[0] * b01[0]; s[1] += a01[0] * b01[1]; s[2] += a01[0] * b23[0]; s[3] += a01[0] * b23[1];
-          s[4] += a01[1] * b01[0]; s[5] += a01[1] * b01[1]; s[6] += a01[1] * b23[0]; s[7] += a01[1] * b23[1];
-          s[8] += a23[0] * b01[0]; s[9] += a23[0] * b01[1]; s[10] += a23[0] * b23[0]; s[11] += a23[0] * b23[1];
-          s[12] += a23[1] * b01[0]; s[13] += a23[1] * b01[1]; s[14] += a23[1] * b23[0]; s[15] += a23[1] * b23[1];
-          a01 = na01; a23 = na23; b01 = nb01; b23 = nb23;
+      // ---- structured Gram (nch == 4), all on the matrix pipe -----------------------
+      // With a_I(i)[r] = xflat[4i + 16I + r] the tile (I,J) of G is sum_{i<c} a_I(i) b_J(i)'.
+      // Because a_{I+1}(i) = a_I(i+4), one step down a tile diagonal is
+      //   tile(I+1,J+1) = tile(I,J) - sum_{i<4} a_I(i) b_J(i)' + sum_{c<=i<c+4} a_I(i) b_J(i)',
+      // i.e. one rank-4 downdate and one rank-4 update = 2 MFMAs (the Hankel sliding-window
+      // recurrence in matrix form).  Only the first tile of each diagonal needs the full sum.
+      static_for<TM::MAXS>([&](auto S) __attribute__((always_inline)) { acc[S] = d4{0.0, 0.0, 0.0, 0.0}; });
+      const int c = P.c;
+      {
+        const int cfull = c & ~3;
+        const double* xp = xs + 4 * l4 + l15;
+        for (int i0 = 0; i0 < cfull; i0 += 4) {
+          const double bv = xp[0];
+          static_for<NT>([&](auto DD) __attribute__((always_inline)) {
+            if constexpr (TM::tab.wave[DD] == WAVE) {
+              constexpr int S = TM::slot(DD, 0);
+              acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(xp[16 * DD], bv, acc[S], 0, 0, 0);
+            }
+          });
+          xp += 16;
         }
-        if (wsl < CHA) {
-          double* o = UU + (wsl * Ln + wd) * 16;
-          static_for<16>([&](auto q) __attribute__((always_inline)) { o[q()] = s[q()]; });
+        if (cfull < c) {
+          const bool kok = (cfull + l4) < c;
+          const double bv = kok ? xp[0] : 0.0;
+          static_for<NT>([&](auto DD) __attribute__((always_inline)) {
+            if constexpr (TM::tab.wave[DD] == WAVE) {
+              constexpr int S = TM::slot(DD, 0);
+              const double av = kok ? xp[16 * DD] : 0.0;
+              acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[S], 0, 0, 0);
+            }
+          });
         }
       }
-      __syncthreads();
-      if (worker && wsl >= CHA) {               // second wave of slices adds into its own slot
-        double* o = UU + ((wsl - CHA) * Ln + wd) * 16;
-        static_for<16>([&](auto q) __attribute__((always_inline)) { o[q()] += s[q()]; });
-      }
-      __syncthreads();
-      for (int o = tid; o < Ln * 16; o += NTHR) {
-        const int d = o >> 4, ab = o & 15;
-        double sum = 0.0;
-        for (int ch = 0; ch < CHA; ++ch) sum += UU[(ch * Ln + d) * 16 + ab];
-        ctab[o] = sum;
-      }
-      __syncthreads();
       stamp();   // 2
-      // (2) every wave walks its own tile diagonals.  Lane (a = l4, b = l3, lo): register j
-      //     of tile (d+t, t) is G(k = 4(d+t)+j, l = 4t+lo), so k-l = 4d+j-lo is constant
-      //     along the diagonal and T advances by 4 terms per tile -- all in registers.
       static_for<NT>([&](auto DD) __attribute__((always_inline)) {
         constexpr int d = DD;
-        if constexpr (TM::tab.wave[d] == WAVE) {
-          // lane-dependent base pointers once per diagonal; everything else is an immediate offset
-          const double* qb0 = xs + l3;                 // x_b[.]      at  qb0[4*time]
-          const double* qb1 = qb0 + 4 * c;             // x_b[. + c]
-          const double* pb0 = qb0 + 4 * lo;            // x_b[lo + .]
-          const double* pb1 = pb0 + 4 * c;
-          // (pb0/pb1 and the pa pointers advance by one tile = 4 time steps per iteration)
-          double cv0, cv1, cv2, cv3, tt0, tt1, tt2, tt3;
-          const double *pa0_0, *pa0_1, *pa0_2, *pa0_3;
-          auto init = [&](int j, double& cv, double& tt, const double*& pa0) __attribute__((always_inline)) {
-            int del = 4 * d + j - lo;
-            del = del < 0 ? 0 : del;            // upper triangle of a diagonal tile: don't care, keep reads in range
-            del = del >= Ln ? Ln - 1 : del;     // padded rows: cleared in the fix-up
-            cv = ctab[del * 16 + l4 * 4 + l3];
-            const double* qa0 = xs + 4 * del + l4;     // x_a[del + .]
-            const double* qa1 = qa0 + 4 * c;
-            double t = 0.0;                     // T_del(lo): at most 3 terms
-            if (0 < lo) t += qa1[0] * qb1[0] - qa0[0] * qb0[0];
-            if (1 < lo) t += qa1[4] * qb1[4] - qa0[4] * qb0[4];
-            if (2 < lo) t += qa1[8] * qb1[8] - qa0[8] * qb0[8];
-            tt = t;
-            pa0 = qa0 + 4 * lo;                 // x_a[lo + del + .]
-          };
-          init(0, cv0, tt0, pa0_0); init(1, cv1, tt1, pa0_1); init(2, cv2, tt2, pa0_2); init(3, cv3, tt3, pa0_3);
-          // Runtime (not unrolled) loop down the diagonal: an unrolled walk lets the compiler
-          // hoist every LDS load of the walk to the top and spill them.  The tile slot is
-          // selected by wave-uniform branches so the accumulators stay statically indexed.
-          const double* pa1_0 = pa0_0 + 4 * c; const double* pa1_1 = pa0_1 + 4 * c;
-          const double* pa1_2 = pa0_2 + 4 * c; const double* pa1_3 = pa0_3 + 4 * c;
+        if constexpr (TM::tab.wave[d] == WAVE && d + 1 < NT) {
+          const double* pb = xs + 4 * l4 + l15;          // b_J(i = l4), J = t
+          const double* pa = pb + 16 * d;                // a_I(i = l4), I = d + t
 #pragma nounroll
-          for (int t = 0; t < NT - d; ++t) {
-            const d4 v = d4{cv0 + tt0, cv1 + tt1, cv2 + tt2, cv3 + tt3};
-            static_for<NT - d>([&](auto T) __attribute__((always_inline)) {
-              if (t == T) acc[TM::slot(d + T, T)] = v;
+          for (int t = 0; t + 1 < NT - d; ++t) {         // runtime loop: keeps the loads from being hoisted wholesale
+            const double a1 = pa[0], b1 = pb[0], a2 = pa[4 * c], b2 = pb[4 * c];
+            static_for<NT - d - 1>([&](auto T) __attribute__((always_inline)) {
+              if (t == T) {
+                const d4 v = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, acc[TM::slot(d + T, T)], 0, 0, 0);
+                acc[TM::slot(d + T + 1, T + 1)] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, v, 0, 0, 0);
+              }
             });
-            const double b00 = pb0[0], b01 = pb0[4], b02 = pb0[8], b03 = pb0[12];
-            const double b10 = pb1[0], b11 = pb1[4], b12 = pb1[8], b13 = pb1[12];
-            tt0 += pa1_0[0] * b10 - pa0_0[0] * b00; tt0 += pa1_0[4] * b11 - pa0_0[4] * b01;
-            tt0 += pa1_0[8] * b12 - pa0_0[8] * b02; tt0 += pa1_0[12] * b13 - pa0_0[12] * b03;
-            tt1 += pa1_1[0] * b10 - pa0_1[0] * b00; tt1 += pa1_1[4] * b11 - pa0_1[4] * b01;
-            tt1 += pa1_1[8] * b12 - pa0_1[8] * b02; tt1 += pa1_1[12] * b13 - pa0_1[12] * b03;
-            tt2 += pa1_2[0] * b10 - pa0_2[0] * b00; tt2 += pa1_2[4] * b11 - pa0_2[4] * b01;
-            tt2 += pa1_2[8] * b12 - pa0_2[8] * b02; tt2 += pa1_2[12] * b13 - pa0_2[12] * b03;
-            tt3 += pa1_3[0] * b10 - pa0_3[0] * b00; tt3 += pa1_3[4] * b11 - pa0_3[4] * b01;
-            tt3 += pa1_3[8] * b12 - pa0_3[8] * b02; tt3 += pa1_3[12] * b13 - pa0_3[12] * b03;
-            pb0 += 16; pb1 += 16;
-            pa0_0 += 16; pa0_1 += 16; pa0_2 += 16; pa0_3 += 16;
-            pa1_0 += 16; pa1_1 += 16; pa1_2 += 16; pa1_3 += 16;
+            pa += 16; pb += 16;
           }
         }
       });
       stamp();   // 3
     }
 
-    // ---- K = G + lam*D (diagonal), identity on dummy rows, rhs row ---------
+    // ---- accumulators := -(G + lam*D); identity on dummy rows; rhs row := -t -----------
+    // The factorisation keeps the NEGATED matrix in the accumulators so that the rank-4
+    // trailing updates are plain  acc += L_I L_J'  (MFMA has no operand-negate modifier).
     static_for<NT>([&](auto J) __attribute__((always_inline)) {
       static_for<NT>([&](auto I) __attribute__((always_inline)) {
         if constexpr (I >= J && TM::wave(I, J) == WAVE) {
           constexpr int S = TM::slot(I, J);
           const int col = 16 * J + l15;
-          static_for<4>([&](auto j) __attribute__((always_inline)) {
-            const int row = 16 * I + l4 + 4 * j;
-            if (16 * I + 15 >= r && (row >= r || col >= r)) acc[S][j()] = 0.0;
-            if (I == J && row < col) acc[S][j()] = 0.0;
-            if (I == J && row == col) {
-              if (row < r) acc[S][j()] += P.lam * dvec[row];
-              else if (row < rE) acc[S][j()] = 1.0;
-            }
-            if (row == rE) acc[S][j()] = (col < r) ? tvec[col] : 0.0;
-          });
+          d4 v = -acc[S];
+          if constexpr (I == J) {
+            static_for<4>([&](auto j) __attribute__((always_inline)) {
+              const int row = 16 * I + l4 + 4 * j;
+              if (row == col && row < r) v[j()] -= P.lam * dvec[row];
+              if (row < col) v[j()] = 0.0;
+            });
+          }
+          if (16 * I + 15 >= r) {                 // wave-uniform: tile rows that touch the padding / rhs row
+            static_for<4>([&](auto j) __attribute__((always_inline)) {
+              const int row = 16 * I + l4 + 4 * j;
+              if (row >= r || col >= r) v[j()] = 0.0;
+              if (I == J && row == col && row >= r && row < rE) v[j()] = -1.0;
+              if (row == rE && col < r) v[j()] = -tvec[col];
+            });
+          }
+          acc[S] = v;
         }
       });
     });
 
-    // ---- blocked Cholesky, 4-wide panels, ONE barrier per step ----------------
-    // Every lane re-derives what it needs from the raw panel PT: the 4x4 diagonal
-    // block is factored redundantly, M = L11^-1 is formed explicitly, and a row of
-    // the factored panel is  L_row = PT_row * M'  (4 FMAs per element).
-    auto extract_panel = [&](auto JN, int qn, double* dst) __attribute__((always_inline)) {
+    // ---- blocked Cholesky, 4-wide panels, two barriers per step -----------------------
+    //   (1) [at the end of the previous step] raw, negated panel columns -> PT
+    //   (2) one thread per row: factor the 4x4 diagonal block (redundantly per thread),
+    //       forward-substitute its own row, write the row of L to LT; the wave that owns
+    //       no rows does the pivot check and forms M = L11^-1 for the back substitution
+    //   (3) every wave: operands from LT; first the rank-4 update of the tiles that hold the
+    //       next panel, whose columns go straight back out to PT (look-ahead); then the rest
+    //       of the trailing update, which drains under the next step's chain; final L is
+    //       written back into the panel columns (kept for the back substitution)
+    double* PT = UU;
+    double* LT = UU + 4 * RP;
+    constexpr bool IDLE_WAVE_DOES_M = (W > 1) && (RP <= 64 * (W - 1)) && (NE == 1);
+    long long tph0 = 0, tph1 = 0, tph2 = 0, tph3 = 0, tph4 = 0;
+    const bool timing = (stamps != nullptr) && (WAVE == 0);
+    auto now = [&]() __attribute__((always_inline)) -> long long { return timing ? (long long)__builtin_amdgcn_s_memtime() : 0; };
+    auto save_m = [&](int s, double d0, double d1, double d2v, double d3, double i0, double i1, double i2, double i3,
+                      double l10, double l20, double l21, double l30, double l31, double l32)
+                      __attribute__((always_inline)) {
+      const bool ok = (d0 > 0.0) && (d1 > 0.0) && (d2v > 0.0) && (d3 > 0.0) &&
+                      (i0 < 1e150) && (i1 < 1e150) && (i2 < 1e150) && (i3 < 1e150);
+      if (!ok) flags[0] = 1;
+      const double m10 = -l10 * i0 * i1;
+      const double m20 = -(l20 * i0 + l21 * m10) * i2, m21 = -(l21 * i1) * i2;
+      const double m30 = -(l30 * i0 + l31 * m10 + l32 * m20) * i3, m31 = -(l31 * i1 + l32 * m21) * i3,
+                   m32 = -(l32 * i2) * i3;
+      double* ms = msave + 12 * s;
+      ms[0] = i0; ms[1] = i1; ms[2] = i2; ms[3] = i3; ms[4] = m10; ms[5] = m20; ms[6] = m21;
+      ms[7] = m30; ms[8] = m31; ms[9] = m32;
+    };
+    auto extract_panel = [&](auto JN, int qn) __attribute__((always_inline)) {
       constexpr int Jn = JN;
       if (lo == qn) {
         static_for<NT>([&](auto I) __attribute__((always_inline)) {
           if constexpr (I >= Jn && TM::wave(I, Jn) == WAVE) {
             constexpr int S = TM::slot(I, Jn);
             static_for<4>([&](auto j) __attribute__((always_inline)) {
-              dst[l3 * RP + 16 * I + l4 + 4 * j] = acc[S][j()];
+              PT[l3 * RP + 16 * I + l4 + 4 * j] = acc[S][j()];
             });
           }
         });
       }
     };
-    __syncthreads();   // everyone is done with U (base-sum slices)
-    extract_panel(std::integral_constant<int, 0>{}, 0, UU);
-    __syncthreads();
-    stamp();   // 4
+    __syncthreads();   // U is free (dense path never used it; structured path neither)
+    extract_panel(std::integral_constant<int, 0>{}, 0);
     static_for<NT>([&](auto JB) __attribute__((always_inline)) {
       constexpr int Jb = JB;
       const int qend = (NS - 4 * Jb) < 4 ? (NS - 4 * Jb) : 4;      // <=0 past the last panel
@@ -420,188 +406,211 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
         const int s = 4 * Jb + q;
         const int c0 = 4 * s;
         const int lim = c0 + 4;                                     // rows/cols below this are final
-        const double* Pc = UU + (s & 1) * 4 * RP;
-        double* Pn = UU + ((s & 1) ^ 1) * 4 * RP;
-        // diagonal block -> L11 and M = L11^-1
-        const double* Pd = Pc + c0;
-        const double p00 = Pd[0 * RP + 0];
-        const double p10 = Pd[0 * RP + 1], p11 = Pd[1 * RP + 1];
-        const double p20 = Pd[0 * RP + 2], p21 = Pd[1 * RP + 2], p22 = Pd[2 * RP + 2];
-        const double p30 = Pd[0 * RP + 3], p31 = Pd[1 * RP + 3], p32 = Pd[2 * RP + 3], p33 = Pd[3 * RP + 3];
-        const double d0 = p00;
-        const double i0 = rsqrt(d0);
-        const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
-        const double d1 = p11 - l10 * l10;
-        const double i1 = rsqrt(d1);
-        const double l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
-        const double d2v = p22 - l20 * l20 - l21 * l21;
-        const double i2 = rsqrt(d2v);
-        const double l32 = (p32 - l30 * l20 - l31 * l21) * i2;
-        const double d3 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
-        const double i3 = rsqrt(d3);
-        const double m10 = -l10 * i0 * i1;
-        const double m20 = -(l20 * i0 + l21 * m10) * i2, m21 = -(l21 * i1) * i2;
-        const double m30 = -(l30 * i0 + l31 * m10 + l32 * m20) * i3, m31 = -(l31 * i1 + l32 * m21) * i3,
-                     m32 = -(l32 * i2) * i3;
-        if (tid == 0) {
-          const bool ok = (d0 > 0.0) && (d1 > 0.0) && (d2v > 0.0) && (d3 > 0.0) &&
-                          (i0 < 1e150) && (i1 < 1e150) && (i2 < 1e150) && (i3 < 1e150);
-          if (!ok) flags[0] = 1;
-          double* ms = msave + 12 * s;
-          ms[0] = i0; ms[1] = i1; ms[2] = i2; ms[3] = i3; ms[4] = m10; ms[5] = m20; ms[6] = m21;
-          ms[7] = m30; ms[8] = m31; ms[9] = m32;
+        const long long ta = now();
+        __syncthreads();
+        const long long tc = now();
+        // (2)
+        if constexpr (IDLE_WAVE_DOES_M && WAVE == W - 1) {
+          const double* Pd = PT + c0;
+          const double p00 = -Pd[0 * RP + 0];
+          const double p10 = -Pd[0 * RP + 1], p11 = -Pd[1 * RP + 1];
+          const double p20 = -Pd[0 * RP + 2], p21 = -Pd[1 * RP + 2], p22 = -Pd[2 * RP + 2];
+          const double p30 = -Pd[0 * RP + 3], p31 = -Pd[1 * RP + 3], p32 = -Pd[2 * RP + 3], p33 = -Pd[3 * RP + 3];
+          const double d0 = p00;
+          const double i0 = rsq_nr(d0);
+          const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
+          const double d1 = p11 - l10 * l10;
+          const double i1 = rsq_nr(d1);
+          const double l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
+          const double d2v = p22 - l20 * l20 - l21 * l21;
+          const double i2 = rsq_nr(d2v);
+          const double l32 = (p32 - l30 * l20 - l31 * l21) * i2;
+          const double d3 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
+          const double i3 = rsq_nr(d3);
+          if (lane == 0) save_m(s, d0, d1, d2v, d3, i0, i1, i2, i3, l10, l20, l21, l30, l31, l32);
         }
-        // column l4 of M' for the MFMA operands
-        const double w0 = sel4(l4, i0, m10, m20, m30), w1 = sel4(l4, 0.0, i1, m21, m31);
-        const double w2 = sel4(l4, 0.0, 0.0, i2, m32), w3 = sel4(l4, 0.0, 0.0, 0.0, i3);
-        double op[NT];
-        auto mkop = [&](auto II) __attribute__((always_inline)) {
-          constexpr int I = II;
-          const double* pp = Pc + 16 * I + l15;
-          const double v = pp[0] * w0 + pp[RP] * w1 + pp[2 * RP] * w2 + pp[3 * RP] * w3;
-          if constexpr (I == Jb) op[I] = (16 * I + l15 >= lim) ? v : 0.0;
-          else op[I] = v;                        // every row/col of a later tile is >= lim
-        };
-        // (a) tiles that hold the NEXT panel's columns first, then hand that panel over
-        if (q < 3) {
-          mkop(std::integral_constant<int, Jb>{});
+        static_for<NE>([&](auto e) __attribute__((always_inline)) {
+          constexpr int row0 = 64 * WAVE + e * NTHR;               // first row of this wave's 64-row slab
+          if constexpr (row0 < RP) {
+            if (row0 + 63 >= c0) {                                  // wave-uniform: slab still has live rows
+              const int row = tid + e * NTHR;
+              const double* Pd = PT + c0;
+              const double p00 = -Pd[0 * RP + 0];
+              const double p10 = -Pd[0 * RP + 1], p11 = -Pd[1 * RP + 1];
+              const double p20 = -Pd[0 * RP + 2], p21 = -Pd[1 * RP + 2], p22 = -Pd[2 * RP + 2];
+              const double p30 = -Pd[0 * RP + 3], p31 = -Pd[1 * RP + 3], p32 = -Pd[2 * RP + 3], p33 = -Pd[3 * RP + 3];
+              const double r0 = PT[0 * RP + row], r1 = PT[1 * RP + row], r2 = PT[2 * RP + row], r3 = PT[3 * RP + row];
+              const double d0 = p00;
+              const double i0 = rsq_nr(d0);
+              const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
+              const double d1 = p11 - l10 * l10;
+              const double i1 = rsq_nr(d1);
+              const double l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
+              const double d2v = p22 - l20 * l20 - l21 * l21;
+              const double i2 = rsq_nr(d2v);
+              const double l32 = (p32 - l30 * l20 - l31 * l21) * i2;
+              const double d3 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
+              const double i3 = rsq_nr(d3);
+              // forward substitution of this row (PT holds the negated entries).  For the rows of
+              // the diagonal block the same substitution yields L11 itself; only its strictly
+              // upper part has to be zeroed.
+              const double x0 = -r0 * i0;
+              double x1 = -(r1 + x0 * l10) * i1;
+              double x2 = -(r2 + x0 * l20 + x1 * l21) * i2;
+              double x3 = -(r3 + x0 * l30 + x1 * l31 + x2 * l32) * i3;
+              const int ii = row - c0;
+              x1 = (ii < 1) ? 0.0 : x1;
+              x2 = (ii < 2) ? 0.0 : x2;
+              x3 = (ii < 3) ? 0.0 : x3;
+              if (row >= c0 && row < RP) {
+                LT[0 * RP + row] = x0; LT[1 * RP + row] = x1; LT[2 * RP + row] = x2; LT[3 * RP + row] = x3;
+              }
+              if constexpr (!IDLE_WAVE_DOES_M) {
+                if (row == c0) save_m(s, d0, d1, d2v, d3, i0, i1, i2, i3, l10, l20, l21, l30, l31, l32);
+              }
+            }
+          }
+        });
+        const long long td = now();
+        __syncthreads();
+        const long long te = now();
+        // (3)
+        {
+          double op[NT];
           static_for<NT>([&](auto I) __attribute__((always_inline)) {
-            if constexpr (I > Jb && TM::wave(I, Jb) == WAVE) mkop(I);
-          });
-          static_for<NT>([&](auto I) __attribute__((always_inline)) {
-            if constexpr (I >= Jb && TM::wave(I, Jb) == WAVE) {
-              constexpr int S = TM::slot(I, Jb);
-              acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(-op[I], op[Jb], acc[S], 0, 0, 0);
+            if constexpr (I >= Jb) {
+              const double v = LT[l4 * RP + 16 * I + l15];
+              if constexpr (I == Jb) op[I] = (16 * I + l15 >= lim) ? v : 0.0;
+              else op[I] = v;                      // every row/col of a later tile is >= lim
             }
           });
-          if (s + 1 < NS) extract_panel(std::integral_constant<int, Jb>{}, q + 1, Pn);
-          __builtin_amdgcn_sched_barrier(0);
-          static_for<NT>([&](auto I) __attribute__((always_inline)) {
-            if constexpr (I > Jb && TM::wave(I, Jb) != WAVE) mkop(I);
-          });
-        } else {
-          if constexpr (Jb + 1 < NT) {
-            mkop(std::integral_constant<int, Jb + 1>{});
+          // (3a) tiles holding the NEXT panel's columns, then that panel goes out to PT
+          //      (PT was last read before barrier 2, so it is free again)
+          if (q < 3) {
             static_for<NT>([&](auto I) __attribute__((always_inline)) {
-              if constexpr (I > Jb + 1 && TM::wave(I, Jb + 1) == WAVE) mkop(I);
+              if constexpr (I >= Jb && TM::wave(I, Jb) == WAVE) {
+                constexpr int S = TM::slot(I, Jb);
+                acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[I], op[Jb], acc[S], 0, 0, 0);
+              }
             });
+            if (s + 1 < NS) extract_panel(std::integral_constant<int, Jb>{}, q + 1);
+          } else if constexpr (Jb + 1 < NT) {
             static_for<NT>([&](auto I) __attribute__((always_inline)) {
               if constexpr (I >= Jb + 1 && TM::wave(I, Jb + 1) == WAVE) {
                 constexpr int S = TM::slot(I, Jb + 1);
-                acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(-op[I], op[Jb + 1], acc[S], 0, 0, 0);
+                acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[I], op[Jb + 1], acc[S], 0, 0, 0);
               }
             });
-            if (s + 1 < NS) extract_panel(std::integral_constant<int, Jb + 1>{}, 0, Pn);
-            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < NS) extract_panel(std::integral_constant<int, Jb + 1>{}, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          // (3b) the rest of the trailing update
+          static_for<NT>([&](auto J) __attribute__((always_inline)) {
             static_for<NT>([&](auto I) __attribute__((always_inline)) {
-              if constexpr (I > Jb + 1 && TM::wave(I, Jb + 1) != WAVE) mkop(I);
+              if constexpr (J > Jb && I >= J && TM::wave(I, J) == WAVE) {
+                constexpr int S = TM::slot(I, J);
+                if constexpr (J == Jb + 1) {
+                  if (q < 3) acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[I], op[J], acc[S], 0, 0, 0);
+                } else {
+                  acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[I], op[J], acc[S], 0, 0, 0);
+                }
+              }
+            });
+          });
+          // (3c) keep the final L in the panel columns of this tile column
+          if (lo == q) {
+            static_for<NT>([&](auto I) __attribute__((always_inline)) {
+              if constexpr (I >= Jb && TM::wave(I, Jb) == WAVE) {
+                constexpr int S = TM::slot(I, Jb);
+                static_for<4>([&](auto j) __attribute__((always_inline)) {
+                  acc[S][j()] = LT[l3 * RP + 16 * I + l4 + 4 * j];
+                });
+              }
             });
           }
         }
-        // (b) the rest of the trailing update (drains while the next step's chain runs)
-        static_for<NT>([&](auto J) __attribute__((always_inline)) {
-          static_for<NT>([&](auto I) __attribute__((always_inline)) {
-            if constexpr (J > Jb && I >= J && TM::wave(I, J) == WAVE) {
-              constexpr int S = TM::slot(I, J);
-              if constexpr (J == Jb + 1) {
-                if (q < 3) acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(-op[I], op[J], acc[S], 0, 0, 0);
-              } else {
-                acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(-op[I], op[J], acc[S], 0, 0, 0);
-              }
-            }
-          });
-        });
-        // (c) keep L in the panel columns of this tile column (for the back substitution)
-        if (lo == q) {
-          const double v0 = sel4(l3, i0, m10, m20, m30), v1 = sel4(l3, 0.0, i1, m21, m31);
-          const double v2 = sel4(l3, 0.0, 0.0, i2, m32), v3 = sel4(l3, 0.0, 0.0, 0.0, i3);
-          static_for<NT>([&](auto I) __attribute__((always_inline)) {
-            if constexpr (I >= Jb && TM::wave(I, Jb) == WAVE) {
-              constexpr int S = TM::slot(I, Jb);
-              static_for<4>([&](auto j) __attribute__((always_inline)) {
-                const double* pp = Pc + 16 * I + l4 + 4 * j;
-                acc[S][j()] = pp[0] * v0 + pp[RP] * v1 + pp[2 * RP] * v2 + pp[3 * RP] * v3;
-              });
-            }
-          });
-        }
-        __syncthreads();
+        const long long tf = now();
+        tph1 += tc - ta; tph2 += td - tc; tph3 += te - td; tph4 += tf - te;
       }
     });
+    if (timing && threadIdx.x == 0) { stamps[7] = tph0; stamps[8] = tph1; stamps[9] = tph2; stamps[10] = tph3; stamps[11] = tph4; }
+    stamp();   // 4
     stamp();   // 5
 
-    // ---- y = L^-1 t sits in row rE of the tiles; hand it to the row-owner threads
+    // ---- y = L^-1 t sits in row rE of the tiles -> tvec[] -----------------------------
     static_for<NT>([&](auto J) __attribute__((always_inline)) {
       static_for<NT>([&](auto I) __attribute__((always_inline)) {
         if constexpr (I >= J && TM::wave(I, J) == WAVE) {
           if (I == IR) {
             constexpr int S = TM::slot(I, J);
             static_for<4>([&](auto j) __attribute__((always_inline)) {
-              if (l4 + 4 * j == rr) beta[16 * J + l15] = acc[S][j()];   // beta[] doubles as y buffer
+              if (l4 + 4 * j == rr) tvec[16 * J + l15] = acc[S][j()];
             });
           }
         }
       });
     });
-    // ---- back substitution L' beta = y: 4 rows per step, ONE barrier per step ----
-    // beta_s = M_s' (y_s - contributions of later blocks); then y_i -= L[rows s][i] . beta_s.
+    __syncthreads();
+    // ---- back substitution L' beta = y, one 16-row tile row per round --------------------
+    //   (i)  the owner of the diagonal tile solves its 16 rows (4 blocks of 4, with the saved
+    //        inverse blocks M) and publishes beta for those rows;
+    //   (ii) y_J -= L(Is,J)' beta_Is for every tile left of it: 4 MFMAs per tile, with the
+    //        accumulator registers themselves as the B operand (register ks of a lane holds
+    //        L[4ks + l4][l15], exactly B[k = l4][j = l15] of k-step ks) and beta in row 0 of A.
     {
-      double yv[NE];
-      auto extract_rows = [&](auto IS, int qs, double* dst) __attribute__((always_inline)) {
-        constexpr int Is = IS;
-        static_for<NT>([&](auto J) __attribute__((always_inline)) {
-          if constexpr (J <= Is && TM::wave(Is, J) == WAVE) {
-            constexpr int S = TM::slot(Is, J);
-            const d4 av = acc[S];
-            dst[l4 * RP + 16 * J + l15] = sel4(qs, av[0], av[1], av[2], av[3]);
-          }
-        });
-      };
-      static_for<NT>([&](auto IS) __attribute__((always_inline)) {
-        if (IS == ((NS - 1) >> 2)) extract_rows(IS, (NS - 1) & 3, UU);
-      });
-      __syncthreads();
-      static_for<NE>([&](auto e) __attribute__((always_inline)) {
-        const int i = tid + e * NTHR;
-        yv[e()] = (i < rE) ? beta[i] : 0.0;
-        if (i >= 4 * (NS - 1) && i < 4 * NS) yc[i - 4 * (NS - 1)] = yv[e()];
-      });
-      __syncthreads();
+      double* DT = UU;                                   // 16 x 16 copy of the diagonal tile
       static_for<NT>([&](auto IREV) __attribute__((always_inline)) {
         constexpr int Is = NT - 1 - IREV;
-        const int qtop = (NS - 4 * Is) < 4 ? (NS - 4 * Is) : 4;
-        for (int q = qtop - 1; q >= 0; --q) {
-          const int s = 4 * Is + q;
-          const int c0 = 4 * s;
-          const int buf = (NS - 1 - s) & 1;
-          const double* LR = UU + buf * 4 * RP;
-          double* LN = UU + (buf ^ 1) * 4 * RP;
-          // next row block leaves the registers first: its LDS latency hides under the chain below
-          if (s > 0) {
-            if (q > 0) extract_rows(std::integral_constant<int, Is>{}, q - 1, LN);
-            else if constexpr (Is > 0) extract_rows(std::integral_constant<int, Is - 1>{}, 3, LN);
-          }
-          const double* ycb = yc + buf * 4;
-          const double* ms = msave + 12 * s;
-          const double y0 = ycb[0], y1 = ycb[1], y2 = ycb[2], y3 = ycb[3];
-          const double b0 = ms[0] * y0 + ms[4] * y1 + ms[5] * y2 + ms[7] * y3;
-          const double b1 = ms[1] * y1 + ms[6] * y2 + ms[8] * y3;
-          const double b2 = ms[2] * y2 + ms[9] * y3;
-          const double b3 = ms[3] * y3;
-          static_for<NE>([&](auto e) __attribute__((always_inline)) {
-            const int i = tid + e * NTHR;
-            if (i < c0) {
-              yv[e()] -= LR[0 * RP + i] * b0 + LR[1 * RP + i] * b1 + LR[2 * RP + i] * b2 + LR[3 * RP + i] * b3;
-              if (i >= c0 - 4) yc[(buf ^ 1) * 4 + (i - (c0 - 4))] = yv[e()];
-            } else if (i < c0 + 4) {
-              beta[i] = sel4(i - c0, b0, b1, b2, b3);
+        if (16 * Is < rE) {
+          if constexpr (TM::wave(Is, Is) == WAVE) {
+            constexpr int S = TM::slot(Is, Is);
+            static_for<4>([&](auto j) __attribute__((always_inline)) { DT[(l4 + 4 * j) * 16 + l15] = acc[S][j()]; });
+            const int qtop = (NS - 4 * Is) < 4 ? (NS - 4 * Is) : 4;
+            for (int qq = qtop - 1; qq >= 0; --qq) {
+              const int s = 4 * Is + qq;
+              const double* ms = msave + 12 * s;
+              const double* yb = tvec + 4 * s;
+              const double y0 = yb[0], y1 = yb[1], y2 = yb[2], y3 = yb[3];
+              const double b0 = ms[0] * y0 + ms[4] * y1 + ms[5] * y2 + ms[7] * y3;
+              const double b1 = ms[1] * y1 + ms[6] * y2 + ms[8] * y3;
+              const double b2 = ms[2] * y2 + ms[9] * y3;
+              const double b3 = ms[3] * y3;
+              if (lane < 4 * qq) {                       // rows of this tile above the block
+                const double* Lb = DT + (4 * qq) * 16 + lane;
+                tvec[16 * Is + lane] -= Lb[0] * b0 + Lb[16] * b1 + Lb[32] * b2 + Lb[48] * b3;
+              } else if (lane < 4 * qq + 4) {
+                beta[16 * Is + lane] = sel4(lane - 4 * qq, b0, b1, b2, b3);
+              }
             }
-          });
-          __syncthreads();
+          }
+          if constexpr (Is > 0) {
+            __syncthreads();
+            {
+              const double* bp = beta + 16 * Is + l4;
+              const int rw = 16 * Is + l4;            // rows >= rE (rhs row, padding) carry no beta
+              const double a0 = (l15 == 0 && rw < rE) ? bp[0] : 0.0, a1 = (l15 == 0 && rw + 4 < rE) ? bp[4] : 0.0;
+              const double a2 = (l15 == 0 && rw + 8 < rE) ? bp[8] : 0.0, a3 = (l15 == 0 && rw + 12 < rE) ? bp[12] : 0.0;
+              static_for<Is>([&](auto J) __attribute__((always_inline)) {
+                if constexpr (TM::wave(Is, J) == WAVE) {
+                  constexpr int S = TM::slot(Is, J);
+                  const d4 Lt = acc[S];
+                  d4 dd = d4{0.0, 0.0, 0.0, 0.0};
+                  dd = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, Lt[0], dd, 0, 0, 0);
+                  dd = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Lt[1], dd, 0, 0, 0);
+                  dd = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Lt[2], dd, 0, 0, 0);
+                  dd = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, Lt[3], dd, 0, 0, 0);
+                  if (l4 == 0) tvec[16 * J + l15] -= dd[0];
+                }
+              });
+            }
+            __syncthreads();
+          }
         }
       });
+      __syncthreads();
     }
     stamp();   // 6
+
 
     // ---- slack box: primal-dual active-set update --------------------------------
     bool again = false;

@@ -29,4 +29,7 @@ for i, nm in enumerate(names[:6]):
     col = dt[:, i]
     print("%-16s median %8.0f  p10 %8.0f  p90 %8.0f cycles" % (nm, np.median(col), np.percentile(col, 10), np.percentile(col, 90)))
 print("%-16s median %8.0f cycles; real time median %.1f us; clock %.2f GHz" % ("total", np.median(tot), np.median(real) / 1e3, np.median(tot / np.maximum(real, 1))))
+ph = st[:, 7:12]
+for i, nm in enumerate(["chol: extract", "chol: barrier1", "chol: factor+row", "chol: barrier2", "chol: operands+mfma+wb"]):
+    print("%-24s median %8.0f cycles (sum over steps, wave 0)" % (nm, np.median(ph[:, i])))
 print("span first entry -> last exit: %.1f us" % ((st[:, 13].max() - st[:, 15].min()) * 10.0 / 1e3))
