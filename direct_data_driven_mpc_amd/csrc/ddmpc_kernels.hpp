@@ -552,59 +552,84 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
     });
     __syncthreads();
     // ---- back substitution L' beta = y, one 16-row tile row per round --------------------
-    //   (i)  the owner of the diagonal tile solves its 16 rows (4 blocks of 4, with the saved
-    //        inverse blocks M) and publishes beta for those rows;
-    //   (ii) y_J -= L(Is,J)' beta_Is for every tile left of it: 4 MFMAs per tile, with the
-    //        accumulator registers themselves as the B operand (register ks of a lane holds
-    //        L[4ks + l4][l15], exactly B[k = l4][j = l15] of k-step ks) and beta in row 0 of A.
+    //   (A) the owner of the diagonal tile solves its 16 rows in registers: 4 blocks of 4 rows,
+    //       beta_blk = M_blk' y_blk with the saved inverse blocks; y values are broadcast with
+    //       v_readlane, and the in-tile update of the rows above is ONE MFMA (beta in row 0 of
+    //       A, accumulator register qq of the diagonal tile as B);
+    //   (C) y_J -= L(Is,J)' beta_Is for every tile left of the diagonal: 4 MFMAs per tile with
+    //       the accumulator registers themselves as B (register ks of a lane holds
+    //       L[4ks + l4][l15] = B[k = l4][j = l15] of k-step ks).  The tile (Is, Is-1) that
+    //       feeds the next diagonal solve goes first; the others are deferred past the barrier
+    //       and overlap with that solve.
     {
-      double* DT = UU;                                   // 16 x 16 copy of the diagonal tile
+      auto rl64 = [&](double v, int src) __attribute__((always_inline)) -> double {
+        const int lo32 = __builtin_amdgcn_readlane(__double2loint(v), src);
+        const int hi32 = __builtin_amdgcn_readlane(__double2hiint(v), src);
+        return __hiloint2double(hi32, lo32);
+      };
+      auto tile_update = [&](auto IS, auto JJ, double a0, double a1, double a2, double a3) __attribute__((always_inline)) {
+        constexpr int S = TM::slot(IS, JJ);
+        const d4 Lt = acc[S];
+        d4 dd = d4{0.0, 0.0, 0.0, 0.0};
+        dd = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, Lt[0], dd, 0, 0, 0);
+        dd = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Lt[1], dd, 0, 0, 0);
+        dd = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Lt[2], dd, 0, 0, 0);
+        dd = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, Lt[3], dd, 0, 0, 0);
+        if (l4 == 0) tvec[16 * JJ + l15] -= dd[0];
+      };
+      double pa0 = 0.0, pa1 = 0.0, pa2 = 0.0, pa3 = 0.0;          // operands of the previous (lower) tile row
       static_for<NT>([&](auto IREV) __attribute__((always_inline)) {
         constexpr int Is = NT - 1 - IREV;
-        if (16 * Is < rE) {
-          if constexpr (TM::wave(Is, Is) == WAVE) {
+        const bool live = 16 * Is < rE;                             // wave-uniform
+        // (A)
+        if constexpr (TM::wave(Is, Is) == WAVE) {
+          if (live) {
             constexpr int S = TM::slot(Is, Is);
-            static_for<4>([&](auto j) __attribute__((always_inline)) { DT[(l4 + 4 * j) * 16 + l15] = acc[S][j()]; });
+            const d4 Ld = acc[S];
+            double yv = tvec[16 * Is + l15];
             const int qtop = (NS - 4 * Is) < 4 ? (NS - 4 * Is) : 4;
-            for (int qq = qtop - 1; qq >= 0; --qq) {
-              const int s = 4 * Is + qq;
-              const double* ms = msave + 12 * s;
-              const double* yb = tvec + 4 * s;
-              const double y0 = yb[0], y1 = yb[1], y2 = yb[2], y3 = yb[3];
-              const double b0 = ms[0] * y0 + ms[4] * y1 + ms[5] * y2 + ms[7] * y3;
-              const double b1 = ms[1] * y1 + ms[6] * y2 + ms[8] * y3;
-              const double b2 = ms[2] * y2 + ms[9] * y3;
-              const double b3 = ms[3] * y3;
-              if (lane < 4 * qq) {                       // rows of this tile above the block
-                const double* Lb = DT + (4 * qq) * 16 + lane;
-                tvec[16 * Is + lane] -= Lb[0] * b0 + Lb[16] * b1 + Lb[32] * b2 + Lb[48] * b3;
-              } else if (lane < 4 * qq + 4) {
-                beta[16 * Is + lane] = sel4(lane - 4 * qq, b0, b1, b2, b3);
-              }
-            }
-          }
-          if constexpr (Is > 0) {
-            __syncthreads();
-            {
-              const double* bp = beta + 16 * Is + l4;
-              const int rw = 16 * Is + l4;            // rows >= rE (rhs row, padding) carry no beta
-              const double a0 = (l15 == 0 && rw < rE) ? bp[0] : 0.0, a1 = (l15 == 0 && rw + 4 < rE) ? bp[4] : 0.0;
-              const double a2 = (l15 == 0 && rw + 8 < rE) ? bp[8] : 0.0, a3 = (l15 == 0 && rw + 12 < rE) ? bp[12] : 0.0;
-              static_for<Is>([&](auto J) __attribute__((always_inline)) {
-                if constexpr (TM::wave(Is, J) == WAVE) {
-                  constexpr int S = TM::slot(Is, J);
-                  const d4 Lt = acc[S];
-                  d4 dd = d4{0.0, 0.0, 0.0, 0.0};
-                  dd = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, Lt[0], dd, 0, 0, 0);
-                  dd = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Lt[1], dd, 0, 0, 0);
-                  dd = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Lt[2], dd, 0, 0, 0);
-                  dd = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, Lt[3], dd, 0, 0, 0);
-                  if (l4 == 0) tvec[16 * J + l15] -= dd[0];
+            static_for<4>([&](auto QR) __attribute__((always_inline)) {
+              constexpr int QQ = 3 - QR;
+              if (QQ < qtop) {
+                const int s = 4 * Is + QQ;
+                const double* ms = msave + 12 * s;
+                const double y0 = rl64(yv, 4 * QQ + 0), y1 = rl64(yv, 4 * QQ + 1);
+                const double y2 = rl64(yv, 4 * QQ + 2), y3 = rl64(yv, 4 * QQ + 3);
+                const double b0 = ms[0] * y0 + ms[4] * y1 + ms[5] * y2 + ms[7] * y3;
+                const double b1 = ms[1] * y1 + ms[6] * y2 + ms[8] * y3;
+                const double b2 = ms[2] * y2 + ms[9] * y3;
+                const double b3 = ms[3] * y3;
+                if (lane == 0) { beta[4 * s + 0] = b0; beta[4 * s + 1] = b1; beta[4 * s + 2] = b2; beta[4 * s + 3] = b3; }
+                if constexpr (QQ > 0) {
+                  const double av = (l15 == 0) ? sel4(l4, b0, b1, b2, b3) : 0.0;
+                  const d4 dd = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Ld[QQ], d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+                  yv -= dd[0];                                      // meaningful in lanes 0..15 (row 0 of D)
                 }
-              });
-            }
-            __syncthreads();
+              }
+            });
           }
+        }
+        // deferred tiles of the previous round (row Is+1, columns < Is): off the critical path
+        if constexpr (Is + 1 < NT && Is >= 1) {
+          if (16 * (Is + 1) < rE) {
+            static_for<Is>([&](auto J) __attribute__((always_inline)) {
+              if constexpr (TM::wave(Is + 1, J) == WAVE) tile_update(std::integral_constant<int, Is + 1>{}, J, pa0, pa1, pa2, pa3);
+            });
+          }
+        }
+        if constexpr (Is > 0) {
+          __syncthreads();                                          // beta_Is visible; deferred updates ordered
+          if (live) {
+            const double* bp = beta + 16 * Is + l4;
+            const int rw = 16 * Is + l4;                            // rows >= rE (rhs row, padding) carry no beta
+            pa0 = (l15 == 0 && rw < rE) ? bp[0] : 0.0;
+            pa1 = (l15 == 0 && rw + 4 < rE) ? bp[4] : 0.0;
+            pa2 = (l15 == 0 && rw + 8 < rE) ? bp[8] : 0.0;
+            pa3 = (l15 == 0 && rw + 12 < rE) ? bp[12] : 0.0;
+            if constexpr (TM::wave(Is, Is - 1) == WAVE)
+              tile_update(std::integral_constant<int, Is>{}, std::integral_constant<int, Is - 1>{}, pa0, pa1, pa2, pa3);
+          }
+          __syncthreads();                                          // y_{Is-1} complete
         }
       });
       __syncthreads();
