@@ -66,6 +66,7 @@ def build(force: bool = False, jobs: int = 0, verbose: bool = True) -> str:
         tasks.append(([hipcc] + COMMON_FLAGS + ["-DDDMPC_INST_NT=%d" % nt, "-DDDMPC_INST_W=%d" % w, "-c",
                                                  os.path.join(CSRC, "ddmpc_inst.hip"), "-o", obj], obj))
     todo = [(c, o) for c, o in tasks if force or not os.path.exists(o) or os.path.getmtime(o) < newest]
+    todo.sort(key=lambda t: -int(re.search(r"ddmpc_inst_(\d+)_", t[1]).group(1)) if "ddmpc_inst_" in t[1] else 0)  # longest first
     if todo:
         jobs = jobs or min(len(todo), max(1, (os.cpu_count() or 2) - 1), 8)
         if verbose:

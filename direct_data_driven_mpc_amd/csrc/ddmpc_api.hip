@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -86,13 +87,12 @@ const KernelChoice kKernels[] = {
 };
 
 size_t lds_doubles_for(int NT, int xs_len) {
-  switch (NT) {
+  // the LDS carve-up depends on NT only (several W may share an NT)
 #define DDMPC_INSTANCE(NT_, W_) \
-  case NT_: return (size_t)Lds<NT_>::total(xs_len);
+  if (NT == NT_) return (size_t)Lds<NT_>::total(xs_len);
 #include "ddmpc_instances.inc"
 #undef DDMPC_INSTANCE
-    default: return 0;
-  }
+  return 0;
 }
 
 }  // namespace
@@ -286,6 +286,14 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   const KernelChoice* kc = nullptr;
   for (const KernelChoice& cand : kKernels)
     if (16 * cand.NT >= rows_needed) { kc = &cand; break; }
+  if (kc) {   // development knob: prefer a given number of waves per instance among equal-NT instances
+    const char* wenv = getenv("DDMPC_WAVES");
+    if (wenv) {
+      const int want = atoi(wenv);
+      for (const KernelChoice& cand : kKernels)
+        if (cand.NT == kc->NT && cand.W == want) { kc = &cand; break; }
+    }
+  }
   if (!kc) {
     delete h;
     return fail(DDMPC_ERR_UNSUPPORTED, "problem too large for the single-workgroup kernels: (m+p)(L+n) = %d rows", k.r);

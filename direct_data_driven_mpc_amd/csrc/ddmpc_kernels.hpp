@@ -29,7 +29,7 @@
 
 // minimum waves per SIMD requested from the register allocator (keeps MFMA in VGPR form)
 #ifndef DDMPC_MIN_WAVES
-#define DDMPC_MIN_WAVES(W) ((W) <= 4 ? 3 : 4)
+#define DDMPC_MIN_WAVES(W) ((W) <= 2 ? 2 : ((W) <= 4 ? 3 : 2))
 #endif
 
 namespace ddmpc {
@@ -125,10 +125,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // LDS carve-up (doubles).  Everything lives in ONE dynamic array (16-B aligned).
 // All offsets are compile-time; only the length of the trajectory region (last) is
-// a runtime value.  The union region U is time-shared:
-//   Gram      : base-sum slices
-//   Cholesky  : PT[2][4][RP]   (raw panel columns, double buffered)
-//   back subst: LROW[2][4][RP] (row blocks of L, double buffered)
+// a runtime value.  Region U holds the two Cholesky panel buffers:
+//   PT[4][RP] raw (negated) panel columns, LT[4][RP] the factored panel rows.
 template <int NT>
 struct Lds {
   static constexpr int RP = 16 * NT;
@@ -140,9 +138,8 @@ struct Lds {
   static constexpr int red = yc + 8;                   // 32
   static constexpr int ints = red + 32;                // int act[RP], int flags[8]
   static constexpr int U = (ints + (RP + 8 + 1) / 2 + 2) & ~1;
-  static constexpr int USIZE = 16 * RP;
-  static constexpr int ctab = U + USIZE;               // C[delta][a][b], delta < RP/4 (nch == 4 path)
-  static constexpr int xs = ctab + 4 * RP;             // trajectory, channel-interleaved
+  static constexpr int USIZE = 8 * RP;                 // PT[4][RP] + LT[4][RP]
+  static constexpr int xs = U + USIZE;                 // trajectory, channel-interleaved
   __host__ __device__ static constexpr int total(int xs_len) { return (xs + xs_len + 1) & ~1; }
 };
 
@@ -178,7 +175,6 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
   double* msave = sm + LD::msave;
   double* yc = sm + LD::yc;
   double* red = sm + LD::red;
-  double* ctab = sm + LD::ctab;
   int* act = reinterpret_cast<int*>(sm + LD::ints);
   int* flags = act + RP;            // [0] fail, [1] active set changed
 

@@ -315,3 +315,74 @@ def test_controller_closed_loop_matches_oracle(gpu, slack, n_mpc_step):
     u_ref, y_ref = orc.closed_loop(spec, inst["u_d"], inst["y_d"], inst["plant"], w, n_mpc_step=n_mpc_step)
     assert np.max(np.abs(u_sys - u_ref)) / np.max(np.abs(u_ref)) < 1e-8
     assert np.max(np.abs(y_sys - y_ref)) < 1e-9
+
+
+# ------------------------------------------------------------ Gram variants, diagnostics
+def test_dense_and_structured_gram_agree(gpu):
+    # gram_mode DENSE = plain H H' by MFMA (what the reference's Hankel product amounts to);
+    # STRUCTURED = Hankel sliding-window recurrence.  Both must match the oracle.
+    spec = orc.spec_from_params(slack_var_constraint_type=1)
+    B = 12
+    u_d, y_d, up, yp = _instances(B, seed0=300)
+    res = {}
+    for mode in (L.GRAM_DENSE, L.GRAM_STRUCTURED, L.GRAM_AUTO):
+        with _engine(spec, 400, B, gram_mode=mode) as eng:
+            eng.set_data(u_d, y_d)
+            u, cost, status, iters = eng.solve(up, yp)
+            f, b = eng.cost_model()
+        _check(spec, u_d, y_d, up, yp, u, cost, status, range(B))
+        res[mode] = (u, cost, iters, f)
+    assert np.max(np.abs(res[L.GRAM_DENSE][0] - res[L.GRAM_STRUCTURED][0])) / np.max(np.abs(res[L.GRAM_DENSE][0])) < 1e-10
+    assert np.array_equal(res[L.GRAM_AUTO][0], res[L.GRAM_STRUCTURED][0])       # AUTO == STRUCTURED for m+p == 4
+    assert np.array_equal(res[L.GRAM_DENSE][2], res[L.GRAM_STRUCTURED][2])
+    assert res[L.GRAM_DENSE][3] > 5 * res[L.GRAM_STRUCTURED][3]                 # dense Gram is charged r^2 c flops
+
+
+def test_repeatable_and_stamps_do_not_perturb(gpu):
+    spec = orc.spec_from_params()
+    B = 64
+    u_d, y_d, up, yp = _instances(B, seed0=900)
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(u_d, y_d)
+        u1, c1, _, _ = eng.solve(up, yp)
+        u2, c2, _, _ = eng.solve(up, yp)
+        assert np.array_equal(u1, u2) and np.array_equal(c1, c2)                 # bit-reproducible
+        eng.debug_stamps(True)
+        u3, c3, _, _ = eng.solve(up, yp)
+        st = eng.debug_stamps(False, fetch=True).astype(np.int64)
+        assert np.array_equal(u1, u3) and np.array_equal(c1, c3)
+        assert np.all(st[:, 14] > st[:, 0]) and np.all(np.diff(st[:, 0:7], axis=1) > 0)
+
+
+# -------------------------------------------------------------- other BASELINE configs
+@pytest.mark.parametrize("slack", [0, 1])
+def test_long_horizon_config4(gpu, slack):
+    # BASELINE configs[3]: L=60, N=1000 robust scheme (r = 256 -> the <17,8> kernel instance)
+    spec = orc.spec_from_params(L=60, N=1000, slack_var_constraint_type=slack)
+    B = 4
+    u_d, y_d, up, yp = _instances(B, N=1000, seed0=11)
+    with _engine(spec, 1000, B) as eng:
+        assert "17,8" in eng.kernel_name()
+        eng.set_data(u_d, y_d)
+        u, cost, status, iters = eng.solve(up, yp)
+        al = eng.get_solution("alpha")
+    _check(spec, u_d, y_d, up, yp, u, cost, status, range(B))
+    assert al.shape == (B, 937)
+
+
+def test_convex_active_set_converges_on_full_batch(gpu):
+    # slack CONVEX on 4096 seeds: every instance must reach a stable active set ("optimal"),
+    # a sample is compared with the full-space oracle, and the bound must hold everywhere
+    spec = orc.spec_from_params(slack_var_constraint_type=1)
+    B = 4096
+    u_d, y_d, up, yp = _instances(B)
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(u_d, y_d)
+        u, cost, status, iters = eng.solve(up, yp)
+        sig = eng.get_solution("sigma")
+    assert np.all(status == 0) and iters.min() >= 1 and iters.max() <= 10
+    assert np.max(np.abs(sig[:, 8:])) <= spec.c * spec.eps_max * (1 + 1e-12)
+    worst = np.argsort(-iters)[:3].tolist()
+    _check(spec, u_d, y_d, up, yp, u, cost, status, [0, 1777, 4095] + worst)
+    for b in worst:
+        assert int(iters[b]) == orc.solve_fullspace(spec, u_d[b], y_d[b], up[b], yp[b]).iters
