@@ -24,6 +24,10 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 2.4 GHz x 2048 flop / 64 clk (v_mfma_f64_16x16x4_f64),
                                # measured 64 clk/instr/SIMD in profiles/r01_mfma_f64_probe.log
+# HBM traffic of one default launch (4096 instances, slack NONE, structured Gram) from separate
+# rocprofv3 --pmc passes of this same command (profiles/r01_final_pmc_fetch.csv / _write.csv):
+# FETCH_SIZE 28,756 KB x2 (gfx950 counts wide reads at half) + WRITE_SIZE 13,785 KB.
+PMC_TRAFFIC_BYTES_DEFAULT = (2 * 28756 + 13785) * 1024
 
 
 def cpu_baseline(cfg, u_d, y_d, up, yp, u_gpu, cost_gpu, n_sample):
@@ -153,7 +157,8 @@ def main():
                        "global_batch": total, "parallelism": "instances sharded dp%d, no data-path collective, one final all-gather" % world,
                        "kernel": eng.kernel_name(), "non_optimal_instances": n_bad},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                         "traffic": (PMC_TRAFFIC_BYTES_DEFAULT if (a.batch_per_gpu == 4096 and a.slack == "none") else None),
                          "kernel_ms": kern_ms, "flops_per_solve": flops, "hbm_bytes_per_solve": bytes_,
                          "hbm_GBps_algorithmic": bytes_ * B / (kern_ms * 1e-3) / 1e9},
         }

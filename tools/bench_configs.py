@@ -1,0 +1,47 @@
+"""Dev tool: throughput of the other BASELINE configs / modes (not the headline bench line)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+import torch
+from direct_data_driven_mpc_amd import _lib as L
+from direct_data_driven_mpc_amd.engine import BatchedDDMPC
+from direct_data_driven_mpc_amd.harness import controller_params, generate_batch
+
+def run(tag, B, Lh, N, slack, gram=0, steps=10, host=False):
+    cfg = controller_params(dict(L=Lh, N=N, slack_var_constraint_type=slack))
+    d = generate_batch(range(B), N=N)
+    n, m, p = 4, 2, 2
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    eng = BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=cfg["Q"], R=cfg["R"], u_s=cfg["u_s"], y_s=cfg["y_s"], batch=B,
+                       controller_type=L.ROBUST, slack_type=L.SLACK_CONVEX if slack else L.SLACK_NONE,
+                       eps_max=cfg["eps_max"], lamb_alpha=cfg["lamb_alpha"], lamb_sigma=cfg["lamb_sigma"], c=cfg["c"], gram_mode=gram)
+    dev = torch.device("cuda", 0)
+    if host:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.set_data(d["u_d"], d["y_d"]); eng.solve(up, yp)
+        dt = (time.perf_counter() - t0) / steps
+    else:
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        ud, yd, upt, ypt = t(d["u_d"]), t(d["y_d"]), t(up), t(yp)
+        eng.set_data(ud, yd)
+        out = eng.solve(upt, ypt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.solve(upt, ypt, *out)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        st = out[2].cpu().numpy(); it = out[3].cpu().numpy()
+        tag += " status_ok=%d iters_mean=%.2f" % (int((st == 0).sum()), it.mean())
+    f, b = eng.cost_model()
+    print("%-70s kernel %-30s B=%6d  %.3f ms/step  %.3e solves/s  %.2f TFLOP/s(alg)" % (tag, eng.kernel_name(), B, dt * 1e3, B / dt, f * B / dt / 1e12), flush=True)
+    eng.close()
+
+run("cfg2 robust NONE structured", 4096, 30, 400, 0)
+run("cfg2 robust NONE dense-MFMA Gram", 4096, 30, 400, 0, gram=1)
+run("cfg2 robust CONVEX (slack box, active set)", 4096, 30, 400, 1)
+run("cfg3 shard: robust NONE, 32768 per GPU", 32768, 30, 400, 0, steps=5)
+run("cfg4 robust NONE L=60 N=1000", 1024, 60, 1000, 0)
+run("cfg4 robust CONVEX L=60 N=1000", 1024, 60, 1000, 1)
+run("cfg2 PCIe-inclusive (host pointers: upload u_d,y_d + solve + download)", 4096, 30, 400, 0, host=True, steps=5)
