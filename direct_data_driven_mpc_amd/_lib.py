@@ -26,6 +26,7 @@ EXPORTS = (
     "ddmpc_version", "ddmpc_last_error", "ddmpc_device_count", "ddmpc_create", "ddmpc_destroy",
     "ddmpc_set_stream", "ddmpc_synchronize", "ddmpc_set_data", "ddmpc_solve", "ddmpc_set_setpoints",
     "ddmpc_get_solution", "ddmpc_hankel", "ddmpc_cost_model", "ddmpc_kernel_name", "ddmpc_debug_stamps",
+    "ddmpc_closed_loop",
 )
 
 c_double_p = C.POINTER(C.c_double)
@@ -43,6 +44,11 @@ class Params(C.Structure):
         ("u_s", c_double_p), ("y_s", c_double_p),
         ("max_iter", C.c_int32), ("gram_mode", C.c_int32),
     ]
+
+
+class Plant(C.Structure):
+    """struct ddmpc_plant (include/ddmpc.h)."""
+    _fields_ = [("ns", C.c_int32), ("A", c_double_p), ("B", c_double_p), ("C", c_double_p), ("D", c_double_p)]
 
 
 class DDMPCError(RuntimeError):
@@ -83,6 +89,8 @@ def load() -> C.CDLL:
     lib.ddmpc_kernel_name.restype = C.c_char_p
     lib.ddmpc_debug_stamps.argtypes = [vp, C.c_int, vp]
     lib.ddmpc_debug_stamps.restype = C.c_int
+    lib.ddmpc_closed_loop.argtypes = [vp, C.POINTER(Plant), C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    lib.ddmpc_closed_loop.restype = C.c_int
     for name in ("ddmpc_create", "ddmpc_destroy", "ddmpc_set_stream", "ddmpc_synchronize", "ddmpc_set_data",
                  "ddmpc_solve", "ddmpc_set_setpoints", "ddmpc_get_solution", "ddmpc_hankel", "ddmpc_cost_model"):
         getattr(lib, name).restype = C.c_int

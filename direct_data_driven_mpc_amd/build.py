@@ -35,9 +35,14 @@ def _hipcc() -> str:
     return exe
 
 
+SKIP_LARGE = os.environ.get("DDMPC_SKIP_LARGE", "") not in ("", "0")   # development only
+LARGE_NT = 16
+
+
 def instances():
     txt = open(os.path.join(CSRC, "ddmpc_instances.inc")).read()
-    return [(int(a), int(b)) for a, b in re.findall(r"^DDMPC_INSTANCE\((\d+),\s*(\d+)\)", txt, re.M)]
+    inst = [(int(a), int(b)) for a, b in re.findall(r"^DDMPC_INSTANCE\((\d+),\s*(\d+)\)", txt, re.M)]
+    return [(nt, w) for nt, w in inst if not (SKIP_LARGE and nt > LARGE_NT)]
 
 
 def _newest_src() -> float:
@@ -59,8 +64,9 @@ def build(force: bool = False, jobs: int = 0, verbose: bool = True) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     newest = _newest_src()
     tasks = []
-    api_obj = os.path.join(OBJ_DIR, "ddmpc_api.o")
-    tasks.append(([hipcc] + COMMON_FLAGS + ["-c", os.path.join(CSRC, "ddmpc_api.hip"), "-o", api_obj], api_obj))
+    api_obj = os.path.join(OBJ_DIR, "ddmpc_api_nolarge.o" if SKIP_LARGE else "ddmpc_api.o")
+    api_flags = ["-DDDMPC_NO_LARGE"] if SKIP_LARGE else []
+    tasks.append(([hipcc] + COMMON_FLAGS + api_flags + ["-c", os.path.join(CSRC, "ddmpc_api.hip"), "-o", api_obj], api_obj))
     for nt, w in instances():
         obj = os.path.join(OBJ_DIR, "ddmpc_inst_%d_%d.o" % (nt, w))
         tasks.append(([hipcc] + COMMON_FLAGS + ["-DDDMPC_INST_NT=%d" % nt, "-DDDMPC_INST_W=%d" % w, "-c",

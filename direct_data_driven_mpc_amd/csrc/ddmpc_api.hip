@@ -116,6 +116,7 @@ struct ddmpc_handle {
   const double* yd = nullptr;
   // staging for host-memory solves + workspace for get_solution
   DevBuf d_up, d_yp, d_uopt, d_cost, d_status, d_iters, d_beta, d_act, d_out, d_stamps;
+  DevBuf d_pl, d_x, d_w, d_usys, d_ysys, d_stacc;
   bool stamps_on = false;
   const double* last_up = nullptr;
   const double* last_yp = nullptr;
@@ -332,7 +333,8 @@ int ddmpc_destroy(ddmpc_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
-                    &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps};
+                    &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
+                    &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc};
   for (DevBuf* b : bufs) b->release();
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -510,6 +512,78 @@ int ddmpc_hankel(const double* X, int64_t batch, int32_t N, int32_t nch, int32_t
   (void)hipFree(dX);
   (void)hipFree(dH);
   if (e != hipSuccess) return fail(DDMPC_ERR_HIP, "ddmpc_hankel: %s", hipGetErrorString(e));
+  return DDMPC_OK;
+}
+
+int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps, int32_t n_mpc_step, double* x,
+                      double* u_past, double* y_past, const double* w, double* u_sys, double* y_sys,
+                      int32_t* status, int mem) {
+  if (!h || !plant || !x || !u_past || !y_past || !w || !u_sys || !y_sys || !status)
+    return fail(DDMPC_ERR_INVALID, "null argument");
+  if (!h->have_data) return fail(DDMPC_ERR_NOT_READY, "ddmpc_set_data must be called before ddmpc_closed_loop");
+  if (n_steps <= 0 || n_mpc_step <= 0) return fail(DDMPC_ERR_INVALID, "n_steps and n_mpc_step must be positive");
+  const ddmpc_params& p = h->prm;
+  if (n_mpc_step > p.L) return fail(DDMPC_ERR_INVALID, "n_mpc_step must not exceed the prediction horizon L");
+  if (plant->ns <= 0 || plant->ns > 16 || !plant->A || !plant->B || !plant->C || !plant->D)
+    return fail(DDMPC_ERR_INVALID, "plant: need 1 <= ns <= 16 and A, B, C, D");
+  if (mem != DDMPC_MEM_HOST && mem != DDMPC_MEM_DEVICE)
+    return fail(DDMPC_ERR_INVALID, "mem must be DDMPC_MEM_HOST or DDMPC_MEM_DEVICE");
+  HIP_TRY(hipSetDevice(h->device));
+  const int ns = plant->ns, m = p.m, pp = p.p, n = p.n;
+  const size_t B = (size_t)h->batch;
+  int rc;
+  // plant matrices -> device
+  std::vector<double> pl;
+  pl.insert(pl.end(), plant->A, plant->A + ns * ns);
+  pl.insert(pl.end(), plant->B, plant->B + ns * m);
+  pl.insert(pl.end(), plant->C, plant->C + pp * ns);
+  pl.insert(pl.end(), plant->D, plant->D + pp * m);
+  if ((rc = h->d_pl.ensure(pl.size() * sizeof(double)))) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_pl.p, pl.data(), pl.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if ((rc = h->d_uopt.ensure(B * p.L * m * sizeof(double)))) return rc;
+  if ((rc = h->d_cost.ensure(B * sizeof(double)))) return rc;
+  if ((rc = h->d_status.ensure(B * sizeof(int32_t)))) return rc;
+  if ((rc = h->d_stacc.ensure(B * sizeof(int32_t)))) return rc;
+  HIP_TRY(hipMemsetAsync(h->d_stacc.p, 0, B * sizeof(int32_t), h->stream));
+  double *dx = x, *dup = u_past, *dyp = y_past, *dus = u_sys, *dys = y_sys;
+  const double* dw = w;
+  const size_t nx = B * ns * sizeof(double), nup = B * n * m * sizeof(double), nyp = B * n * pp * sizeof(double);
+  const size_t nw = B * (size_t)n_steps * pp * sizeof(double), nus = B * (size_t)n_steps * m * sizeof(double);
+  if (mem == DDMPC_MEM_HOST) {
+    if ((rc = h->d_x.ensure(nx)) || (rc = h->d_up.ensure(nup)) || (rc = h->d_yp.ensure(nyp)) ||
+        (rc = h->d_w.ensure(nw)) || (rc = h->d_usys.ensure(nus)) || (rc = h->d_ysys.ensure(nw)))
+      return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_x.p, x, nx, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_up.p, u_past, nup, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_yp.p, y_past, nyp, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_w.p, w, nw, hipMemcpyHostToDevice, h->stream));
+    dx = (double*)h->d_x.p; dup = (double*)h->d_up.p; dyp = (double*)h->d_yp.p; dw = (const double*)h->d_w.p;
+    dus = (double*)h->d_usys.p; dys = (double*)h->d_ysys.p;
+  }
+  const unsigned pblocks = (unsigned)((B + 127) / 128);
+  for (int t = 0; t < n_steps; t += n_mpc_step) {
+    if ((rc = launch_cold(h, dup, dyp, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int32_t*)h->d_status.p, nullptr)))
+      return rc;
+    const int nsub = (t + n_mpc_step <= n_steps) ? n_mpc_step : n_steps - t;
+    hipLaunchKernelGGL(ddmpc_plant_kernel, dim3(pblocks), dim3(128), 0, h->stream, (long long)B, ns, m, pp, n,
+                       p.L * m, (const double*)h->d_pl.p, t, nsub, n_steps, (const double*)h->d_uopt.p,
+                       (const int*)h->d_status.p, (int*)h->d_stacc.p, dx, dup, dyp, dw, dus, dys);
+    HIP_TRY(hipGetLastError());
+  }
+  h->last_up = dup;
+  h->last_yp = dyp;
+  h->solved = true;
+  if (mem == DDMPC_MEM_HOST) {
+    HIP_TRY(hipMemcpyAsync(x, dx, nx, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(u_past, dup, nup, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(y_past, dyp, nyp, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(u_sys, dus, nus, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(y_sys, dys, nw, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(status, h->d_stacc.p, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(status, h->d_stacc.p, B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+  }
   return DDMPC_OK;
 }
 

@@ -830,6 +830,64 @@ __global__ void ddmpc_reconstruct_kernel(KParams P, int RPs, int what, const dou
     if (what == 3) out[b * (long long)(P.Ln * P.p) + k * P.p + cy] = sg;
   }
 }
+// --------------------------------------------------------------------------
+// Closed-loop glue: apply up to `nsub` inputs of the last solve to the plant, record the
+// trajectories, push (u,y) into the past windows.  One thread per instance (tiny matvecs).
+//   pl: [A (ns*ns) | B (ns*m) | C (p*ns) | D (p*m)] row-major.
+// utilities/controller/controller_operation.py:278-305, utilities/model_simulation.py:93-98,
+// direct_data_driven_mpc_controller.py:893-895.
+// --------------------------------------------------------------------------
+__global__ void ddmpc_plant_kernel(long long batch, int ns, int m, int p, int n, int Lm, const double* __restrict__ pl,
+                                   int t0, int nsub, int n_steps, const double* __restrict__ u_opt,
+                                   const int* __restrict__ st_step, int* __restrict__ st_acc,
+                                   double* __restrict__ x, double* __restrict__ u_past, double* __restrict__ y_past,
+                                   const double* __restrict__ w, double* __restrict__ u_sys, double* __restrict__ y_sys) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const double* A = pl;
+  const double* Bm = A + ns * ns;
+  const double* C = Bm + ns * m;
+  const double* D = C + p * ns;
+  int acc = st_acc[b];
+  if (st_step[b] > acc) acc = st_step[b];
+  st_acc[b] = acc;
+  double* xb = x + b * ns;
+  double* up = u_past + b * (long long)(n * m);
+  double* yp = y_past + b * (long long)(n * p);
+  const double* uo = u_opt + b * (long long)Lm;
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+  for (int j = 0; j < nsub; ++j) {
+    const int k = t0 + j;
+    double* us = u_sys + (b * n_steps + k) * m;
+    double* ys = y_sys + (b * n_steps + k) * p;
+    if (acc > 1) {                               // not optimal / optimal_inaccurate: the reference raises here
+      for (int i = 0; i < m; ++i) us[i] = nanv;
+      for (int i = 0; i < p; ++i) ys[i] = nanv;
+      continue;
+    }
+    const double* uk = uo + j * m;
+    const double* wk = w + (b * n_steps + k) * p;
+    for (int i = 0; i < p; ++i) {                // y = C x + D u + w, with the state BEFORE the update
+      double s = wk[i];
+      for (int q = 0; q < ns; ++q) s += C[i * ns + q] * xb[q];
+      for (int q = 0; q < m; ++q) s += D[i * m + q] * uk[q];
+      ys[i] = s;
+    }
+    double xn[16];
+    for (int i = 0; i < ns; ++i) {
+      double s = 0.0;
+      for (int q = 0; q < ns; ++q) s += A[i * ns + q] * xb[q];
+      for (int q = 0; q < m; ++q) s += Bm[i * m + q] * uk[q];
+      xn[i] = s;
+    }
+    for (int i = 0; i < ns; ++i) xb[i] = xn[i];
+    for (int i = 0; i < m; ++i) us[i] = uk[i];
+    for (int i = 0; i < (n - 1) * m; ++i) up[i] = up[i + m];       // FIFO shift
+    for (int i = 0; i < m; ++i) up[(n - 1) * m + i] = uk[i];
+    for (int i = 0; i < (n - 1) * p; ++i) yp[i] = yp[i + p];
+    for (int i = 0; i < p; ++i) yp[(n - 1) * p + i] = ys[i];
+  }
+}
 #endif  // DDMPC_WITH_AUX_KERNELS
 
 }  // namespace ddmpc

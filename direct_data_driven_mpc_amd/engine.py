@@ -180,6 +180,33 @@ class BatchedDDMPC:
         self._keep["solve"] = (k1, k2, k3, k4, k5, k6)
         return u_opt, cost, status, iters
 
+    def closed_loop(self, A, B, Cm, D, x0, u_past, y_past, w, n_mpc_step: int = 1):
+        """Batched closed loop on the device (controller_operation.py:259-305 for every instance).
+
+        A,B,Cm,D: plant matrices; x0 [batch,ns]; u_past [batch,n*m], y_past [batch,n*p];
+        w [batch,n_steps,p] measurement noise.  Returns (u_sys, y_sys, status, x_end, u_past_end, y_past_end)
+        as host arrays (inputs are not modified)."""
+        A = np.ascontiguousarray(A, dtype=np.float64); Bm = np.ascontiguousarray(B, dtype=np.float64)
+        Cm = np.ascontiguousarray(Cm, dtype=np.float64); D = np.ascontiguousarray(D, dtype=np.float64)
+        ns = A.shape[0]
+        if A.shape != (ns, ns) or Bm.shape != (ns, self.m) or Cm.shape != (self.p, ns) or D.shape != (self.p, self.m):
+            raise ValueError("plant matrices have inconsistent shapes")
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        if w.ndim != 3 or w.shape[0] != self.batch or w.shape[2] != self.p:
+            raise ValueError("w must have shape [batch, n_steps, p]")
+        n_steps = w.shape[1]
+        x = np.array(x0, dtype=np.float64, order="C").reshape(self.batch, ns).copy()
+        up = np.array(u_past, dtype=np.float64, order="C").reshape(self.batch, self.n * self.m).copy()
+        yp = np.array(y_past, dtype=np.float64, order="C").reshape(self.batch, self.n * self.p).copy()
+        u_sys = np.empty((self.batch, n_steps, self.m)); y_sys = np.empty((self.batch, n_steps, self.p))
+        status = np.empty((self.batch,), dtype=np.int32)
+        pl = L.Plant(ns, A.ctypes.data_as(L.c_double_p), Bm.ctypes.data_as(L.c_double_p),
+                     Cm.ctypes.data_as(L.c_double_p), D.ctypes.data_as(L.c_double_p))
+        vp = lambda a: C.c_void_p(a.ctypes.data)
+        L.check(self._lib.ddmpc_closed_loop(self._h, C.byref(pl), n_steps, int(n_mpc_step), vp(x), vp(up), vp(yp), vp(w),
+                                            vp(u_sys), vp(y_sys), vp(status), L.MEM_HOST))
+        return u_sys, y_sys, status, x, up, yp
+
     def set_setpoints(self, u_s, y_s) -> None:
         us = np.ascontiguousarray(np.asarray(u_s, dtype=np.float64).reshape(-1))
         ys = np.ascontiguousarray(np.asarray(y_s, dtype=np.float64).reshape(-1))

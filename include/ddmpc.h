@@ -143,6 +143,33 @@ int ddmpc_get_solution(ddmpc_handle* h, int what, double* out, int mem);
 int ddmpc_hankel(const double* X, int64_t batch, int32_t N, int32_t nch, int32_t L,
                  double* H, int mem, int device);
 
+/* LTI plant x+ = A x + B u, y = C x + D u + w (utilities/model_simulation.py:70-98); row-major HOST pointers. */
+typedef struct ddmpc_plant {
+  int32_t ns;                       /* state dimension                              */
+  const double* A;                  /* [ns,ns]                                      */
+  const double* B;                  /* [ns,m]                                       */
+  const double* C;                  /* [p,ns]                                       */
+  const double* D;                  /* [p,m]                                        */
+} ddmpc_plant;
+
+/* Batched closed loop, entirely on the device: the driver loop of
+ * utilities/controller/controller_operation.py:259-305 (Algorithm 1, and the n-step
+ * Algorithm 2 when n_mpc_step > 1) for every instance of the batch:
+ *   for t = 0, n_mpc_step, 2 n_mpc_step, ... < n_steps:
+ *     cold QP solve with the current past windows              (controller.py:389-407)
+ *     for k = t .. min(t + n_mpc_step, n_steps) - 1:
+ *       u[k] = optimal_u[(k-t) m : (k-t+1) m]                  (controller.py:839)
+ *       y[k] = C x + D u[k] + w[k];  x <- A x + B u[k]         (model_simulation.py:93-98)
+ *       FIFO push of (u[k], y[k]) into the past windows         (controller.py:893-895)
+ * x [batch,ns], u_past [batch,n*m], y_past [batch,n*p] are updated in place;
+ * w [batch,n_steps,p] is the measurement noise; u_sys [batch,n_steps,m], y_sys [batch,n_steps,p]
+ * receive the closed-loop trajectories; status [batch] the worst solve status seen (an instance whose
+ * solve is not optimal stops evolving -- the reference raises at that point, controller.py:808 --
+ * and the rest of its trajectory is NaN).  All buffers follow `mem`. */
+int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps, int32_t n_mpc_step,
+                      double* x, double* u_past, double* y_past, const double* w,
+                      double* u_sys, double* y_sys, int32_t* status, int mem);
+
 /* Kernel facts for benchmarking: algorithmic flops and bytes of one cold solve
  * with this handle's configuration (see DESIGN.md "Roofline accounting"). */
 int ddmpc_cost_model(ddmpc_handle* h, double* flops_per_solve, double* bytes_per_solve);

@@ -386,3 +386,82 @@ def test_convex_active_set_converges_on_full_batch(gpu):
     _check(spec, u_d, y_d, up, yp, u, cost, status, [0, 1777, 4095] + worst)
     for b in worst:
         assert int(iters[b]) == orc.solve_fullspace(spec, u_d[b], y_d[b], up[b], yp[b]).iters
+
+
+# ------------------------------------------------------ batched closed loop on the device
+@pytest.mark.parametrize("kw,n_mpc_step", [(dict(), 4), (dict(slack_var_constraint_type=1), 1), (dict(tec=False), 1)],
+                         ids=["tec-nstep4", "tec-convex-1step", "ucon-1step"])
+def test_device_closed_loop_matches_oracle(gpu, kw, n_mpc_step):
+    # the loop of utilities/controller/controller_operation.py:259-305 for a batch of
+    # instances, entirely on the device, vs the same loop on the CPU oracle with identical noise.
+    spec = orc.spec_from_params(**kw)
+    B, n_steps = 3, 14
+    insts = [orc.generate_instance(s) for s in range(B)]
+    u_d = np.stack([i["u_d"] for i in insts]); y_d = np.stack([i["y_d"] for i in insts])
+    x0 = np.stack([i["plant"].x for i in insts])
+    w = np.stack([i["plant"].eps_max * i["rng"].uniform(-1.0, 1.0, (n_steps, 2)) for i in insts])
+    up = u_d[:, -4:, :].reshape(B, -1); yp = y_d[:, -4:, :].reshape(B, -1)
+    P = orc.FOUR_TANK
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(u_d, y_d)
+        u_sys, y_sys, status, x_end, up_end, yp_end = eng.closed_loop(P["A"], P["B"], P["C"], P["D"], x0, up, yp, w,
+                                                                      n_mpc_step=n_mpc_step)
+    assert np.all(status == 0)
+    for b in range(B):
+        u_ref, y_ref = orc.closed_loop(spec, u_d[b], y_d[b], insts[b]["plant"], w[b], n_mpc_step=n_mpc_step)
+        assert np.max(np.abs(u_sys[b] - u_ref)) / np.max(np.abs(u_ref)) < 1e-8
+        assert np.max(np.abs(y_sys[b] - y_ref)) < 1e-9
+        assert np.max(np.abs(x_end[b] - insts[b]["plant"].x)) < 1e-9           # oracle plant was advanced in place
+        assert np.allclose(up_end[b], u_sys[b, -4:].reshape(-1)) and np.allclose(yp_end[b], y_sys[b, -4:].reshape(-1))
+
+
+def test_paper_reproduction_known_answers(gpu):
+    # Behavioural known answers of the reference's reproduction script (seed 4, y_0 = [0.4, 0.4],
+    # t_sim = 600; examples/robust_data_driven_mpc_reproduction.py:126-295, README figure): TEC and
+    # TEC n-step converge to y_s, UCON diverges past |u| = 15 around k = 384.
+    inst = orc.generate_instance(4)
+    plant, rng = inst["plant"], inst["rng"]
+    u_d, y_d = inst["u_d"], inst["y_d"]
+    n, n_steps = 4, 600
+    y0 = np.array([0.4, 0.4])
+    u_eq = plant.equilibrium_input_from_output(y0)
+    x_eq = plant.initial_state_from_trajectory(np.tile(u_eq, n), np.tile(y0, n))     # paper_reproduction.py:80-116
+    plant.x = x_eq
+    U_n = np.tile(np.array([1.0, 1.0]), (n, 1))                                       # controller_operation.py:190-197
+    W_n = plant.eps_max * rng.uniform(-1.0, 1.0, (n, 2))
+    Y_n = plant.simulate(U_n, W_n)
+    x_start = plant.x.copy()
+    P = orc.FOUR_TANK
+    out = {}
+    for tag, kw, step in (("tec", {}, 1), ("tec_n", {}, 4), ("ucon", dict(tec=False), 1)):
+        spec = orc.spec_from_params(**kw)
+        w = plant.eps_max * rng.uniform(-1.0, 1.0, (n_steps - n, 2))                  # drawn per controller, in order
+        with _engine(spec, 400, 1) as eng:
+            eng.set_data(u_d[None], y_d[None])
+            u_sys, y_sys, status, *_ = eng.closed_loop(P["A"], P["B"], P["C"], P["D"], x_start[None], U_n.reshape(1, -1),
+                                                       Y_n.reshape(1, -1), w[None], n_mpc_step=step)
+        assert status[0] == 0
+        out[tag] = (u_sys[0], y_sys[0])
+    assert np.allclose(out["tec"][0][0], [8.6604991, 8.53323249], atol=2e-7)
+    assert np.allclose(out["tec_n"][0][0], [8.6604991, 8.53323249], atol=2e-7)
+    assert np.allclose(out["ucon"][0][0], [7.89630434, 9.2946719], atol=2e-7)
+    assert np.all(np.abs(out["tec"][1][-1] - [0.65, 0.77]) < 0.02) and np.all(np.abs(out["tec_n"][1][-1] - [0.65, 0.77]) < 0.02)
+    big = np.nonzero(np.max(np.abs(out["ucon"][0]), axis=1) > 15.0)[0]
+    assert big.size > 0 and abs(int(big[0]) + n - 384) <= 2          # k counted from the start of the n warm-up steps
+
+
+def test_device_closed_loop_full_batch_converges(gpu):
+    # 512 instances x 201 steps (n-step scheme, 51 solves each) entirely on the device: every
+    # instance must settle near the setpoint (y -> (0.65, 0.77), u -> (1, 1))
+    spec = orc.spec_from_params()
+    B, n_steps = 512, 201
+    d = generate_batch(range(B))
+    rng = np.random.default_rng(123)
+    w = 0.002 * rng.uniform(-1.0, 1.0, (B, n_steps, 2))
+    up = d["u_d"][:, -4:, :].reshape(B, -1); yp = d["y_d"][:, -4:, :].reshape(B, -1)
+    P = orc.FOUR_TANK
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(d["u_d"], d["y_d"])
+        u_sys, y_sys, status, *_ = eng.closed_loop(P["A"], P["B"], P["C"], P["D"], d["x_end"], up, yp, w, n_mpc_step=4)
+    assert np.all(status == 0) and np.all(np.isfinite(u_sys))
+    assert np.max(np.abs(y_sys[:, -1] - spec.y_s)) < 0.05 and np.max(np.abs(u_sys[:, -1] - spec.u_s)) < 0.5
