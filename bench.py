@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--slack", choices=["none", "convex"], default="none")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development only: run all ranks on device 0 with the gloo backend (exercises the "
+                         "multi-rank code path on a one-GPU box; numbers are meaningless)")
     a = ap.parse_args()
 
     import torch
@@ -88,10 +91,15 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    if a.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if a.rehearse_on_one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     cfg = controller_params(dict(slack_var_constraint_type=1 if a.slack == "convex" else 0))
     total = a.batch_per_gpu * world
@@ -117,7 +125,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            if a.rehearse_on_one_gpu:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
 
     for _ in range(a.warmup):
         eng.solve(up, yp, u_opt, cost, status, iters)
@@ -131,11 +142,14 @@ def main():
         eng.solve(up, yp, u_opt, cost, status, iters)
         ev[k][1].record()
     if world > 1:
-        g_u, g_c, g_s = gather_results(u_opt, cost, status, total)
+        if a.rehearse_on_one_gpu:
+            g_u, g_c, g_s = gather_results(u_opt.cpu(), cost.cpu(), status.cpu(), total)
+        else:
+            g_u, g_c, g_s = gather_results(u_opt, cost, status, total)
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=("cpu" if a.rehearse_on_one_gpu else dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
@@ -143,6 +157,7 @@ def main():
     n_bad = int(np.count_nonzero(st != 0))
     if world > 1:
         n_bad = int(np.count_nonzero(g_s.cpu().numpy() != 0))
+        assert g_u.shape[0] == total and torch.equal(g_u[lo:hi].cpu(), u_opt.cpu()), "gather mismatch"
 
     if rank == 0:
         flops, bytes_ = eng.cost_model()

@@ -207,6 +207,14 @@ class BatchedDDMPC:
                                             vp(u_sys), vp(y_sys), vp(status), L.MEM_HOST))
         return u_sys, y_sys, status, x, up, yp
 
+    def persistent_excitation_ranks(self, u_d) -> np.ndarray:
+        """Rank of the order-(L+2n) Hankel matrix of every instance's input data, the reference's
+        construction-time guard (controller.py:275-296, hankel_matrix.py:55-87): Hankel gather on the
+        GPU, ranks by batched SVD on the host with numpy's default tolerance (exactly the reference's
+        test).  An instance is persistently exciting iff its rank equals m*(L+2n)."""
+        H = hankel_matrix_batched(np.asarray(u_d, dtype=np.float64), self.L + 2 * self.n, device=self.device)
+        return np.linalg.matrix_rank(H)
+
     def set_setpoints(self, u_s, y_s) -> None:
         us = np.ascontiguousarray(np.asarray(u_s, dtype=np.float64).reshape(-1))
         ys = np.ascontiguousarray(np.asarray(y_s, dtype=np.float64).reshape(-1))

@@ -465,3 +465,13 @@ def test_device_closed_loop_full_batch_converges(gpu):
         u_sys, y_sys, status, *_ = eng.closed_loop(P["A"], P["B"], P["C"], P["D"], d["x_end"], up, yp, w, n_mpc_step=4)
     assert np.all(status == 0) and np.all(np.isfinite(u_sys))
     assert np.max(np.abs(y_sys[:, -1] - spec.y_s)) < 0.05 and np.max(np.abs(u_sys[:, -1] - spec.u_s)) < 0.5
+
+
+def test_batched_persistent_excitation_guard(gpu, golden):
+    spec = orc.spec_from_params()
+    B = 6
+    u_d, y_d, up, yp = _instances(B)
+    u_bad = u_d.copy(); u_bad[3] = 1.0                       # constant input: not persistently exciting
+    with _engine(spec, 400, B) as eng:
+        ranks = eng.persistent_excitation_ranks(u_bad)
+    assert ranks.tolist() == [76, 76, 76, int(golden["const_pe_rank"][0]), 76, 76]
