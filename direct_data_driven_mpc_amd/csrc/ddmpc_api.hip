@@ -302,7 +302,7 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   h->kc = *kc;
   // dense-Gram operand reads reach (c+2)*nch + 16*NT; the structured walks read up to
   // x[c + 4*NT + 2]; everything past N*nch is zero padding
-  k.xs_len = ((p.N - k.Ln + 4) * k.nch + 16 * kc->NT + 8 + 1) & ~1;
+  k.xs_len = ((p.N - k.Ln + 4) * k.nch + 16 * kc->NT + 8 + 64 + 1) & ~1;   // + lag groups past Ln in the 4x4x4 base loop
   if (k.xs_len < (p.N + 2) * k.nch) k.xs_len = ((p.N + 2) * k.nch + 1) & ~1;
   const size_t lds_doubles = lds_doubles_for(kc->NT, k.xs_len);
   h->lds_bytes = lds_doubles * sizeof(double);

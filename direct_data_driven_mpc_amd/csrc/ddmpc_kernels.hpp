@@ -139,7 +139,8 @@ struct Lds {
   static constexpr int ints = red + 32;                // int act[RP], int flags[8]
   static constexpr int U = (ints + (RP + 8 + 1) / 2 + 2) & ~1;
   static constexpr int USIZE = 8 * RP;                 // PT[4][RP] + LT[4][RP]
-  static constexpr int xs = U + USIZE;                 // trajectory, channel-interleaved
+  static constexpr int ctab = U + USIZE;               // lag blocks C[d][a][b], d < RP/4 (structured Gram)
+  static constexpr int xs = ctab + 4 * RP;             // trajectory, channel-interleaved
   __host__ __device__ static constexpr int total(int xs_len) { return (xs + xs_len + 1) & ~1; }
 };
 
@@ -175,6 +176,7 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
   double* msave = sm + LD::msave;
   double* yc = sm + LD::yc;
   double* red = sm + LD::red;
+  double* ctab = sm + LD::ctab;
   int* act = reinterpret_cast<int*>(sm + LD::ints);
   int* flags = act + RP;            // [0] fail, [1] active set changed
 
@@ -273,34 +275,100 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
       //   tile(I+1,J+1) = tile(I,J) - sum_{i<4} a_I(i) b_J(i)' + sum_{c<=i<c+4} a_I(i) b_J(i)',
       // i.e. one rank-4 downdate and one rank-4 update = 2 MFMAs (the Hankel sliding-window
       // recurrence in matrix form).  Only the first tile of each diagonal needs the full sum.
+      const int c = P.c, Ln = P.Ln;
+      // (explicit definition of every tile: keeps the previous active-set iteration's values from
+      //  being considered live across the loop back-edge)
       static_for<TM::MAXS>([&](auto S) __attribute__((always_inline)) { acc[S] = d4{0.0, 0.0, 0.0, 0.0}; });
-      const int c = P.c;
+      // (1) lag blocks C_d(a,b) = sum_{t<c} x_a[t+d] x_b[t] (= G(d,0)) by v_mfma_f64_4x4x4_4b: one
+      //     instruction does 4 lags x 4 time steps with no wasted outputs (17 clk vs 64 for a
+      //     16x16x4).  Lane layout (probed, tools/mfma_f64_4x4_probe.hip): A_blk[i][k] at lane
+      //     (k<<4 | blk<<2 | i), B_blk[k][j] at (k<<4 | blk<<2 | j), D_blk[i][j] at (i<<4 | blk<<2 | j).
       {
+        constexpr int MAXG = (NT + W - 1) / W;             // lag groups (4 lags each) per wave
+        const int ngroups = (Ln + 3) >> 2;
+        const int kq = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
+        double cacc[MAXG];
+        static_for<MAXG>([&](auto gi) __attribute__((always_inline)) { cacc[gi()] = 0.0; });
+        const double* pB = xs + 4 * kq + ij;               // B[k][j] = x_j[t0 + k]
+        const double* pA = xs + 4 * (kq + blk) + ij;       // A[i][k] = x_i[t0 + k + 4g + blk]
         const int cfull = c & ~3;
-        const double* xp = xs + 4 * l4 + l15;
-        for (int i0 = 0; i0 < cfull; i0 += 4) {
-          const double bv = xp[0];
-          static_for<NT>([&](auto DD) __attribute__((always_inline)) {
-            if constexpr (TM::tab.wave[DD] == WAVE) {
-              constexpr int S = TM::slot(DD, 0);
-              acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(xp[16 * DD], bv, acc[S], 0, 0, 0);
-            }
+        // Groups past the last lag (4g >= Ln) just compute unused lags: no branches in the loop
+        // (reads stay inside the zero-padded trajectory region).
+        int t0 = 0;
+        for (; t0 + 16 <= cfull; t0 += 16) {               // 4 k-steps per trip: all loads first, then the MFMAs
+          double bv[4], av[MAXG][4];
+          static_for<4>([&](auto u) __attribute__((always_inline)) {
+            bv[u()] = pB[16 * u];
+            static_for<MAXG>([&](auto gi) __attribute__((always_inline)) { av[gi()][u()] = pA[16 * (WAVE + gi * W) + 16 * u]; });
           });
-          xp += 16;
+          static_for<4>([&](auto u) __attribute__((always_inline)) {
+            static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
+              cacc[gi()] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[gi()][u()], bv[u()], cacc[gi()], 0, 0, 0);
+            });
+          });
+          pA += 64; pB += 64;
+        }
+        for (; t0 < cfull; t0 += 4) {
+          const double bv = pB[0];
+          double av[MAXG];
+          static_for<MAXG>([&](auto gi) __attribute__((always_inline)) { av[gi()] = pA[16 * (WAVE + gi * W)]; });
+          static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
+            cacc[gi()] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[gi()], bv, cacc[gi()], 0, 0, 0);
+          });
+          pA += 16; pB += 16;
         }
         if (cfull < c) {
-          const bool kok = (cfull + l4) < c;
-          const double bv = kok ? xp[0] : 0.0;
+          const bool kok = (cfull + kq) < c;
+          const double bv = kok ? pB[0] : 0.0;
+          static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
+            const double a1 = pA[16 * (WAVE + gi * W)];
+            cacc[gi()] = __builtin_amdgcn_mfma_f64_4x4x4f64(kok ? a1 : 0.0, bv, cacc[gi()], 0, 0, 0);
+          });
+        }
+        static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
+          constexpr int g = WAVE + gi * W;
+          const int d = 4 * g + blk;                       // D layout: i = lane>>4, j = lane&3
+          if (g < ngroups && d < Ln) ctab[d * 16 + kq * 4 + ij] = cacc[gi()];
+        });
+      }
+      __syncthreads();
+      stamp();   // 2
+      // (2) first tile of every owned tile diagonal from the lag blocks:
+      //     G(l+d, l)(a,b) = C_d(a,b) + sum_{j<l} ( x_a[j+c+d] x_b[j+c] - x_a[j+d] x_b[j] ),  l = lo <= 3.
+      //     Lane (a = l4, b = l3, lo), register j of tile (d,0): k = 4d+j, l = lo, lag 4d+j-lo.
+      {
+        const double* qb0 = xs + l3;                       // x_b[.]      at  qb0[4*time]
+        const double* qb1 = qb0 + 4 * c;                   // x_b[. + c]
+#pragma nounroll
+        for (int d = 0; d < NT; ++d) {                     // runtime loop (an unrolled one gets hoisted into spills)
+          bool mine = false;
           static_for<NT>([&](auto DD) __attribute__((always_inline)) {
-            if constexpr (TM::tab.wave[DD] == WAVE) {
-              constexpr int S = TM::slot(DD, 0);
-              const double av = kok ? xp[16 * DD] : 0.0;
-              acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[S], 0, 0, 0);
-            }
+            if constexpr (TM::tab.wave[DD] == WAVE) mine = mine || (d == DD);
+          });
+          if (!mine) continue;
+          auto base = [&](int j) __attribute__((always_inline)) -> double {
+            int del = 4 * d + j - lo;
+            del = del < 0 ? 0 : del;                       // upper triangle of a diagonal tile: don't care
+            del = del >= Ln ? Ln - 1 : del;                // padded rows: cleared in the fix-up
+            const double* qa0 = xs + 4 * del + l4;         // x_a[del + .]
+            const double* qa1 = qa0 + 4 * c;
+            double t = ctab[del * 16 + l4 * 4 + l3];
+            // branch-free: all three window terms are computed (reads are in range), unused ones dropped
+            const double e0 = qa1[0] * qb1[0] - qa0[0] * qb0[0];
+            const double e1 = qa1[4] * qb1[4] - qa0[4] * qb0[4];
+            const double e2 = qa1[8] * qb1[8] - qa0[8] * qb0[8];
+            t += (0 < lo) ? e0 : 0.0;
+            t += (1 < lo) ? e1 : 0.0;
+            t += (2 < lo) ? e2 : 0.0;
+            return t;
+          };
+          const d4 v = d4{base(0), base(1), base(2), base(3)};
+          static_for<NT>([&](auto DD) __attribute__((always_inline)) {
+            if constexpr (TM::tab.wave[DD] == WAVE) { if (d == DD) acc[TM::slot(DD, 0)] = v; }
           });
         }
       }
-      stamp();   // 2
+      // (3) walk down the diagonals: 2 MFMAs per tile
       static_for<NT>([&](auto DD) __attribute__((always_inline)) {
         constexpr int d = DD;
         if constexpr (TM::tab.wave[d] == WAVE && d + 1 < NT) {
