@@ -1,0 +1,34 @@
+#!/bin/bash
+# Collect the per-round evidence on the GPU box (run through gpurun from the repo root):
+#   bash tools/collect_profiles.sh <tag>         e.g. r01_final
+# Writes everything under gpurun_out/<tag>/; copy the summaries into profiles/ afterwards.
+# Counter passes are separate runs with --pmc only (no trace domains), as the pool requires.
+set -e -o pipefail
+TAG=${1:-r01_final}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+
+timeout -k 10 300 python bench.py --steps 50 --warmup 5 > "$OUT/bench.log" 2>&1
+tail -1 "$OUT/bench.log" > "$OUT/bench.json"
+echo "[collect] bench done"
+
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- \
+    python bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/stats.log" 2>&1
+echo "[collect] kernel stats done"
+
+pass() {  # name, counters...
+    local name=$1; shift
+    timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- \
+        python bench.py --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/pmc_$name.log" 2>&1
+    echo "[collect] pmc $name done"
+}
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass sq SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES SQ_WAVE_CYCLES
+pass sq2 GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_F64 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+
+timeout -k 10 120 python tools/phase_stamps.py > "$OUT/phase_stamps.log" 2>&1
+timeout -k 10 300 python tools/bench_configs.py > "$OUT/other_configs.log" 2>&1
+echo "[collect] all done"

@@ -20,7 +20,7 @@ eng.solve(up, yp)
 eng.debug_stamps(True)
 eng.solve(up, yp)
 st = eng.debug_stamps(False, fetch=True).astype(np.int64)
-names = ["entry->tables", "base sums", "gram", "fixup+panel0", "cholesky", "backsolve", "-", "-"]
+names = ["staging+tables", "lag blocks (4x4x4)", "base tiles + walks", "cholesky", "(chol exit)", "back substitution", "-", "-"]
 dt = np.diff(st[:, :8], axis=1)
 tot = st[:, 14] - st[:, 0]
 real = (st[:, 13] - st[:, 15]) * 10.0   # ns
