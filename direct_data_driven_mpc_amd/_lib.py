@@ -20,13 +20,16 @@ STATUS_STRINGS = {0: "optimal", 1: "optimal_inaccurate", 2: "infeasible", 3: "un
 WEIGHT_SCALAR, WEIGHT_DIAG = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 GRAM_AUTO, GRAM_DENSE, GRAM_STRUCTURED = 0, 1, 2
+OPT_CLOSED_LOOP_PATH = 1
+PATH_AUTO, PATH_COLD, PATH_WARM = 0, 1, 2
 SOL_ALPHA, SOL_UBAR, SOL_YBAR, SOL_SIGMA = 0, 1, 2, 3
 
 EXPORTS = (
     "ddmpc_version", "ddmpc_last_error", "ddmpc_device_count", "ddmpc_create", "ddmpc_destroy",
     "ddmpc_set_stream", "ddmpc_synchronize", "ddmpc_set_data", "ddmpc_solve", "ddmpc_set_setpoints",
     "ddmpc_get_solution", "ddmpc_hankel", "ddmpc_cost_model", "ddmpc_kernel_name", "ddmpc_debug_stamps",
-    "ddmpc_closed_loop",
+    "ddmpc_closed_loop", "ddmpc_prepare", "ddmpc_step", "ddmpc_get_gain", "ddmpc_set_option",
+    "ddmpc_pe_guard",
 )
 
 c_double_p = C.POINTER(C.c_double)
@@ -91,6 +94,13 @@ def load() -> C.CDLL:
     lib.ddmpc_debug_stamps.restype = C.c_int
     lib.ddmpc_closed_loop.argtypes = [vp, C.POINTER(Plant), C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, C.c_int]
     lib.ddmpc_closed_loop.restype = C.c_int
+    lib.ddmpc_prepare.argtypes = [vp]
+    lib.ddmpc_step.argtypes = [vp, vp, vp, vp, vp, i32p, i32p, C.c_int]
+    lib.ddmpc_get_gain.argtypes = [vp, vp, C.c_int]
+    lib.ddmpc_set_option.argtypes = [vp, C.c_int, C.c_int]
+    lib.ddmpc_pe_guard.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int, C.c_int]
+    for name in ("ddmpc_prepare", "ddmpc_step", "ddmpc_get_gain", "ddmpc_set_option", "ddmpc_pe_guard"):
+        getattr(lib, name).restype = C.c_int
     for name in ("ddmpc_create", "ddmpc_destroy", "ddmpc_set_stream", "ddmpc_synchronize", "ddmpc_set_data",
                  "ddmpc_solve", "ddmpc_set_setpoints", "ddmpc_get_solution", "ddmpc_hankel", "ddmpc_cost_model"):
         getattr(lib, name).restype = C.c_int

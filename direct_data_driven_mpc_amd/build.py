@@ -45,10 +45,14 @@ def instances():
     return [(nt, w) for nt, w in inst if not (SKIP_LARGE and nt > LARGE_NT)]
 
 
-def _newest_src() -> float:
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    srcs.append(os.path.join(os.path.dirname(PKG_DIR), "include", "ddmpc.h"))
-    return max(os.path.getmtime(p) for p in srcs)
+# what each kind of translation unit is built from (mtime-based rebuild)
+INST_DEPS = ["ddmpc_inst.hip", "ddmpc_kernels.hpp"]
+API_DEPS = ["ddmpc_api.hip", "ddmpc_aux_kernels.hpp", "ddmpc_kernels.hpp", "ddmpc_instances.inc"]
+
+
+def _newest(names, extra=()) -> float:
+    paths = [os.path.join(CSRC, f) for f in names] + list(extra)
+    return max(os.path.getmtime(p) for p in paths)
 
 
 def _compile(cmd, out):
@@ -62,7 +66,8 @@ def build(force: bool = False, jobs: int = 0, verbose: bool = True) -> str:
     """Compile every HIP translation unit for gfx950 and link libddmpc.so."""
     hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
-    newest = _newest_src()
+    newest_inst = _newest(INST_DEPS)
+    newest_api = _newest(API_DEPS, [os.path.join(os.path.dirname(PKG_DIR), "include", "ddmpc.h")])
     tasks = []
     api_obj = os.path.join(OBJ_DIR, "ddmpc_api_nolarge.o" if SKIP_LARGE else "ddmpc_api.o")
     api_flags = ["-DDDMPC_NO_LARGE"] if SKIP_LARGE else []
@@ -71,7 +76,8 @@ def build(force: bool = False, jobs: int = 0, verbose: bool = True) -> str:
         obj = os.path.join(OBJ_DIR, "ddmpc_inst_%d_%d.o" % (nt, w))
         tasks.append(([hipcc] + COMMON_FLAGS + ["-DDDMPC_INST_NT=%d" % nt, "-DDDMPC_INST_W=%d" % w, "-c",
                                                  os.path.join(CSRC, "ddmpc_inst.hip"), "-o", obj], obj))
-    todo = [(c, o) for c, o in tasks if force or not os.path.exists(o) or os.path.getmtime(o) < newest]
+    todo = [(c, o) for c, o in tasks if force or not os.path.exists(o) or
+            os.path.getmtime(o) < (newest_inst if "ddmpc_inst_" in o else newest_api)]
     todo.sort(key=lambda t: -int(re.search(r"ddmpc_inst_(\d+)_", t[1]).group(1)) if "ddmpc_inst_" in t[1] else 0)  # longest first
     if todo:
         jobs = jobs or min(len(todo), max(1, (os.cpu_count() or 2) - 1), 8)

@@ -2,8 +2,7 @@
 // Host-side responsibilities: parameter validation with the reference's error
 // conditions (direct_data_driven_mpc_controller.py:165-168,211-222,298-343,664-670),
 // device buffer ownership, kernel-instance selection, launch.
-#define DDMPC_WITH_AUX_KERNELS 1
-#include "ddmpc_kernels.hpp"
+#include "ddmpc_aux_kernels.hpp"
 #include "../../include/ddmpc.h"
 
 #include <cstdarg>
@@ -21,7 +20,7 @@ namespace ddmpc {
 #define DDMPC_INSTANCE(NT, W)                                                                        \
   extern template __global__ void ddmpc_cold_solve_kernel<NT, W>(                                    \
       KParams, const double*, const double*, const double*, const double*, double*, double*, int*,  \
-      int*, double*, signed char*, unsigned long long*);
+      int*, double*, signed char*, unsigned long long*, double*);
 #include "ddmpc_instances.inc"
 #undef DDMPC_INSTANCE
 }  // namespace ddmpc
@@ -68,7 +67,7 @@ struct DevBuf {
 };
 
 typedef void (*cold_kernel_t)(KParams, const double*, const double*, const double*, const double*, double*,
-                              double*, int*, int*, double*, signed char*, unsigned long long*);
+                              double*, int*, int*, double*, signed char*, unsigned long long*, double*);
 
 struct KernelChoice {
   int NT, W;
@@ -117,6 +116,10 @@ struct ddmpc_handle {
   // staging for host-memory solves + workspace for get_solution
   DevBuf d_up, d_yp, d_uopt, d_cost, d_status, d_iters, d_beta, d_act, d_out, d_stamps;
   DevBuf d_pl, d_x, d_w, d_usys, d_ysys, d_stacc;
+  // warm path: per-instance affine law (ddmpc_prepare)
+  DevBuf d_lfac, d_lfacT, d_gain, d_prep_status, d_zero;
+  bool prepared = false;
+  int closed_loop_path = DDMPC_PATH_AUTO;
   bool stamps_on = false;
   const double* last_up = nullptr;
   const double* last_yp = nullptr;
@@ -334,7 +337,8 @@ int ddmpc_destroy(ddmpc_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
-                    &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc};
+                    &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero};
   for (DevBuf* b : bufs) b->release();
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -380,24 +384,50 @@ int ddmpc_set_data(ddmpc_handle* h, const double* u_d, const double* y_d, int me
   }
   h->have_data = true;
   h->solved = false;
+  h->prepared = false;
   return DDMPC_OK;
 }
 
 static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
-                       int32_t* status, int32_t* iters) {
+                       int32_t* status, int32_t* iters, double* lfac = nullptr) {
   int rc;
   if ((rc = h->d_beta.ensure((size_t)h->batch * h->kp.rE * sizeof(double)))) return rc;
   if ((rc = h->d_act.ensure((size_t)h->batch * h->kp.rE))) return rc;
   dim3 grid((unsigned)h->batch), block(64 * h->kc.W);
   hipLaunchKernelGGL(h->kc.fn, grid, block, h->lds_bytes, h->stream, h->kp, h->ud, h->yd, up, yp, uo, cost,
                      (int*)status, (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p,
-                     h->stamps_on ? (unsigned long long*)h->d_stamps.p : (unsigned long long*)nullptr);
+                     h->stamps_on ? (unsigned long long*)h->d_stamps.p : (unsigned long long*)nullptr, lfac);
   HIP_TRY(hipGetLastError());
   return DDMPC_OK;
 }
 
-int ddmpc_solve(ddmpc_handle* h, const double* u_past, const double* y_past, double* u_opt, double* cost,
-                int32_t* status, int32_t* iters, int mem) {
+static bool warm_capable(const ddmpc_handle* h) {
+  // the affine law exists when the QP has no inequality: nominal, or robust with slack NONE
+  return !h->kp.convex;
+}
+
+static int launch_warm(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
+                       int32_t* status, int32_t* iters) {
+  int rc;
+  if ((rc = h->d_beta.ensure((size_t)h->batch * h->kp.rE * sizeof(double)))) return rc;
+  if ((rc = h->d_act.ensure((size_t)h->batch * h->kp.rE))) return rc;
+  const int nf = h->prm.n * h->kp.nch;
+  const unsigned threads = (unsigned)(((h->kp.r + 63) / 64) * 64 > 1024 ? 1024 : ((h->kp.r + 63) / 64) * 64);
+  hipLaunchKernelGGL(ddmpc_warm_step_kernel, dim3((unsigned)h->batch), dim3(threads), 0, h->stream, h->kp,
+                     16 * h->kc.NT, nf, (const double*)h->d_gain.p, (const int*)h->d_prep_status.p, up, yp, uo, cost,
+                     (int*)status, (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p);
+  HIP_TRY(hipGetLastError());
+  return DDMPC_OK;
+}
+
+typedef int (*launch_fn)(ddmpc_handle*, const double*, const double*, double*, double*, int32_t*, int32_t*);
+static int launch_cold_plain(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
+                             int32_t* status, int32_t* iters) {
+  return launch_cold(h, up, yp, uo, cost, status, iters, nullptr);
+}
+
+static int solve_impl(ddmpc_handle* h, const double* u_past, const double* y_past, double* u_opt, double* cost,
+                      int32_t* status, int32_t* iters, int mem, launch_fn launch) {
   if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
   if (!h->have_data) return fail(DDMPC_ERR_NOT_READY, "ddmpc_set_data must be called before ddmpc_solve");
   if (!u_past || !y_past || !u_opt || !cost || !status) return fail(DDMPC_ERR_INVALID, "null argument");
@@ -409,7 +439,7 @@ int ddmpc_solve(ddmpc_handle* h, const double* u_past, const double* y_past, dou
   const size_t n_uo = (size_t)h->batch * p.L * p.m * sizeof(double);
   int rc;
   if (mem == DDMPC_MEM_DEVICE) {
-    if ((rc = launch_cold(h, u_past, y_past, u_opt, cost, status, iters))) return rc;
+    if ((rc = launch(h, u_past, y_past, u_opt, cost, status, iters))) return rc;
     h->last_up = u_past;
     h->last_yp = y_past;
     h->solved = true;
@@ -424,8 +454,8 @@ int ddmpc_solve(ddmpc_handle* h, const double* u_past, const double* y_past, dou
   if ((rc = h->d_iters.ensure((size_t)h->batch * sizeof(int32_t)))) return rc;
   HIP_TRY(hipMemcpyAsync(h->d_up.p, u_past, n_up, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_yp.p, y_past, n_yp, hipMemcpyHostToDevice, h->stream));
-  if ((rc = launch_cold(h, (const double*)h->d_up.p, (const double*)h->d_yp.p, (double*)h->d_uopt.p,
-                        (double*)h->d_cost.p, (int32_t*)h->d_status.p, (int32_t*)h->d_iters.p)))
+  if ((rc = launch(h, (const double*)h->d_up.p, (const double*)h->d_yp.p, (double*)h->d_uopt.p,
+                   (double*)h->d_cost.p, (int32_t*)h->d_status.p, (int32_t*)h->d_iters.p)))
     return rc;
   HIP_TRY(hipMemcpyAsync(u_opt, h->d_uopt.p, n_uo, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(cost, h->d_cost.p, (size_t)h->batch * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -439,6 +469,92 @@ int ddmpc_solve(ddmpc_handle* h, const double* u_past, const double* y_past, dou
   return DDMPC_OK;
 }
 
+int ddmpc_solve(ddmpc_handle* h, const double* u_past, const double* y_past, double* u_opt, double* cost,
+                int32_t* status, int32_t* iters, int mem) {
+  return solve_impl(h, u_past, y_past, u_opt, cost, status, iters, mem, &launch_cold_plain);
+}
+
+int ddmpc_prepare(ddmpc_handle* h) {
+  if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
+  if (!h->have_data) return fail(DDMPC_ERR_NOT_READY, "ddmpc_set_data must be called before ddmpc_prepare");
+  if (h->batch > 0x7fffffffLL) return fail(DDMPC_ERR_INVALID, "batch too large for one launch");
+  if (h->prepared) return DDMPC_OK;
+  if (!warm_capable(h)) return DDMPC_OK;          // slack CONVEX: every step is a cold solve
+  HIP_TRY(hipSetDevice(h->device));
+  const ddmpc_params& p = h->prm;
+  const KParams& k = h->kp;
+  const int nf = p.n * k.nch, nrhs = nf + 1, NT = h->kc.NT;
+  if (nf > WARM_MAX_NF) return fail(DDMPC_ERR_UNSUPPORTED, "warm path supports n*(m+p) <= %d", WARM_MAX_NF);
+  const size_t B = (size_t)h->batch;
+  const size_t lf_bytes = B * (size_t)(NT * (NT + 1) / 2) * 256 * sizeof(double);
+  int rc;
+  if ((rc = h->d_lfac.ensure(lf_bytes)) || (rc = h->d_lfacT.ensure(lf_bytes)) || (rc = h->d_gain.ensure(B * nrhs * k.r * sizeof(double))) ||
+      (rc = h->d_prep_status.ensure(B * sizeof(int32_t))) || (rc = h->d_zero.ensure(B * nf * sizeof(double))) ||
+      (rc = h->d_uopt.ensure(B * p.L * p.m * sizeof(double))) || (rc = h->d_cost.ensure(B * sizeof(double))))
+    return rc;
+  HIP_TRY(hipMemsetAsync(h->d_zero.p, 0, B * nf * sizeof(double), h->stream));
+  const double* z = (const double*)h->d_zero.p;
+  // one cold factorisation with the factor exported (its solution for a zero past window is discarded)
+  if ((rc = launch_cold(h, z, z + B * p.n * p.m, (double*)h->d_uopt.p, (double*)h->d_cost.p,
+                        (int32_t*)h->d_prep_status.p, nullptr, (double*)h->d_lfac.p)))
+    return rc;
+  const unsigned ch = nrhs <= 32 ? 32u : 64u;
+  const size_t lds = (size_t)k.r * ch * sizeof(double);
+  if (lds > 160 * 1024) return fail(DDMPC_ERR_UNSUPPORTED, "warm path: r = %d too large for the gain kernel", k.r);
+  HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_gain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t ntiles = B * (size_t)(NT * (NT + 1) / 2);
+  if (ntiles > 0x7fffffffULL) return fail(DDMPC_ERR_INVALID, "batch too large for ddmpc_prepare");
+  hipLaunchKernelGGL(ddmpc_transpose_tiles_kernel, dim3((unsigned)ntiles), dim3(256), 0, h->stream,
+                     (const double*)h->d_lfac.p, (double*)h->d_lfacT.p);
+  hipLaunchKernelGGL(ddmpc_gain_kernel, dim3((unsigned)B), dim3(ch), lds, h->stream, k, 16 * NT, NT, nf,
+                     (const double*)h->d_lfac.p, (const double*)h->d_lfacT.p, (double*)h->d_gain.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->d_lfac.release();                           // the factor is only needed to form the gain
+  h->d_lfacT.release();
+  h->prepared = true;
+  h->solved = false;
+  return DDMPC_OK;
+}
+
+int ddmpc_step(ddmpc_handle* h, const double* u_past, const double* y_past, double* u_opt, double* cost,
+               int32_t* status, int32_t* iters, int mem) {
+  if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
+  if (!h->have_data) return fail(DDMPC_ERR_NOT_READY, "ddmpc_set_data must be called before ddmpc_step");
+  if (!warm_capable(h)) return solve_impl(h, u_past, y_past, u_opt, cost, status, iters, mem, &launch_cold_plain);
+  if (!h->prepared) {
+    int rc = ddmpc_prepare(h);
+    if (rc) return rc;
+  }
+  return solve_impl(h, u_past, y_past, u_opt, cost, status, iters, mem, &launch_warm);
+}
+
+int ddmpc_get_gain(ddmpc_handle* h, double* out, int mem) {
+  if (!h || !out) return fail(DDMPC_ERR_INVALID, "null argument");
+  if (!warm_capable(h)) return fail(DDMPC_ERR_UNSUPPORTED, "no affine control law with the CONVEX slack box");
+  if (!h->prepared) return fail(DDMPC_ERR_NOT_READY, "ddmpc_prepare must be called before ddmpc_get_gain");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t bytes = (size_t)h->batch * (h->prm.n * h->kp.nch + 1) * h->kp.r * sizeof(double);
+  HIP_TRY(hipMemcpyAsync(out, h->d_gain.p, bytes, mem == DDMPC_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                         h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return DDMPC_OK;
+}
+
+int ddmpc_set_option(ddmpc_handle* h, int option, int value) {
+  if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
+  switch (option) {
+    case DDMPC_OPT_CLOSED_LOOP_PATH:
+      if (value != DDMPC_PATH_AUTO && value != DDMPC_PATH_COLD && value != DDMPC_PATH_WARM)
+        return fail(DDMPC_ERR_INVALID, "closed-loop path must be DDMPC_PATH_AUTO, _COLD or _WARM");
+      if (value == DDMPC_PATH_WARM && !warm_capable(h))
+        return fail(DDMPC_ERR_UNSUPPORTED, "no warm path with the CONVEX slack box");
+      h->closed_loop_path = value;
+      return DDMPC_OK;
+    default: return fail(DDMPC_ERR_INVALID, "unknown option %d", option);
+  }
+}
+
 int ddmpc_set_setpoints(ddmpc_handle* h, const double* u_s, const double* y_s) {
   if (!h || !u_s || !y_s) return fail(DDMPC_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(h->device));
@@ -447,6 +563,7 @@ int ddmpc_set_setpoints(ddmpc_handle* h, const double* u_s, const double* y_s) {
   h->prm.u_s = h->us_h.data();
   h->prm.y_s = h->ys_h.data();
   h->solved = false;
+  h->prepared = false;
   HIP_TRY(hipStreamSynchronize(h->stream));
   return upload_params(h);
 }
@@ -515,6 +632,45 @@ int ddmpc_hankel(const double* X, int64_t batch, int32_t N, int32_t nch, int32_t
   return DDMPC_OK;
 }
 
+int ddmpc_pe_guard(const double* u_d, int64_t batch, int32_t N, int32_t m, int32_t order, double* ratio_lb,
+                   int mem, int device) {
+  if (!u_d || !ratio_lb) return fail(DDMPC_ERR_INVALID, "null argument");
+  if (batch <= 0 || N <= 0 || m <= 0 || order <= 0) return fail(DDMPC_ERR_INVALID, "sizes must be positive");
+  if (N < order) return fail(DDMPC_ERR_INVALID, "N must be greater than or equal to L.");   // hankel_matrix.py:43-44
+  if (batch > 0x7fffffffLL) return fail(DDMPC_ERR_INVALID, "batch too large for one launch");
+  if (mem != DDMPC_MEM_HOST && mem != DDMPC_MEM_DEVICE)
+    return fail(DDMPC_ERR_INVALID, "mem must be DDMPC_MEM_HOST or DDMPC_MEM_DEVICE");
+  if (ddmpc_device_count() <= 0) return fail(DDMPC_ERR_NO_DEVICE, "no HIP device visible (the engine has no CPU fallback)");
+  const long long r = (long long)m * order;
+  const size_t lds = (size_t)(r * (r + 1) / 2 + r + 64) * sizeof(double);
+  if (lds > 160 * 1024 - 64)
+    return fail(DDMPC_ERR_UNSUPPORTED, "pe guard: m*order = %lld rows do not fit one workgroup's LDS", r);
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_pe_guard_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (mem == DDMPC_MEM_DEVICE) {
+    hipLaunchKernelGGL(ddmpc_pe_guard_kernel, dim3((unsigned)batch), dim3(256), lds, 0, u_d, N, m, order, ratio_lb);
+    HIP_TRY(hipGetLastError());
+    return DDMPC_OK;
+  }
+  const size_t nx = (size_t)batch * N * m * sizeof(double);
+  double *dX = nullptr, *dR = nullptr;
+  HIP_TRY(hipMalloc((void**)&dX, nx));
+  if (hipMalloc((void**)&dR, (size_t)batch * sizeof(double)) != hipSuccess) {
+    (void)hipFree(dX);
+    return fail(DDMPC_ERR_HIP, "hipMalloc failed");
+  }
+  hipError_t e = hipMemcpy(dX, u_d, nx, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(ddmpc_pe_guard_kernel, dim3((unsigned)batch), dim3(256), lds, 0, dX, N, m, order, dR);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(ratio_lb, dR, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(dX);
+  (void)hipFree(dR);
+  if (e != hipSuccess) return fail(DDMPC_ERR_HIP, "ddmpc_pe_guard: %s", hipGetErrorString(e));
+  return DDMPC_OK;
+}
+
 int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps, int32_t n_mpc_step, double* x,
                       double* u_past, double* y_past, const double* w, double* u_sys, double* y_sys,
                       int32_t* status, int mem) {
@@ -560,8 +716,21 @@ int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps
     dx = (double*)h->d_x.p; dup = (double*)h->d_up.p; dyp = (double*)h->d_yp.p; dw = (const double*)h->d_w.p;
     dus = (double*)h->d_usys.p; dys = (double*)h->d_ysys.p;
   }
+  const bool warm = warm_capable(h) && h->closed_loop_path != DDMPC_PATH_COLD &&
+                    (size_t)n_mpc_step * m <= (size_t)WARM_MAX_NF && n * h->kp.nch <= WARM_MAX_NF;
+  if (warm) {
+    // affine control law: the whole loop of an instance runs inside one workgroup
+    if ((rc = ddmpc_prepare(h))) return rc;
+    if ((rc = h->d_beta.ensure(B * h->kp.rE * sizeof(double))) || (rc = h->d_act.ensure(B * h->kp.rE))) return rc;
+    const unsigned threads = (unsigned)(((h->kp.r + 63) / 64) * 64 > 1024 ? 1024 : ((h->kp.r + 63) / 64) * 64);
+    hipLaunchKernelGGL(ddmpc_closed_loop_warm_kernel, dim3((unsigned)B), dim3(threads), 0, h->stream, h->kp,
+                       16 * h->kc.NT, n * h->kp.nch, (const double*)h->d_gain.p, (const int*)h->d_prep_status.p, ns,
+                       (const double*)h->d_pl.p, n_steps, n_mpc_step, dx, dup, dyp, dw, dus, dys, (int*)h->d_stacc.p,
+                       (double*)h->d_beta.p, (signed char*)h->d_act.p);
+    HIP_TRY(hipGetLastError());
+  }
   const unsigned pblocks = (unsigned)((B + 127) / 128);
-  for (int t = 0; t < n_steps; t += n_mpc_step) {
+  for (int t = 0; !warm && t < n_steps; t += n_mpc_step) {
     if ((rc = launch_cold(h, dup, dyp, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int32_t*)h->d_status.p, nullptr)))
       return rc;
     const int nsub = (t + n_mpc_step <= n_steps) ? n_mpc_step : n_steps - t;

@@ -1,0 +1,483 @@
+// ddmpc_aux_kernels.hpp -- the small, non-template gfx950 kernels around the cold-solve kernel:
+// Hankel gather, variable reconstruction, plant/FIFO step, the warm path (gain, warm step, fused
+// closed loop) and the persistent-excitation guard.  Included by the API translation unit only, so
+// editing it does not rebuild the (slow to compile) cold-solve instantiations.
+#pragma once
+#include "ddmpc_kernels.hpp"
+
+namespace ddmpc {
+
+// --------------------------------------------------------------------------
+// hankel_matrix for a batch: H[b][k*nch+ch][i] = X[b][i+k][ch]
+// (direct_data_driven_mpc/utilities/hankel_matrix.py:47-51)
+// --------------------------------------------------------------------------
+__global__ void ddmpc_hankel_kernel(const double* __restrict__ X, double* __restrict__ H, int N, int nch,
+                                    int L, long long batch) {
+  const int cols = N - L + 1;
+  const long long per = (long long)L * nch * cols;
+  const long long total = per * batch;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+       g += (long long)gridDim.x * blockDim.x) {
+    const long long b = g / per;
+    const long long e = g - b * per;
+    const int row = (int)(e / cols), i = (int)(e - (long long)row * cols);
+    const int k = row / nch, ch = row - k * nch;
+    H[g] = X[b * (long long)N * nch + (long long)(i + k) * nch + ch];
+  }
+}
+
+// --------------------------------------------------------------------------
+// Variable reconstruction for ddmpc_get_solution (the `.value` stand-ins of
+// controller.py:434-445) from the beta / active-set workspace of the last solve.
+// what: 0 alpha, 1 ubar, 2 ybar, 3 sigma.  One workgroup per instance.
+// `RPs` is the row stride of the component tables.
+// --------------------------------------------------------------------------
+__global__ void ddmpc_reconstruct_kernel(KParams P, int RPs, int what, const double* __restrict__ u_d,
+                                         const double* __restrict__ y_d, const double* __restrict__ u_past,
+                                         const double* __restrict__ y_past, const double* __restrict__ beta_ws,
+                                         const signed char* __restrict__ act_ws, double* __restrict__ out) {
+  const long long b = blockIdx.x;
+  const int n = P.npu / P.m;
+  const double* bw = beta_ws + b * (long long)P.rE;
+  const signed char* aw = act_ws + b * (long long)P.rE;
+  const double* up = u_past + b * (long long)P.npu;
+  const double* yp = y_past + b * (long long)(n * P.p);
+  if (what == 0) {                       // alpha = H' beta
+    const double* ud = u_d + b * (long long)P.N * P.m;
+    const double* yd = y_d + b * (long long)P.N * P.p;
+    double* o = out + b * (long long)P.c;
+    for (int i = threadIdx.x; i < P.c; i += blockDim.x) {
+      double s = 0.0;
+      for (int k = 0; k < P.Ln; ++k) {
+        for (int ch = 0; ch < P.m; ++ch) s += ud[(i + k) * P.m + ch] * bw[k * P.nch + ch];
+        for (int ch = 0; ch < P.p; ++ch) s += yd[(i + k) * P.p + ch] * bw[k * P.nch + P.m + ch];
+      }
+      o[i] = s;
+    }
+    return;
+  }
+  for (int rho = threadIdx.x; rho < P.r; rho += blockDim.x) {
+    const int k = rho / P.nch, ch = rho - k * P.nch;
+    const int s_act = aw[rho];
+    const int kind = P.tabi[0 * RPs + rho];
+    const int pidx = P.tabi[1 * RPs + rho];
+    const double tb = P.tabd[2 * RPs + rho];
+    const double D = s_act ? P.tabd[1 * RPs + rho] : P.tabd[0 * RPs + rho];
+    const double tpast = (pidx >= 0) ? ((pidx < P.npu) ? up[pidx] : yp[pidx - P.npu]) : tb;
+    const double t = tpast + s_act * P.bound;
+    const double bb = bw[rho];
+    const double z = t - P.lam * D * bb;
+    if (ch < P.m) {
+      if (what == 1) out[b * (long long)(P.Ln * P.m) + k * P.m + ch] = z;
+      continue;
+    }
+    const int cy = ch - P.m;
+    double sg = 0.0;
+    if (kind == K_WINT) sg = z - tpast;
+    else if (kind == K_WTERM) sg = z - tb;
+    else if (kind == K_WPRED) sg = (s_act != 0) ? s_act * P.bound : -P.lam * bb / P.lamb_sigma;
+    if (what == 2) out[b * (long long)(P.Ln * P.p) + k * P.p + cy] = z - sg;
+    if (what == 3) out[b * (long long)(P.Ln * P.p) + k * P.p + cy] = sg;
+  }
+}
+// --------------------------------------------------------------------------
+// Closed-loop glue: apply up to `nsub` inputs of the last solve to the plant, record the
+// trajectories, push (u,y) into the past windows.  One thread per instance (tiny matvecs).
+//   pl: [A (ns*ns) | B (ns*m) | C (p*ns) | D (p*m)] row-major.
+// utilities/controller/controller_operation.py:278-305, utilities/model_simulation.py:93-98,
+// direct_data_driven_mpc_controller.py:893-895.
+// --------------------------------------------------------------------------
+__global__ void ddmpc_plant_kernel(long long batch, int ns, int m, int p, int n, int Lm, const double* __restrict__ pl,
+                                   int t0, int nsub, int n_steps, const double* __restrict__ u_opt,
+                                   const int* __restrict__ st_step, int* __restrict__ st_acc,
+                                   double* __restrict__ x, double* __restrict__ u_past, double* __restrict__ y_past,
+                                   const double* __restrict__ w, double* __restrict__ u_sys, double* __restrict__ y_sys) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const double* A = pl;
+  const double* Bm = A + ns * ns;
+  const double* C = Bm + ns * m;
+  const double* D = C + p * ns;
+  int acc = st_acc[b];
+  if (st_step[b] > acc) acc = st_step[b];
+  st_acc[b] = acc;
+  double* xb = x + b * ns;
+  double* up = u_past + b * (long long)(n * m);
+  double* yp = y_past + b * (long long)(n * p);
+  const double* uo = u_opt + b * (long long)Lm;
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+  for (int j = 0; j < nsub; ++j) {
+    const int k = t0 + j;
+    double* us = u_sys + (b * n_steps + k) * m;
+    double* ys = y_sys + (b * n_steps + k) * p;
+    if (acc > 1) {                               // not optimal / optimal_inaccurate: the reference raises here
+      for (int i = 0; i < m; ++i) us[i] = nanv;
+      for (int i = 0; i < p; ++i) ys[i] = nanv;
+      continue;
+    }
+    const double* uk = uo + j * m;
+    const double* wk = w + (b * n_steps + k) * p;
+    for (int i = 0; i < p; ++i) {                // y = C x + D u + w, with the state BEFORE the update
+      double s = wk[i];
+      for (int q = 0; q < ns; ++q) s += C[i * ns + q] * xb[q];
+      for (int q = 0; q < m; ++q) s += D[i * m + q] * uk[q];
+      ys[i] = s;
+    }
+    double xn[16];
+    for (int i = 0; i < ns; ++i) {
+      double s = 0.0;
+      for (int q = 0; q < ns; ++q) s += A[i * ns + q] * xb[q];
+      for (int q = 0; q < m; ++q) s += Bm[i * m + q] * uk[q];
+      xn[i] = s;
+    }
+    for (int i = 0; i < ns; ++i) xb[i] = xn[i];
+    for (int i = 0; i < m; ++i) us[i] = uk[i];
+    for (int i = 0; i < (n - 1) * m; ++i) up[i] = up[i + m];       // FIFO shift
+    for (int i = 0; i < m; ++i) up[(n - 1) * m + i] = uk[i];
+    for (int i = 0; i < (n - 1) * p; ++i) yp[i] = yp[i + p];
+    for (int i = 0; i < p; ++i) yp[(n - 1) * p + i] = ys[i];
+  }
+}
+// --------------------------------------------------------------------------
+// Warm path (ddmpc_prepare / ddmpc_step), slack NONE and nominal controllers.
+// Without inequality constraints the QP is equality-constrained, so beta is an affine
+// function of the past window:  beta = A^-1 t,  t = t0 + sum_f past[f] e_{rho(f)}  with the
+// step-invariant A = G + lam*D0 (controller.py:404-407 re-solves with only u_past/y_past
+// changed, :577-581).  ddmpc_gain_kernel solves the nf+1 right-hand sides
+// [t0 | e_rho(0) .. e_rho(nf-1)] once per instance against the exported Cholesky factor;
+// a warm step is then one [r x (nf+1)] matrix-vector product and the usual output stage.
+//
+// gain layout: gain[b][j][rho], j = 0 (offset) .. nf, rho < r (stride r): lanes = rho coalesce.
+// One wave per instance, lane = right-hand side, the column being solved lives in LDS
+// (Y[i*CH + lane]); L entries are wave-uniform (scalar loads).  Setup-time only.
+// --------------------------------------------------------------------------
+__device__ __forceinline__ const double* lfac_row(const double* __restrict__ Lb, int i, int J) {
+  const int I = i >> 4;
+  return Lb + ((I * (I + 1) / 2 + J) << 8) + ((i & 15) << 4);
+}
+
+// Tile-wise transpose of the exported factor (lfacT tile (I,J) = L(I,J)'), so that the back
+// substitution below also reads contiguous rows.  One workgroup (256 threads) per tile.
+__global__ void ddmpc_transpose_tiles_kernel(const double* __restrict__ in, double* __restrict__ out) {
+  __shared__ double t[16][17];
+  const long long base = (long long)blockIdx.x * 256;
+  const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+  t[r][c] = in[base + threadIdx.x];
+  __syncthreads();
+  out[base + threadIdx.x] = t[c][r];
+}
+
+__global__ void ddmpc_gain_kernel(KParams P, int RPs, int NT, int nf, const double* __restrict__ lfac,
+                                  const double* __restrict__ lfacT, double* __restrict__ gain) {
+  extern __shared__ __attribute__((aligned(16))) double Y[];
+  const long long b = blockIdx.x;
+  const int CH = blockDim.x, tid = threadIdx.x, r = P.r, nrhs = nf + 1;
+  const double* __restrict__ Lb = lfac + b * (long long)(NT * (NT + 1) / 2 * 256);
+  const double* __restrict__ Tb = lfacT + b * (long long)(NT * (NT + 1) / 2 * 256);
+  const int ntr = (r + 15) >> 4;            // tile rows that hold real rows
+  for (int j0 = 0; j0 < nrhs; j0 += CH) {
+    const int n = j0 + tid;
+    for (int i = 0; i < r; ++i) {
+      const int pidx = P.tabi[1 * RPs + i];
+      const double tb = P.tabd[2 * RPs + i];
+      Y[i * CH + tid] = (n == 0) ? (pidx >= 0 ? 0.0 : tb) : ((pidx == n - 1) ? 1.0 : 0.0);
+    }
+    // forward substitution L y = t: y_i = (t_i - sum_{k<i} L[i][k] y_k) / L[i][i]
+    for (int i = 0; i < r; ++i) {
+      double s0 = Y[i * CH + tid], s1 = 0.0;
+      const int I = i >> 4;
+      for (int J = 0; J < I; ++J) {
+        const double* __restrict__ Lr = lfac_row(Lb, i, J);
+        const double* yk = Y + (16 * J) * CH + tid;
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) { s0 -= Lr[kk] * yk[kk * CH]; s1 -= Lr[kk + 1] * yk[(kk + 1) * CH]; }
+      }
+      const double* __restrict__ Lr = lfac_row(Lb, i, I);
+      const double* yk = Y + (16 * I) * CH + tid;
+      for (int kk = 0; kk < (i & 15); ++kk) s0 -= Lr[kk] * yk[kk * CH];
+      Y[i * CH + tid] = (s0 + s1) / Lr[i & 15];
+    }
+    // back substitution L' beta = y: beta_i = (y_i - sum_{k>i} L[k][i] beta_k) / L[i][i],
+    // L[16I+kk][i] = lfacT tile (I, i>>4), row i&15, entry kk
+    for (int i = r - 1; i >= 0; --i) {
+      double s0 = Y[i * CH + tid], s1 = 0.0;
+      const int Ji = i >> 4;
+      for (int I = ntr - 1; I > Ji; --I) {
+        const double* __restrict__ Tr = Tb + ((I * (I + 1) / 2 + Ji) << 8) + ((i & 15) << 4);
+        const double* yk = Y + (16 * I) * CH + tid;
+        const int lim = (r - 16 * I) < 16 ? (r - 16 * I) : 16;      // rows >= r are padding / the rhs row
+        if (lim == 16) {
+#pragma unroll
+          for (int kk = 0; kk < 16; kk += 2) { s0 -= Tr[kk] * yk[kk * CH]; s1 -= Tr[kk + 1] * yk[(kk + 1) * CH]; }
+        } else {
+          for (int kk = 0; kk < lim; ++kk) s0 -= Tr[kk] * yk[kk * CH];
+        }
+      }
+      const double* __restrict__ Tr = Tb + ((Ji * (Ji + 1) / 2 + Ji) << 8) + ((i & 15) << 4);
+      const double* yk = Y + (16 * Ji) * CH + tid;
+      const int lim = (r - 16 * Ji) < 16 ? (r - 16 * Ji) : 16;
+      for (int kk = (i & 15) + 1; kk < lim; ++kk) s0 -= Tr[kk] * yk[kk * CH];
+      Y[i * CH + tid] = (s0 + s1) / Tr[i & 15];
+    }
+    if (n < nrhs) {
+      double* g = gain + (b * nrhs + n) * (long long)r;
+      for (int i = 0; i < r; ++i) g[i] = Y[i * CH + tid];
+    }
+  }
+}
+
+// Output stage shared by the warm kernels: z, cost contribution and optimal_u of one component
+// (same formulas as the cold kernel's output stage, active set empty).
+__device__ __forceinline__ double warm_component(const KParams& P, int RPs, int rho, double beta, const double* pv,
+                                                 double* z_out) {
+  const int kind = P.tabi[0 * RPs + rho];
+  const int pidx = P.tabi[1 * RPs + rho];
+  const double D = P.tabd[0 * RPs + rho];
+  const double tb = P.tabd[2 * RPs + rho];
+  const double wq = P.tabd[3 * RPs + rho];
+  const double t = (pidx >= 0) ? pv[pidx] : tb;
+  const double z = t - P.lam * D * beta;
+  double contrib = P.lam * beta * z;
+  if (kind == K_UFREE || kind == K_YFREE) { const double dlt = z - tb; contrib += wq * dlt * dlt; }
+  else if (kind == K_WINT) { const double sg = z - t; contrib += P.lamb_sigma * sg * sg; }
+  else if (kind == K_WTERM) { const double sg = z - tb; contrib += P.lamb_sigma * sg * sg; }
+  else if (kind == K_WPRED) {
+    const double sg = -P.lam * beta / P.lamb_sigma;
+    const double dlt = z - sg - tb;
+    contrib += wq * dlt * dlt + P.lamb_sigma * sg * sg;
+  }
+  *z_out = z;
+  return contrib;
+}
+
+constexpr int WARM_MAX_NF = 256;
+
+// One warm step for the batch: grid = batch, block = r rounded up to 64.
+// Replaces update_and_solve_data_driven_mpc (controller.py:389-407) once the data are fixed.
+__global__ void ddmpc_warm_step_kernel(KParams P, int RPs, int nf, const double* __restrict__ gain,
+                                       const int* __restrict__ prep_status, const double* __restrict__ u_past,
+                                       const double* __restrict__ y_past, double* __restrict__ u_opt,
+                                       double* __restrict__ cost, int* __restrict__ status, int* __restrict__ iters,
+                                       double* __restrict__ beta_ws, signed char* __restrict__ act_ws) {
+  __shared__ double pv[WARM_MAX_NF];
+  __shared__ double red[32];
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x, r = P.r, nrhs = nf + 1;
+  const int nyp = nf - P.npu;
+  for (int f = tid; f < nf; f += blockDim.x)
+    pv[f] = (f < P.npu) ? u_past[b * P.npu + f] : y_past[b * nyp + (f - P.npu)];
+  __syncthreads();
+  double part = 0.0;
+  bool finite = true;
+  const double* g = gain + b * (long long)nrhs * r;
+  for (int rho = tid; rho < r; rho += blockDim.x) {
+    double beta = g[rho];
+    for (int f = 0; f < nf; ++f) beta += pv[f] * g[(long long)(1 + f) * r + rho];
+    double z;
+    part += warm_component(P, RPs, rho, beta, pv, &z);
+    finite = finite && (fabs(beta) < 1e300);
+    const int oidx = P.tabi[2 * RPs + rho];
+    if (oidx >= 0) u_opt[b * (long long)((P.Ln - P.npu / P.m) * P.m) + oidx] = z;
+    if (beta_ws) beta_ws[b * (long long)P.rE + rho] = beta;
+    if (act_ws) act_ws[b * (long long)P.rE + rho] = 0;
+  }
+  part = wave_sum(part);
+  const unsigned long long okmask = __ballot(finite);
+  if ((tid & 63) == 0) { red[tid >> 6] = part; red[16 + (tid >> 6)] = (okmask == ~0ull) ? 0.0 : 1.0; }
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0, bad = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { tot += red[w]; bad += red[16 + w]; }
+    int st = prep_status[b];
+    if (bad != 0.0 || !(fabs(tot) < 1e300)) st = 4;
+    cost[b] = tot;
+    status[b] = st;
+    if (iters) iters[b] = 1;
+  }
+}
+
+// Whole closed loop of one instance in one workgroup (warm path): per solve the affine law gives
+// optimal_u, then the plant/FIFO steps of ddmpc_plant_kernel.  Same loop order as
+// utilities/controller/controller_operation.py:263-305.
+__global__ void ddmpc_closed_loop_warm_kernel(KParams P, int RPs, int nf, const double* __restrict__ gain,
+                                              const int* __restrict__ prep_status, int ns, const double* __restrict__ pl,
+                                              int n_steps, int n_mpc_step, double* __restrict__ x,
+                                              double* __restrict__ u_past, double* __restrict__ y_past,
+                                              const double* __restrict__ w, double* __restrict__ u_sys,
+                                              double* __restrict__ y_sys, int* __restrict__ status_out,
+                                              double* __restrict__ beta_ws, signed char* __restrict__ act_ws) {
+  __shared__ double pv[WARM_MAX_NF];
+  __shared__ double uo[WARM_MAX_NF];      // the first n_mpc_step*m entries of optimal_u
+  __shared__ double xs[16];
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x, r = P.r, nrhs = nf + 1, m = P.m, p = P.p;
+  const int n = P.npu / m, nyp = nf - P.npu;
+  const double* A = pl;
+  const double* Bm = A + ns * ns;
+  const double* C = Bm + ns * m;
+  const double* Dm = C + p * ns;
+  for (int f = tid; f < nf; f += blockDim.x)
+    pv[f] = (f < P.npu) ? u_past[b * P.npu + f] : y_past[b * nyp + (f - P.npu)];
+  if (tid < ns) xs[tid] = x[b * ns + tid];
+  const int st = prep_status[b];
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+  const double* g = gain + b * (long long)nrhs * r;
+  const int nuse = n_mpc_step * m;
+  double* up = pv;
+  double* yp = pv + P.npu;
+  for (int t0 = 0; t0 < n_steps; t0 += n_mpc_step) {
+    __syncthreads();
+    const bool last = (t0 + n_mpc_step >= n_steps);
+    for (int rho = tid; rho < r; rho += blockDim.x) {
+      const int oidx = P.tabi[2 * RPs + rho];
+      if ((oidx >= 0 && oidx < nuse) || last) {
+        double beta = g[rho];
+        for (int f = 0; f < nf; ++f) beta += pv[f] * g[(long long)(1 + f) * r + rho];
+        double z;
+        (void)warm_component(P, RPs, rho, beta, pv, &z);
+        if (oidx >= 0 && oidx < nuse) uo[oidx] = z;
+        if (last && beta_ws) { beta_ws[b * (long long)P.rE + rho] = beta; act_ws[b * (long long)P.rE + rho] = 0; }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const int nsub = (t0 + n_mpc_step <= n_steps) ? n_mpc_step : n_steps - t0;
+      for (int j = 0; j < nsub; ++j) {
+        const int k = t0 + j;
+        double* us = u_sys + (b * n_steps + k) * m;
+        double* ys = y_sys + (b * n_steps + k) * p;
+        if (st > 1) {
+          for (int i = 0; i < m; ++i) us[i] = nanv;
+          for (int i = 0; i < p; ++i) ys[i] = nanv;
+          continue;
+        }
+        const double* uk = uo + j * m;
+        const double* wk = w + (b * n_steps + k) * p;
+        double yv[16], xn[16];
+        for (int i = 0; i < p; ++i) {              // y = C x + D u + w with the state BEFORE the update
+          double s = wk[i];
+          for (int q = 0; q < ns; ++q) s += C[i * ns + q] * xs[q];
+          for (int q = 0; q < m; ++q) s += Dm[i * m + q] * uk[q];
+          yv[i] = s;
+          ys[i] = s;
+        }
+        for (int i = 0; i < ns; ++i) {
+          double s = 0.0;
+          for (int q = 0; q < ns; ++q) s += A[i * ns + q] * xs[q];
+          for (int q = 0; q < m; ++q) s += Bm[i * m + q] * uk[q];
+          xn[i] = s;
+        }
+        for (int i = 0; i < ns; ++i) xs[i] = xn[i];
+        for (int i = 0; i < m; ++i) us[i] = uk[i];
+        for (int i = 0; i < (n - 1) * m; ++i) up[i] = up[i + m];       // FIFO shift
+        for (int i = 0; i < m; ++i) up[(n - 1) * m + i] = uk[i];
+        for (int i = 0; i < (n - 1) * p; ++i) yp[i] = yp[i + p];
+        for (int i = 0; i < p; ++i) yp[(n - 1) * p + i] = yv[i];
+      }
+    }
+  }
+  __syncthreads();
+  for (int f = tid; f < nf; f += blockDim.x) {
+    if (f < P.npu) u_past[b * P.npu + f] = pv[f]; else y_past[b * nyp + (f - P.npu)] = pv[f];
+  }
+  if (tid < ns) x[b * ns + tid] = xs[tid];
+  if (tid == 0) status_out[b] = st;
+}
+// --------------------------------------------------------------------------
+// Persistent-excitation guard (controller.py:275-296, hankel_matrix.py:55-87) for a batch.
+// The reference tests rank(H_order(u_d)) == m*order with an SVD.  Here one workgroup per instance
+// forms G = H H' (r = m*order rows), factors G = L L' and inverts L in place, all in LDS, and
+// returns a rigorous LOWER bound of sigma_min/sigma_max of H:
+//     sigma_min^2 = lambda_min(G) >= 1 / trace(G^-1) = 1 / |L^-1|_F^2,   sigma_max^2 <= trace(G).
+// A bound above a threshold far from both the SVD tolerance (max(M,N)*eps) and the rounding floor of
+// the Gram (~sqrt(r*c*eps)) certifies full rank; anything else (incl. a failed pivot) reports 0 and
+// is left to the exact SVD test on the host.  Packed lower storage: (i,j) at i(i+1)/2 + j.
+// --------------------------------------------------------------------------
+__global__ void ddmpc_pe_guard_kernel(const double* __restrict__ X, int N, int m, int order,
+                                      double* __restrict__ ratio_lb) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int r = m * order, c = N - order + 1;
+  const int npk = r * (r + 1) / 2;
+  double* G = sm;                 // packed lower, r(r+1)/2
+  double* col = sm + npk;         // r
+  double* red = col + r;          // 64
+  __shared__ int bad;
+  const double* x = X + b * (long long)N * m;   // H[i][t] = x[t*m + i]  (i = k*m + ch)
+  if (tid == 0) bad = 0;
+  // ---- Gram: one entry per thread-iteration, operands straight from global/L2 (setup-time kernel)
+  for (int e = tid; e < npk; e += nthr) {
+    int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= e) ++i;
+    while (i * (i + 1) / 2 > e) --i;
+    const int j = e - i * (i + 1) / 2;
+    const double* xi = x + i;
+    const double* xj = x + j;
+    double s0 = 0.0, s1 = 0.0;
+    int t = 0;
+    for (; t + 1 < c; t += 2) { s0 += xi[t * m] * xj[t * m]; s1 += xi[(t + 1) * m] * xj[(t + 1) * m]; }
+    if (t < c) s0 += xi[t * m] * xj[t * m];
+    G[e] = s0 + s1;
+  }
+  __syncthreads();
+  double tr = 0.0;
+  for (int i = tid; i < r; i += nthr) tr += G[i * (i + 1) / 2 + i];
+  tr = wave_sum(tr);
+  if ((tid & 63) == 0) red[tid >> 6] = tr;
+  __syncthreads();
+  double trace = 0.0;
+  for (int w = 0; w < (nthr >> 6); ++w) trace += red[w];
+  __syncthreads();
+  // ---- right-looking Cholesky, column by column
+  for (int k = 0; k < r; ++k) {
+    const double dk = G[k * (k + 1) / 2 + k];
+    if (!(dk > 1e-13 * trace)) { if (tid == 0) bad = 1; break; }     // uniform: every thread reads the same dk
+    const double inv = 1.0 / sqrt(dk);
+    for (int i = k + tid; i < r; i += nthr) col[i] = G[i * (i + 1) / 2 + k] * inv;
+    __syncthreads();
+    for (int i = k + tid; i < r; i += nthr) G[i * (i + 1) / 2 + k] = col[i];
+    // trailing update of the packed lower triangle: entry (i,j), k < j <= i
+    const int nt = r - k - 1;
+    const int ne = nt * (nt + 1) / 2;
+    for (int e = tid; e < ne; e += nthr) {
+      int ii = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+      while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
+      while (ii * (ii + 1) / 2 > e) --ii;
+      const int jj = e - ii * (ii + 1) / 2;
+      const int i = k + 1 + ii, j = k + 1 + jj;
+      G[i * (i + 1) / 2 + j] -= col[i] * col[j];
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (bad) { if (tid == 0) ratio_lb[b] = 0.0; return; }
+  // ---- in-place inverse of L (unblocked, last column first): T = L^-1,
+  //      T[j][j] = 1/L[j][j],  T[i][j] = -T[j][j] * sum_{k=j+1..i} T[i][k] L[k][j]
+  for (int j = r - 1; j >= 0; --j) {
+    const double tjj = 1.0 / G[j * (j + 1) / 2 + j];
+    for (int i = j + 1 + tid; i < r; i += nthr) col[i] = G[i * (i + 1) / 2 + j];
+    __syncthreads();
+    for (int i = j + 1 + tid; i < r; i += nthr) {
+      const double* Ti = G + i * (i + 1) / 2;
+      double s = 0.0;
+      for (int k = j + 1; k <= i; ++k) s += Ti[k] * col[k];
+      G[i * (i + 1) / 2 + j] = -tjj * s;
+    }
+    if (tid == 0) G[j * (j + 1) / 2 + j] = tjj;
+    __syncthreads();
+  }
+  double fs = 0.0;
+  for (int e = tid; e < npk; e += nthr) fs += G[e] * G[e];
+  fs = wave_sum(fs);
+  if ((tid & 63) == 0) red[tid >> 6] = fs;
+  __syncthreads();
+  if (tid == 0) {
+    double f2 = 0.0;
+    for (int w = 0; w < (nthr >> 6); ++w) f2 += red[w];
+    const double lb = 1.0 / (f2 * trace);                 // lambda_min_lb / lambda_max_ub
+    ratio_lb[b] = (lb > 0.0 && lb < 1e300) ? sqrt(lb) : 0.0;
+  }
+}
+
+}  // namespace ddmpc

@@ -154,7 +154,7 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
                                           double* __restrict__ u_opt, double* __restrict__ cost_out,
                                           int* __restrict__ status_out, int* __restrict__ iters_out,
                                           double* __restrict__ beta_ws, signed char* __restrict__ act_ws,
-                                          unsigned long long* __restrict__ stamps) {
+                                          unsigned long long* __restrict__ stamps, double* __restrict__ lfac) {
   using TM = TileMap<NT, W>;
   using LD = Lds<NT>;
   constexpr int RP = 16 * NT;
@@ -601,6 +601,20 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
     stamp();   // 4
     stamp();   // 5
 
+    // ---- optional export of the factor (ddmpc_prepare): lower tiles, row-major 16x16 each,
+    //      tile (I,J) at lfac[(I(I+1)/2 + J) * 256]; register j of lane l is row l4+4j, col l15
+    if (lfac != nullptr) {
+      static_for<NT>([&](auto J) __attribute__((always_inline)) {
+        static_for<NT>([&](auto I) __attribute__((always_inline)) {
+          if constexpr (I >= J && TM::wave(I, J) == WAVE) {
+            constexpr int S = TM::slot(I, J);
+            double* dst = lfac + (I * (I + 1) / 2 + J) * 256 + lane;
+            static_for<4>([&](auto j) __attribute__((always_inline)) { dst[64 * j] = acc[S][j()]; });
+          }
+        });
+      });
+    }
+
     // ---- y = L^-1 t sits in row rE of the tiles -> tvec[] -----------------------------
     static_for<NT>([&](auto J) __attribute__((always_inline)) {
       static_for<NT>([&](auto I) __attribute__((always_inline)) {
@@ -777,7 +791,8 @@ __global__ __launch_bounds__(64 * W, DDMPC_MIN_WAVES(W)) void ddmpc_cold_solve_k
     KParams P, const double* __restrict__ u_d, const double* __restrict__ y_d,
     const double* __restrict__ u_past, const double* __restrict__ y_past, double* __restrict__ u_opt,
     double* __restrict__ cost, int* __restrict__ status, int* __restrict__ iters,
-    double* __restrict__ beta_ws, signed char* __restrict__ act_ws, unsigned long long* __restrict__ stamps) {
+    double* __restrict__ beta_ws, signed char* __restrict__ act_ws, unsigned long long* __restrict__ stamps,
+    double* __restrict__ lfac) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const long long b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -818,144 +833,15 @@ __global__ __launch_bounds__(64 * W, DDMPC_MIN_WAVES(W)) void ddmpc_cold_solve_k
   double* bw = beta_ws ? beta_ws + b * (long long)P.rE : nullptr;
   signed char* aw = act_ws ? act_ws + b * (long long)P.rE : nullptr;
   int* it = iters ? iters + b : nullptr;
+  double* lf = lfac ? lfac + b * (long long)(NT * (NT + 1) / 2 * 256) : nullptr;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   static_for<W>([&](auto WV) {
-    if (wave == WV) wave_body<NT, W, WV>(P, sm, up, yp, uo, cost + b, status + b, it, bw, aw, st);
+    if (wave == WV) wave_body<NT, W, WV>(P, sm, up, yp, uo, cost + b, status + b, it, bw, aw, st, lf);
   });
 }
 
-#ifdef DDMPC_WITH_AUX_KERNELS   // non-template kernels: defined once, in the API translation unit
-// --------------------------------------------------------------------------
-// hankel_matrix for a batch: H[b][k*nch+ch][i] = X[b][i+k][ch]
-// (direct_data_driven_mpc/utilities/hankel_matrix.py:47-51)
-// --------------------------------------------------------------------------
-__global__ void ddmpc_hankel_kernel(const double* __restrict__ X, double* __restrict__ H, int N, int nch,
-                                    int L, long long batch) {
-  const int cols = N - L + 1;
-  const long long per = (long long)L * nch * cols;
-  const long long total = per * batch;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total;
-       g += (long long)gridDim.x * blockDim.x) {
-    const long long b = g / per;
-    const long long e = g - b * per;
-    const int row = (int)(e / cols), i = (int)(e - (long long)row * cols);
-    const int k = row / nch, ch = row - k * nch;
-    H[g] = X[b * (long long)N * nch + (long long)(i + k) * nch + ch];
-  }
-}
 
-// --------------------------------------------------------------------------
-// Variable reconstruction for ddmpc_get_solution (the `.value` stand-ins of
-// controller.py:434-445) from the beta / active-set workspace of the last solve.
-// what: 0 alpha, 1 ubar, 2 ybar, 3 sigma.  One workgroup per instance.
-// `RPs` is the row stride of the component tables.
-// --------------------------------------------------------------------------
-__global__ void ddmpc_reconstruct_kernel(KParams P, int RPs, int what, const double* __restrict__ u_d,
-                                         const double* __restrict__ y_d, const double* __restrict__ u_past,
-                                         const double* __restrict__ y_past, const double* __restrict__ beta_ws,
-                                         const signed char* __restrict__ act_ws, double* __restrict__ out) {
-  const long long b = blockIdx.x;
-  const int n = P.npu / P.m;
-  const double* bw = beta_ws + b * (long long)P.rE;
-  const signed char* aw = act_ws + b * (long long)P.rE;
-  const double* up = u_past + b * (long long)P.npu;
-  const double* yp = y_past + b * (long long)(n * P.p);
-  if (what == 0) {                       // alpha = H' beta
-    const double* ud = u_d + b * (long long)P.N * P.m;
-    const double* yd = y_d + b * (long long)P.N * P.p;
-    double* o = out + b * (long long)P.c;
-    for (int i = threadIdx.x; i < P.c; i += blockDim.x) {
-      double s = 0.0;
-      for (int k = 0; k < P.Ln; ++k) {
-        for (int ch = 0; ch < P.m; ++ch) s += ud[(i + k) * P.m + ch] * bw[k * P.nch + ch];
-        for (int ch = 0; ch < P.p; ++ch) s += yd[(i + k) * P.p + ch] * bw[k * P.nch + P.m + ch];
-      }
-      o[i] = s;
-    }
-    return;
-  }
-  for (int rho = threadIdx.x; rho < P.r; rho += blockDim.x) {
-    const int k = rho / P.nch, ch = rho - k * P.nch;
-    const int s_act = aw[rho];
-    const int kind = P.tabi[0 * RPs + rho];
-    const int pidx = P.tabi[1 * RPs + rho];
-    const double tb = P.tabd[2 * RPs + rho];
-    const double D = s_act ? P.tabd[1 * RPs + rho] : P.tabd[0 * RPs + rho];
-    const double tpast = (pidx >= 0) ? ((pidx < P.npu) ? up[pidx] : yp[pidx - P.npu]) : tb;
-    const double t = tpast + s_act * P.bound;
-    const double bb = bw[rho];
-    const double z = t - P.lam * D * bb;
-    if (ch < P.m) {
-      if (what == 1) out[b * (long long)(P.Ln * P.m) + k * P.m + ch] = z;
-      continue;
-    }
-    const int cy = ch - P.m;
-    double sg = 0.0;
-    if (kind == K_WINT) sg = z - tpast;
-    else if (kind == K_WTERM) sg = z - tb;
-    else if (kind == K_WPRED) sg = (s_act != 0) ? s_act * P.bound : -P.lam * bb / P.lamb_sigma;
-    if (what == 2) out[b * (long long)(P.Ln * P.p) + k * P.p + cy] = z - sg;
-    if (what == 3) out[b * (long long)(P.Ln * P.p) + k * P.p + cy] = sg;
-  }
-}
-// --------------------------------------------------------------------------
-// Closed-loop glue: apply up to `nsub` inputs of the last solve to the plant, record the
-// trajectories, push (u,y) into the past windows.  One thread per instance (tiny matvecs).
-//   pl: [A (ns*ns) | B (ns*m) | C (p*ns) | D (p*m)] row-major.
-// utilities/controller/controller_operation.py:278-305, utilities/model_simulation.py:93-98,
-// direct_data_driven_mpc_controller.py:893-895.
-// --------------------------------------------------------------------------
-__global__ void ddmpc_plant_kernel(long long batch, int ns, int m, int p, int n, int Lm, const double* __restrict__ pl,
-                                   int t0, int nsub, int n_steps, const double* __restrict__ u_opt,
-                                   const int* __restrict__ st_step, int* __restrict__ st_acc,
-                                   double* __restrict__ x, double* __restrict__ u_past, double* __restrict__ y_past,
-                                   const double* __restrict__ w, double* __restrict__ u_sys, double* __restrict__ y_sys) {
-  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= batch) return;
-  const double* A = pl;
-  const double* Bm = A + ns * ns;
-  const double* C = Bm + ns * m;
-  const double* D = C + p * ns;
-  int acc = st_acc[b];
-  if (st_step[b] > acc) acc = st_step[b];
-  st_acc[b] = acc;
-  double* xb = x + b * ns;
-  double* up = u_past + b * (long long)(n * m);
-  double* yp = y_past + b * (long long)(n * p);
-  const double* uo = u_opt + b * (long long)Lm;
-  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
-  for (int j = 0; j < nsub; ++j) {
-    const int k = t0 + j;
-    double* us = u_sys + (b * n_steps + k) * m;
-    double* ys = y_sys + (b * n_steps + k) * p;
-    if (acc > 1) {                               // not optimal / optimal_inaccurate: the reference raises here
-      for (int i = 0; i < m; ++i) us[i] = nanv;
-      for (int i = 0; i < p; ++i) ys[i] = nanv;
-      continue;
-    }
-    const double* uk = uo + j * m;
-    const double* wk = w + (b * n_steps + k) * p;
-    for (int i = 0; i < p; ++i) {                // y = C x + D u + w, with the state BEFORE the update
-      double s = wk[i];
-      for (int q = 0; q < ns; ++q) s += C[i * ns + q] * xb[q];
-      for (int q = 0; q < m; ++q) s += D[i * m + q] * uk[q];
-      ys[i] = s;
-    }
-    double xn[16];
-    for (int i = 0; i < ns; ++i) {
-      double s = 0.0;
-      for (int q = 0; q < ns; ++q) s += A[i * ns + q] * xb[q];
-      for (int q = 0; q < m; ++q) s += Bm[i * m + q] * uk[q];
-      xn[i] = s;
-    }
-    for (int i = 0; i < ns; ++i) xb[i] = xn[i];
-    for (int i = 0; i < m; ++i) us[i] = uk[i];
-    for (int i = 0; i < (n - 1) * m; ++i) up[i] = up[i + m];       // FIFO shift
-    for (int i = 0; i < m; ++i) up[(n - 1) * m + i] = uk[i];
-    for (int i = 0; i < (n - 1) * p; ++i) yp[i] = yp[i + p];
-    for (int i = 0; i < p; ++i) yp[(n - 1) * p + i] = ys[i];
-  }
-}
-#endif  // DDMPC_WITH_AUX_KERNELS
+
+
 
 }  // namespace ddmpc

@@ -243,7 +243,13 @@ class DirectDataDrivenMPCController:
     def _solve_on_device(self) -> None:
         up = np.asarray(self.u_past, dtype=np.float64).reshape(1, -1)
         yp = np.asarray(self.y_past, dtype=np.float64).reshape(1, -1)
-        u_opt, cost, status, _ = self._engine.solve(up, yp)
+        # The construction-time solve is a cold one; later control steps only change u_past / y_past
+        # (controller.py:404-407), so they go through ddmpc_step: the affine law prepared once per data
+        # set when the QP has no inequality, a cold solve otherwise.  `use_warm_steps = False` forces
+        # cold solves everywhere.
+        warm = bool(getattr(self, "use_warm_steps", True)) and getattr(self, "_cold_solved", False)
+        u_opt, cost, status, _ = self._engine.solve(up, yp, warm=warm)
+        self._cold_solved = True
         self._solution_cache = {}
         self._last_u = u_opt[0].copy()
         self.problem.status = L.STATUS_STRINGS.get(int(status[0]), "solver_error")

@@ -146,8 +146,11 @@ class BatchedDDMPC:
         L.check(self._lib.ddmpc_set_data(self._h, pu, py, mu))
         self._keep["data"] = (ku, ky)
 
-    def solve(self, u_past, y_past, u_opt=None, cost=None, status=None, iters=None):
-        """One cold QP solve per instance.  Returns (u_opt, cost, status, iters)."""
+    def solve(self, u_past, y_past, u_opt=None, cost=None, status=None, iters=None, warm: bool = False):
+        """One QP solve per instance.  Returns (u_opt, cost, status, iters).
+
+        warm=False: cold solve (Hankel -> Gram -> KKT -> Cholesky -> solve), `ddmpc_solve`.
+        warm=True : `ddmpc_step`, the affine law prepared once per data set (cold solve with slack CONVEX)."""
         B = self.batch
         dev = _is_torch(u_past)
         if u_opt is None:
@@ -176,9 +179,31 @@ class BatchedDDMPC:
             raise ValueError("all solve buffers must live in the same memory space")
         if m1 == L.MEM_DEVICE:
             self._use_torch_stream()
-        L.check(self._lib.ddmpc_solve(self._h, p1, p2, p3, p4, p5, p6, m1))
+        fn = self._lib.ddmpc_step if warm else self._lib.ddmpc_solve
+        L.check(fn(self._h, p1, p2, p3, p4, p5, p6, m1))
         self._keep["solve"] = (k1, k2, k3, k4, k5, k6)
         return u_opt, cost, status, iters
+
+    def prepare(self) -> None:
+        """Factor once per data set and form the affine law used by `step` (no-op with slack CONVEX)."""
+        if "data" in self._keep and self._keep["data"][0] is not None and _is_torch(self._keep["data"][0]):
+            self._use_torch_stream()
+        L.check(self._lib.ddmpc_prepare(self._h))
+
+    def step(self, u_past, y_past, u_opt=None, cost=None, status=None, iters=None):
+        """Warm control step (`ddmpc_step`): same outputs as `solve`."""
+        return self.solve(u_past, y_past, u_opt, cost, status, iters, warm=True)
+
+    def gain(self) -> np.ndarray:
+        """The prepared affine law: [batch, n*(m+p)+1, r] with beta = gain[:,0] + gain[:,1:]^T [u_past; y_past]."""
+        nf = self.n * (self.m + self.p)
+        out = np.empty((self.batch, nf + 1, (self.m + self.p) * (self.L + self.n)))
+        L.check(self._lib.ddmpc_get_gain(self._h, C.c_void_p(out.ctypes.data), L.MEM_HOST))
+        return out
+
+    def set_closed_loop_path(self, path: str) -> None:
+        """'auto' | 'cold' | 'warm' (DDMPC_OPT_CLOSED_LOOP_PATH)."""
+        L.check(self._lib.ddmpc_set_option(self._h, L.OPT_CLOSED_LOOP_PATH, {"auto": 0, "cold": 1, "warm": 2}[path]))
 
     def closed_loop(self, A, B, Cm, D, x0, u_past, y_past, w, n_mpc_step: int = 1):
         """Batched closed loop on the device (controller_operation.py:259-305 for every instance).
@@ -214,6 +239,29 @@ class BatchedDDMPC:
         test).  An instance is persistently exciting iff its rank equals m*(L+2n)."""
         H = hankel_matrix_batched(np.asarray(u_d, dtype=np.float64), self.L + 2 * self.n, device=self.device)
         return np.linalg.matrix_rank(H)
+
+    PE_CERTIFY_RATIO = 1e-5
+
+    def persistent_excitation_guard(self, u_d):
+        """Batched construction-time guard (controller.py:275-296): returns (ok [batch] bool, rank [batch] int).
+
+        Device: `ddmpc_pe_guard` gives a rigorous lower bound of sigma_min/sigma_max of every instance's
+        order-(L+2n) input Hankel matrix; a bound above PE_CERTIFY_RATIO (1e-5, nine orders above the SVD
+        tolerance max(M,N)*eps and three above the Gram's rounding floor) certifies rank m*(L+2n).
+        Host: only the instances left undecided get the reference's exact SVD test (numpy default tolerance)."""
+        u_d = np.ascontiguousarray(np.asarray(u_d, dtype=np.float64))
+        B, N, m = u_d.shape
+        order = self.L + 2 * self.n
+        full = m * order
+        ratio = np.empty((B,))
+        L.check(self._lib.ddmpc_pe_guard(C.c_void_p(u_d.ctypes.data), B, N, m, order, C.c_void_p(ratio.ctypes.data),
+                                         L.MEM_HOST, self.device))
+        rank = np.full((B,), full, dtype=np.int64)
+        undecided = np.nonzero(~(ratio > self.PE_CERTIFY_RATIO))[0]
+        if undecided.size:
+            H = hankel_matrix_batched(u_d[undecided], order, device=self.device)
+            rank[undecided] = np.linalg.matrix_rank(H)
+        return rank == full, rank
 
     def set_setpoints(self, u_s, y_s) -> None:
         us = np.ascontiguousarray(np.asarray(u_s, dtype=np.float64).reshape(-1))

@@ -78,6 +78,12 @@ extern "C" {
 #define DDMPC_SOL_YBAR  2           /* [batch, (L+n)*p]   */
 #define DDMPC_SOL_SIGMA 3           /* [batch, (L+n)*p], robust only */
 
+/* ddmpc_set_option */
+#define DDMPC_OPT_CLOSED_LOOP_PATH 1
+#define DDMPC_PATH_AUTO 0           /* warm (affine law) when the QP has no inequality, else cold */
+#define DDMPC_PATH_COLD 1           /* a full cold solve per control step                         */
+#define DDMPC_PATH_WARM 2
+
 typedef struct ddmpc_handle ddmpc_handle;
 
 /* Controller parameters = the constructor arguments of
@@ -131,6 +137,30 @@ int ddmpc_set_data(ddmpc_handle* h, const double* u_d, const double* y_d, int me
 int ddmpc_solve(ddmpc_handle* h, const double* u_past, const double* y_past,
                 double* u_opt, double* cost, int32_t* status, int32_t* iters, int mem);
 
+/* Warm path = what the reference's per-step entry point could reuse but does not:
+ * update_and_solve_data_driven_mpc (controller.py:389-407) rebuilds and re-solves the whole QP
+ * although only u_past / y_past changed (:404-407, :577-581); the Hankel matrices, weights and
+ * therefore the KKT matrix are step-invariant (:376-377).  For a nominal controller and for a
+ * robust one with slack NONE the QP has no inequality, so the solution is an affine function of
+ * [u_past; y_past].
+ *
+ * ddmpc_prepare: one cold factorisation per instance with the Cholesky factor exported, then
+ *   nf+1 = n*(m+p)+1 triangular solves per instance give the affine law
+ *   beta = gain[:,0] + gain[:,1:] [u_past; y_past].  Invalidated by ddmpc_set_data /
+ *   ddmpc_set_setpoints.  With slack CONVEX it does nothing (no affine law exists).
+ * ddmpc_step: same contract and outputs as ddmpc_solve; uses the affine law (preparing on first
+ *   use); with slack CONVEX it is a cold solve.  The status of a warm step is the status of the
+ *   factorisation it rests on.
+ * ddmpc_get_gain: out [batch, nf+1, r] doubles, r = (m+p)(L+n) components in the internal
+ *   time-major order rho = k*(m+p) + ch (ch < m: ubar, else ybar+sigma). */
+int ddmpc_prepare(ddmpc_handle* h);
+int ddmpc_step(ddmpc_handle* h, const double* u_past, const double* y_past,
+               double* u_opt, double* cost, int32_t* status, int32_t* iters, int mem);
+int ddmpc_get_gain(ddmpc_handle* h, double* out, int mem);
+
+/* Engine options (DDMPC_OPT_*). */
+int ddmpc_set_option(ddmpc_handle* h, int option, int value);
+
 /* set_input_output_setpoints (controller.py:945-982); takes effect at the next solve. */
 int ddmpc_set_setpoints(ddmpc_handle* h, const double* u_s, const double* y_s);
 
@@ -142,6 +172,17 @@ int ddmpc_get_solution(ddmpc_handle* h, int what, double* out, int mem);
  * X [batch,N,nch] -> H [batch, L*nch, N-L+1].  Stand-alone (no handle). */
 int ddmpc_hankel(const double* X, int64_t batch, int32_t N, int32_t nch, int32_t L,
                  double* H, int mem, int device);
+
+/* Batched persistent-excitation guard = the construction-time check of the reference
+ * (controller.py:275-296 -> evaluate_persistent_excitation, hankel_matrix.py:55-87: rank of the
+ * order-`order` Hankel matrix of u_d equals m*order, by SVD).  u_d [batch,N,m]; for every instance
+ * ratio_lb[b] receives a rigorous lower bound of sigma_min/sigma_max of that Hankel matrix, from a
+ * Cholesky factorisation of its Gram matrix (0 when the factorisation breaks down).  A bound well
+ * above the SVD tolerance max(M,N)*eps certifies full rank on the device; the caller runs the exact
+ * SVD test only on the instances it leaves undecided (see BatchedDDMPC.persistent_excitation_guard).
+ * Stand-alone (no handle).  DDMPC_ERR_UNSUPPORTED when m*order rows exceed one workgroup's LDS. */
+int ddmpc_pe_guard(const double* u_d, int64_t batch, int32_t N, int32_t m, int32_t order,
+                   double* ratio_lb, int mem, int device);
 
 /* LTI plant x+ = A x + B u, y = C x + D u + w (utilities/model_simulation.py:70-98); row-major HOST pointers. */
 typedef struct ddmpc_plant {
@@ -156,7 +197,10 @@ typedef struct ddmpc_plant {
  * utilities/controller/controller_operation.py:259-305 (Algorithm 1, and the n-step
  * Algorithm 2 when n_mpc_step > 1) for every instance of the batch:
  *   for t = 0, n_mpc_step, 2 n_mpc_step, ... < n_steps:
- *     cold QP solve with the current past windows              (controller.py:389-407)
+ *     QP solve with the current past windows                   (controller.py:389-407)
+ *       -- by the affine law of ddmpc_prepare when there is no inequality (the whole loop of an
+ *          instance then runs inside one workgroup), else a cold solve per step; see
+ *          DDMPC_OPT_CLOSED_LOOP_PATH
  *     for k = t .. min(t + n_mpc_step, n_steps) - 1:
  *       u[k] = optimal_u[(k-t) m : (k-t+1) m]                  (controller.py:839)
  *       y[k] = C x + D u[k] + w[k];  x <- A x + B u[k]         (model_simulation.py:93-98)

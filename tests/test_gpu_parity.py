@@ -475,3 +475,180 @@ def test_batched_persistent_excitation_guard(gpu, golden):
     with _engine(spec, 400, B) as eng:
         ranks = eng.persistent_excitation_ranks(u_bad)
     assert ranks.tolist() == [76, 76, 76, int(golden["const_pe_rank"][0]), 76, 76]
+
+
+# --------------------------------------------------- warm path: ddmpc_prepare / ddmpc_step
+@pytest.mark.parametrize("kw,N", [(dict(), 400), (dict(tec=False), 400), (dict(controller_type=0), 400),
+                                  (dict(L=10, N=120), 120), (dict(L=60, N=1000), 1000)],
+                         ids=["robust-none-tec", "robust-none-ucon", "nominal", "small", "config4"])
+def test_warm_step_matches_oracle(gpu, kw, N):
+    # SURVEY 8(d) "warm" step: per step only u_past / y_past change (controller.py:404-407,577-581), so
+    # the engine evaluates the affine law prepared once per data set.  Same tolerances as a cold solve.
+    spec = orc.spec_from_params(**kw)
+    B = 6
+    u_d, y_d, up, yp = _instances(B, N=N, seed0=60)
+    rng = np.random.default_rng(17)
+    with _engine(spec, N, B) as eng:
+        eng.set_data(u_d, y_d)
+        eng.prepare()
+        for trial in range(3):
+            if trial:
+                up = rng.uniform(-1.0, 1.0, up.shape); yp = rng.uniform(0.0, 1.0, yp.shape)
+            u, cost, status, iters = eng.step(up, yp)
+            assert np.all(iters == 1)
+            if spec.robust:
+                _check(spec, u_d, y_d, up, yp, u, cost, status, range(B))
+            else:                      # nominal with full-row-rank H: u = u_s, cost = 0 (analytic known answer)
+                assert np.all(status == 0) and np.max(np.abs(u - np.tile(spec.u_s, spec.L))) < 1e-9
+                assert np.max(np.abs(cost)) < 1e-12
+            uc, cc, sc, _ = eng.solve(up, yp)
+            assert np.max(np.abs(u - uc)) / np.max(np.abs(uc)) < 1e-10 and np.array_equal(status, sc)
+        if spec.robust:
+            u, cost, status, _ = eng.step(up, yp)          # variables read back after a WARM step
+            al, sg, ub, yb = (eng.get_solution(k) for k in ("alpha", "sigma", "ubar", "ybar"))
+            sol = orc.solve_fullspace(spec, u_d[1], y_d[1], up[1], yp[1])
+            assert np.max(np.abs(al[1] - sol.alpha)) < 1e-9 and np.max(np.abs(sg[1] - sol.sigma)) < 1e-10
+            assert np.max(np.abs(ub[1] - sol.ubar.ravel())) / np.max(np.abs(sol.ubar)) < 1e-8
+            assert np.max(np.abs(yb[1] - sol.ybar.ravel())) < 1e-8
+
+
+def test_warm_step_affine_law_full_batch(gpu):
+    # size-independent property at the full BASELINE batch: the warm step is affine in the past window,
+    # and the exported gain reproduces it.  4096 instances.
+    spec = orc.spec_from_params()
+    B = 4096
+    u_d, y_d, up, yp = _instances(B)
+    rng = np.random.default_rng(3)
+    p1 = np.concatenate([up, yp], axis=1); p2 = rng.uniform(-1.0, 1.0, p1.shape)
+    a = 0.3
+    pm = a * p1 + (1 - a) * p2
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(u_d, y_d)
+        r1 = eng.step(p1[:, :8].copy(), p1[:, 8:].copy()); r1 = [x.copy() for x in r1]
+        r2 = eng.step(p2[:, :8].copy(), p2[:, 8:].copy()); r2 = [x.copy() for x in r2]
+        rm = eng.step(pm[:, :8].copy(), pm[:, 8:].copy())
+        uc, cc, sc, _ = eng.solve(up, yp)
+        gain = eng.gain()
+    assert np.all(rm[2] == 0) and np.all(sc == 0)
+    scale = np.max(np.abs(r1[0])) + np.max(np.abs(r2[0]))
+    assert np.max(np.abs(rm[0] - (a * r1[0] + (1 - a) * r2[0]))) / scale < 1e-10
+    assert np.max(np.abs(r1[0] - uc)) / np.max(np.abs(uc)) < 1e-10            # warm == cold on all 4096
+    assert np.max(np.abs(r1[1] - cc) / cc) < 1e-9
+    # gain: beta = g0 + G' p; optimal_u rows are z = u_s - lam/r * beta on the free input components
+    assert gain.shape == (B, 17, 136)
+    beta = gain[:, 0, :] + np.einsum("bfr,bf->br", gain[:, 1:, :], p1)
+    lam = spec.lamb_alpha * spec.eps_max
+    rows = np.array([(4 + k) * 4 + ch for k in range(spec.L - 4) for ch in range(2)])     # free ubar components
+    z = np.tile(spec.u_s, spec.L - 4)[None] - lam / spec.R[0, 0] * beta[:, rows]
+    assert np.max(np.abs(z - r1[0][:, : 2 * (spec.L - 4)])) / np.max(np.abs(z)) < 1e-10
+
+
+def test_warm_step_with_slack_box_is_a_cold_solve(gpu):
+    # slack CONVEX has an inequality: no affine law; ddmpc_step must give exactly the cold result
+    spec = orc.spec_from_params(slack_var_constraint_type=1)
+    B = 8
+    u_d, y_d, up, yp = _instances(B, seed0=5)
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(u_d, y_d)
+        eng.prepare()                                           # no-op
+        uw, cw, sw, iw = eng.step(up, yp); uw = uw.copy(); iw = iw.copy()
+        uc, cc, sc, ic = eng.solve(up, yp)
+        assert np.array_equal(uw, uc) and np.array_equal(iw, ic) and np.max(ic) >= 2
+        with pytest.raises(L.DDMPCError):
+            eng.gain()
+        with pytest.raises(L.DDMPCError):
+            eng.set_closed_loop_path("warm")
+    _check(spec, u_d, y_d, up, yp, uw, cw, sw, range(B))
+
+
+def test_warm_path_invalidation_and_bad_instance(gpu):
+    # new setpoints / new data invalidate the prepared law; a singular instance keeps its error status
+    spec = orc.spec_from_params()
+    B = 4
+    u_d, y_d, up, yp = _instances(B, seed0=21)
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(u_d, y_d)
+        u, cost, status, _ = eng.step(up, yp)
+        _check(spec, u_d, y_d, up, yp, u, cost, status, range(B))
+        spec.u_s = np.array([0.8, 1.1]); spec.y_s = np.array([0.5, 0.9])
+        eng.set_setpoints(spec.u_s, spec.y_s)
+        u, cost, status, _ = eng.step(up, yp)
+        _check(spec, u_d, y_d, up, yp, u, cost, status, range(B))
+        u_d2, y_d2, up2, yp2 = _instances(B, seed0=33)
+        eng.set_data(u_d2, y_d2)
+        u, cost, status, _ = eng.step(up2, yp2)
+        _check(spec, u_d2, y_d2, up2, yp2, u, cost, status, range(B))
+    specn = orc.spec_from_params(controller_type=0)
+    u_d = u_d.copy(); y_d = y_d.copy(); u_d[2] = 1.0; y_d[2] = 0.5       # constant data: singular Gram
+    with _engine(specn, 400, B) as eng:
+        eng.set_data(u_d, y_d)
+        u, cost, status, _ = eng.step(up, yp)
+    assert L.STATUS_STRINGS[int(status[2])] == "solver_error" and [int(s) for s in status[[0, 1, 3]]] == [0, 0, 0]
+
+
+@pytest.mark.parametrize("kw,n_mpc_step", [(dict(), 1), (dict(), 4), (dict(tec=False), 1), (dict(controller_type=0), 2)],
+                         ids=["tec-1step", "tec-nstep4", "ucon-1step", "nominal-2step"])
+def test_closed_loop_warm_and_cold_paths_agree(gpu, kw, n_mpc_step):
+    # the fused one-workgroup-per-instance loop (affine law) vs one cold solve per control step
+    spec = orc.spec_from_params(**kw)
+    B, n_steps = 16, 61
+    d = generate_batch(range(70, 70 + B))
+    w = 0.002 * np.random.default_rng(9).uniform(-1.0, 1.0, (B, n_steps, 2))
+    up = d["u_d"][:, -4:, :].reshape(B, -1); yp = d["y_d"][:, -4:, :].reshape(B, -1)
+    P = orc.FOUR_TANK
+    out = {}
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(d["u_d"], d["y_d"])
+        for path in ("cold", "warm", "auto"):
+            eng.set_closed_loop_path(path)
+            out[path] = eng.closed_loop(P["A"], P["B"], P["C"], P["D"], d["x_end"], up, yp, w, n_mpc_step=n_mpc_step)
+    for a, b in zip(out["cold"], out["warm"]):
+        assert np.max(np.abs(np.asarray(a, dtype=float) - np.asarray(b, dtype=float))) < 1e-9
+    for a, b in zip(out["warm"], out["auto"]):
+        assert np.array_equal(a, b)                            # AUTO picks the warm path here
+    assert np.all(out["warm"][2] == 0)
+
+
+# ----------------------------------------------------- device persistent-excitation guard
+def test_device_pe_guard_certifies_and_defers(gpu, golden):
+    # SURVEY 8(f)-4.  Random four-tank input data is certified on the device (rank 76 for seeds 0-4 in
+    # the reference); degenerate data is never certified and gets the reference's exact SVD verdict.
+    spec = orc.spec_from_params()
+    B = 64
+    u_d, y_d, up, yp = _instances(B)
+    order, full = spec.L + 2 * spec.n, spec.m * (spec.L + 2 * spec.n)
+    ratio = np.empty((B,))
+    lib = L.load()
+    import ctypes as C
+    L.check(lib.ddmpc_pe_guard(C.c_void_p(u_d.ctypes.data), B, 400, 2, order, C.c_void_p(ratio.ctypes.data), L.MEM_HOST, 0))
+    # the bound really is a lower bound of sigma_min/sigma_max, and not uselessly loose (factor <= r)
+    for b in range(8):
+        s = np.linalg.svd(orc.hankel_matrix(u_d[b], order), compute_uv=False)
+        assert ratio[b] <= s[-1] / s[0] * (1 + 1e-9) and ratio[b] >= s[-1] / s[0] / full
+    assert np.all(ratio > 1e-4)
+    u_bad = u_d.copy()
+    u_bad[3] = 1.0                                                      # constant: rank m
+    t = np.arange(400)
+    u_bad[5] = np.stack([np.sin(0.3 * t), np.cos(0.3 * t)], axis=1)     # one sinusoid per channel: rank 4
+    u_bad[7] = u_d[7] * 1e-9 + 1.0                                      # nearly constant but still exciting
+    with _engine(spec, 400, B) as eng:
+        ok, rank = eng.persistent_excitation_guard(u_bad)
+        ranks_svd = eng.persistent_excitation_ranks(u_bad[:10])
+    assert rank[:10].tolist() == ranks_svd.tolist()                    # identical to the all-SVD path
+    assert int(rank[3]) == int(golden["const_pe_rank"][0]) and not ok[3] and not ok[5] and rank[5] < full
+    good = np.ones(B, dtype=bool); good[[3, 5]] = False
+    assert np.all(ok[good]) and np.all(rank[good] == full)
+    # sizes the kernel cannot hold are reported, not silently skipped
+    with pytest.raises(L.DDMPCError):
+        r = np.empty((1,))
+        big = np.zeros((1, 2000, 8))
+        L.check(lib.ddmpc_pe_guard(C.c_void_p(big.ctypes.data), 1, 2000, 8, 46, C.c_void_p(r.ctypes.data), L.MEM_HOST, 0))
+
+
+def test_device_pe_guard_full_batch(gpu):
+    B = 4096
+    u_d, y_d, up, yp = _instances(B)
+    spec = orc.spec_from_params()
+    with _engine(spec, 400, B) as eng:
+        ok, rank = eng.persistent_excitation_guard(u_d)
+    assert np.all(ok) and np.all(rank == 76)
