@@ -29,7 +29,7 @@
 
 // minimum waves per SIMD requested from the register allocator (keeps MFMA in VGPR form)
 #ifndef DDMPC_MIN_WAVES
-#define DDMPC_MIN_WAVES(W) ((W) <= 2 ? 2 : ((W) <= 4 ? 3 : 2))
+#define DDMPC_MIN_WAVES(NT, W) ((W) <= 2 ? 2 : ((W) <= 4 ? 3 : ((NT) <= 9 ? 4 : 2)))
 #endif
 
 namespace ddmpc {
@@ -138,7 +138,8 @@ struct Lds {
   static constexpr int red = yc + 8;                   // 32
   static constexpr int ints = red + 32;                // int act[RP], int flags[8]
   static constexpr int U = (ints + (RP + 8 + 1) / 2 + 2) & ~1;
-  static constexpr int USIZE = 8 * RP;                 // PT[4][RP] + LT[4][RP]
+  static constexpr int RS = RP + 4;                    // row stride of PT/LT: +4 doubles spreads the 4 k-rows over the banks
+  static constexpr int USIZE = 8 * RS;                 // PT[4][RS] + LT[4][RS]
   static constexpr int ctab = U + USIZE;               // lag blocks C[d][a][b], d < RP/4 (structured Gram)
   static constexpr int xs = ctab + 4 * RP;             // trajectory, channel-interleaved
   __host__ __device__ static constexpr int total(int xs_len) { return (xs + xs_len + 1) & ~1; }
@@ -428,8 +429,9 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
     //       next panel, whose columns go straight back out to PT (look-ahead); then the rest
     //       of the trailing update, which drains under the next step's chain; final L is
     //       written back into the panel columns (kept for the back substitution)
+    constexpr int RS = LD::RS;
     double* PT = UU;
-    double* LT = UU + 4 * RP;
+    double* LT = UU + 4 * RS;
     constexpr bool IDLE_WAVE_DOES_M = (W > 1) && (RP <= 64 * (W - 1)) && (NE == 1);
     long long tph0 = 0, tph1 = 0, tph2 = 0, tph3 = 0, tph4 = 0;
     const bool timing = (stamps != nullptr) && (WAVE == 0);
@@ -455,7 +457,7 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
           if constexpr (I >= Jn && TM::wave(I, Jn) == WAVE) {
             constexpr int S = TM::slot(I, Jn);
             static_for<4>([&](auto j) __attribute__((always_inline)) {
-              PT[l3 * RP + 16 * I + l4 + 4 * j] = acc[S][j()];
+              PT[l3 * RS + 16 * I + l4 + 4 * j] = acc[S][j()];
             });
           }
         });
@@ -476,10 +478,10 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
         // (2)
         if constexpr (IDLE_WAVE_DOES_M && WAVE == W - 1) {
           const double* Pd = PT + c0;
-          const double p00 = -Pd[0 * RP + 0];
-          const double p10 = -Pd[0 * RP + 1], p11 = -Pd[1 * RP + 1];
-          const double p20 = -Pd[0 * RP + 2], p21 = -Pd[1 * RP + 2], p22 = -Pd[2 * RP + 2];
-          const double p30 = -Pd[0 * RP + 3], p31 = -Pd[1 * RP + 3], p32 = -Pd[2 * RP + 3], p33 = -Pd[3 * RP + 3];
+          const double p00 = -Pd[0 * RS + 0];
+          const double p10 = -Pd[0 * RS + 1], p11 = -Pd[1 * RS + 1];
+          const double p20 = -Pd[0 * RS + 2], p21 = -Pd[1 * RS + 2], p22 = -Pd[2 * RS + 2];
+          const double p30 = -Pd[0 * RS + 3], p31 = -Pd[1 * RS + 3], p32 = -Pd[2 * RS + 3], p33 = -Pd[3 * RS + 3];
           const double d0 = p00;
           const double i0 = rsq_nr(d0);
           const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
@@ -499,11 +501,11 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
             if (row0 + 63 >= c0) {                                  // wave-uniform: slab still has live rows
               const int row = tid + e * NTHR;
               const double* Pd = PT + c0;
-              const double p00 = -Pd[0 * RP + 0];
-              const double p10 = -Pd[0 * RP + 1], p11 = -Pd[1 * RP + 1];
-              const double p20 = -Pd[0 * RP + 2], p21 = -Pd[1 * RP + 2], p22 = -Pd[2 * RP + 2];
-              const double p30 = -Pd[0 * RP + 3], p31 = -Pd[1 * RP + 3], p32 = -Pd[2 * RP + 3], p33 = -Pd[3 * RP + 3];
-              const double r0 = PT[0 * RP + row], r1 = PT[1 * RP + row], r2 = PT[2 * RP + row], r3 = PT[3 * RP + row];
+              const double p00 = -Pd[0 * RS + 0];
+              const double p10 = -Pd[0 * RS + 1], p11 = -Pd[1 * RS + 1];
+              const double p20 = -Pd[0 * RS + 2], p21 = -Pd[1 * RS + 2], p22 = -Pd[2 * RS + 2];
+              const double p30 = -Pd[0 * RS + 3], p31 = -Pd[1 * RS + 3], p32 = -Pd[2 * RS + 3], p33 = -Pd[3 * RS + 3];
+              const double r0 = PT[0 * RS + row], r1 = PT[1 * RS + row], r2 = PT[2 * RS + row], r3 = PT[3 * RS + row];
               const double d0 = p00;
               const double i0 = rsq_nr(d0);
               const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
@@ -527,7 +529,7 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
               x2 = (ii < 2) ? 0.0 : x2;
               x3 = (ii < 3) ? 0.0 : x3;
               if (row >= c0 && row < RP) {
-                LT[0 * RP + row] = x0; LT[1 * RP + row] = x1; LT[2 * RP + row] = x2; LT[3 * RP + row] = x3;
+                LT[0 * RS + row] = x0; LT[1 * RS + row] = x1; LT[2 * RS + row] = x2; LT[3 * RS + row] = x3;
               }
               if constexpr (!IDLE_WAVE_DOES_M) {
                 if (row == c0) save_m(s, d0, d1, d2v, d3, i0, i1, i2, i3, l10, l20, l21, l30, l31, l32);
@@ -543,7 +545,7 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
           double op[NT];
           static_for<NT>([&](auto I) __attribute__((always_inline)) {
             if constexpr (I >= Jb) {
-              const double v = LT[l4 * RP + 16 * I + l15];
+              const double v = LT[l4 * RS + 16 * I + l15];
               if constexpr (I == Jb) op[I] = (16 * I + l15 >= lim) ? v : 0.0;
               else op[I] = v;                      // every row/col of a later tile is >= lim
             }
@@ -587,7 +589,7 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
               if constexpr (I >= Jb && TM::wave(I, Jb) == WAVE) {
                 constexpr int S = TM::slot(I, Jb);
                 static_for<4>([&](auto j) __attribute__((always_inline)) {
-                  acc[S][j()] = LT[l3 * RP + 16 * I + l4 + 4 * j];
+                  acc[S][j()] = LT[l3 * RS + 16 * I + l4 + 4 * j];
                 });
               }
             });
@@ -787,7 +789,7 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
 // Cold-solve kernel: grid = batch, block = 64*W threads.
 // --------------------------------------------------------------------------
 template <int NT, int W>
-__global__ __launch_bounds__(64 * W, DDMPC_MIN_WAVES(W)) void ddmpc_cold_solve_kernel(
+__global__ __launch_bounds__(64 * W, DDMPC_MIN_WAVES(NT, W)) void ddmpc_cold_solve_kernel(
     KParams P, const double* __restrict__ u_d, const double* __restrict__ y_d,
     const double* __restrict__ u_past, const double* __restrict__ y_past, double* __restrict__ u_opt,
     double* __restrict__ cost, int* __restrict__ status, int* __restrict__ iters,

@@ -7,6 +7,7 @@ set -e -o pipefail
 TAG=${1:-r01_final}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
+rm -rf "$OUT"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 
@@ -15,13 +16,13 @@ tail -1 "$OUT/bench.log" > "$OUT/bench.json"
 echo "[collect] bench done"
 
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- \
-    python bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/stats.log" 2>&1
+    python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-warm > "$OUT/stats.log" 2>&1
 echo "[collect] kernel stats done"
 
 pass() {  # name, counters...
     local name=$1; shift
     timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- \
-        python bench.py --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/pmc_$name.log" 2>&1
+        python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-warm > "$OUT/pmc_$name.log" 2>&1
     echo "[collect] pmc $name done"
 }
 pass fetch FETCH_SIZE

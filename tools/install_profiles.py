@@ -1,0 +1,58 @@
+"""Copy the summaries produced by tools/collect_profiles.sh from gpurun_out/<tag>/ into profiles/
+(tracked) and print the per-launch numbers that profiles/README.md and bench.py quote.
+
+    python tools/install_profiles.py r01_final
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+src = os.path.join("gpurun_out", tag)
+dst = "profiles"
+KERNEL = "ddmpc_cold_solve_kernel"
+
+
+def one(pattern):
+    files = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)
+    if not files:
+        raise SystemExit("missing " + pattern)
+    return files[-1]
+
+
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, tag + "_bench.json"))
+shutil.copy(one("stats/*/*_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "phase_stamps.log"), os.path.join(dst, tag + "_phase_stamps.log"))
+shutil.copy(os.path.join(src, "other_configs.log"), os.path.join(dst, tag + "_other_configs.log"))
+
+b = json.load(open(os.path.join(src, "bench.json")))
+print("bench: %.3e solves/s, %.4f ms/step, kernel %.4f ms, %.2f TFLOP/s = %.1f %% of peak" % (
+    b["value"], b["ms_per_step"], b["roofline"]["kernel_ms"], b["roofline"]["achieved"], 100 * b["roofline"]["frac"]))
+if "warm_step" in b:
+    w = b["warm_step"]
+    print("warm : %.3e steps/s, %.1f GB/s = %.1f %% of HBM peak, prepare %.2f ms" % (
+        w["value"], w["roofline"]["achieved"], 100 * w["roofline"]["frac"], w["prepare_ms"]))
+print("cpu  : %.1f solves/s (%d threads); parity u %.2e cost %.2e" % (
+    b["cpu_baseline"]["value"], b["cpu_baseline"]["cores"], b["parity"]["max_rel_err_u"], b["parity"]["max_rel_err_cost"]))
+for row in csv.DictReader(open(one("stats/*/*_kernel_stats.csv"))):
+    if KERNEL in row["Name"]:
+        print("rocprof: %s calls, avg %.1f us" % (row["Calls"], float(row["AverageNs"]) / 1e3))
+
+for name in ("fetch", "write", "sq", "sq2"):
+    f = one("pmc_%s/*/*_counter_collection.csv" % name)
+    rows = [r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"]]
+    with open(os.path.join(dst, "%s_pmc_%s.csv" % (tag, name)), "w", newline="") as out:
+        wr = csv.DictWriter(out, fieldnames=list(rows[0].keys()))
+        wr.writeheader()
+        wr.writerows(rows)
+    acc = collections.defaultdict(list)
+    for r in rows:
+        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    meta = rows[0]
+    print("pmc %-5s VGPR %s scratch %s B/lane LDS %s" % (name, meta["VGPR_Count"], meta["Scratch_Size"], meta["LDS_Block_Size"]))
+    for k, v in acc.items():
+        print("    %-28s n=%d mean %.6g" % (k, len(v), sum(v) / len(v)))
