@@ -49,6 +49,41 @@ def controller_params(overrides: Optional[Dict] = None) -> Dict:
     )
 
 
+def load_yaml_config_params(config_file: str, key: str):
+    """Same contract as utilities/yaml_config_loading.py:6-37: FileNotFoundError for a missing file,
+    ValueError for a missing key."""
+    import os
+    import yaml
+    if not os.path.exists(config_file):
+        raise FileNotFoundError(f"Configuration file {config_file} not found.")
+    with open(config_file, "r") as fh:
+        config = yaml.safe_load(fh)
+    if key not in config:
+        raise ValueError(f"Missing `{key}` value in the configuration file.")
+    return config[key]
+
+
+def plant_from_yaml(config_file: str, key: str = "FourTankSystem") -> Dict:
+    """Model file -> dict(A, B, C, D, eps_max) (utilities/model_simulation.py:161-195 reads the same keys)."""
+    d = load_yaml_config_params(config_file, key)
+    return dict(A=np.array(d["A"], float), B=np.array(d["B"], float), C=np.array(d["C"], float),
+                D=np.array(d["D"], float), eps_max=float(d["eps_max"]))
+
+
+def controller_params_from_yaml(config_file: str, key: str = "data_driven_mpc_params", m: Optional[int] = None,
+                                p: Optional[int] = None, overrides: Optional[Dict] = None) -> Dict:
+    """Controller file -> derived parameters (controller_creation.py:105-168).  `m`, `p` (from the model)
+    are checked against the setpoint lengths like the reference does when it reshapes u_s / y_s."""
+    d = dict(load_yaml_config_params(config_file, key))
+    if overrides:
+        d.update(overrides)
+    if m is not None and len(d["u_s"]) != m:
+        raise ValueError("u_s must have m entries")
+    if p is not None and len(d["y_s"]) != p:
+        raise ValueError("y_s must have p entries")
+    return controller_params(d)
+
+
 def _observer(A, B, C, D):
     """pinv(O) and T of the least-squares initial-state observer
     (utilities/initial_state_estimation.py:3-24,72-93,131)."""

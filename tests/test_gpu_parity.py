@@ -652,3 +652,29 @@ def test_device_pe_guard_full_batch(gpu):
     with _engine(spec, 400, B) as eng:
         ok, rank = eng.persistent_excitation_guard(u_d)
     assert np.all(ok) and np.all(rank == 76)
+
+
+# ------------------------------------------------------------- example flow
+def test_batched_example_script(gpu, tmp_path):
+    # the reference example's flow (YAML configs -> data -> controller -> closed loop) for a batch, with
+    # the reference's per-step line format for instance 0 (controller_operation.py:327-329)
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "loop.npz"
+    res = subprocess.run([sys.executable, os.path.join(root, "examples", "batched_data_driven_mpc_example.py"),
+                          "--batch", "8", "--t_sim", "40", "--seed", "0", "--verbose", "2", "--out", str(out)],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("    Time step:")]
+    assert len(lines) == 41 and "MPC cost value:" in lines[0] and "u_1e =" in lines[0] and "y_2e =" in lines[0]
+    z = np.load(out)
+    assert z["u_sys"].shape == (8, 41, 2) and np.all(z["status"] == 0)
+    # instance 0 is the reference example with --seed 0: same closed loop as the oracle (n-step scheme, n = 4)
+    inst = orc.generate_instance(0)
+    w = inst["plant"].eps_max * inst["rng"].uniform(-1.0, 1.0, (41, 2))
+    u_ref, y_ref = orc.closed_loop(orc.spec_from_params(), inst["u_d"], inst["y_d"], inst["plant"], w, n_mpc_step=4)
+    assert np.max(np.abs(z["u_sys"][0] - u_ref)) / np.max(np.abs(u_ref)) < 1e-8
+    assert np.max(np.abs(z["y_sys"][0] - y_ref)) < 1e-9
+    res = subprocess.run([sys.executable, os.path.join(root, "examples", "batched_data_driven_mpc_example.py"),
+                          "--batch", "2", "--slack_var_const_type", "NonConvex"], capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "not currently implemented" in res.stderr

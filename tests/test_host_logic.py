@@ -85,3 +85,32 @@ def test_harness_parameters_and_batched_generation(golden):
         assert np.array_equal(d["u_d"][s], golden[f"s{s}_u_d"])          # RNG stream identical
         assert np.max(np.abs(d["y_d"][s] - golden[f"s{s}_y_d"])) < 1e-14  # batched matmul: last-ulp only
         assert np.max(np.abs(d["x_0"][s] - golden[f"s{s}_x0"])) < 1e-14
+
+
+def test_yaml_config_helpers(tmp_path):
+    # same YAML keys and error behaviour as utilities/yaml_config_loading.py:6-37 and
+    # the parameter derivation of utilities/controller/controller_creation.py:105-168
+    import os
+    from direct_data_driven_mpc_amd import harness as hs
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    model = os.path.join(root, "examples", "config", "models", "four_tank_system_params.yaml")
+    ctrl = os.path.join(root, "examples", "config", "controllers", "data_driven_mpc_example_params.yaml")
+    pl = hs.plant_from_yaml(model, "FourTankSystem")
+    for k in ("A", "B", "C", "D"):
+        assert np.array_equal(pl[k], hs.FOUR_TANK[k])
+    assert pl["eps_max"] == hs.FOUR_TANK["eps_max"]
+    cfg = hs.controller_params_from_yaml(ctrl, "data_driven_mpc_params", m=2, p=2)
+    ref = hs.controller_params()
+    assert set(cfg) == set(ref)
+    for k in ref:
+        assert np.all(np.asarray(cfg[k] == ref[k])), k
+    assert cfg["lamb_alpha"] == pytest.approx(0.1 / 0.002) and cfg["n_mpc_step"] == cfg["n"] == 4 and cfg["c"] == 1.0
+    over = hs.controller_params_from_yaml(ctrl, overrides=dict(controller_type=0, slack_var_constraint_type=1,
+                                                               epsilon_bar=0.0))
+    assert over["robust"] is False and over["slack"] == "convex" and over["lamb_alpha"] == 1000.0
+    with pytest.raises(FileNotFoundError):
+        hs.load_yaml_config_params(str(tmp_path / "missing.yaml"), "x")
+    with pytest.raises(ValueError, match="Missing `nope` value"):
+        hs.load_yaml_config_params(ctrl, "nope")
+    with pytest.raises(ValueError):
+        hs.controller_params_from_yaml(ctrl, m=3, p=2)
