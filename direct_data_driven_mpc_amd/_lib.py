@@ -17,7 +17,7 @@ OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_READY = 0, -1,
 NOMINAL, ROBUST = 0, 1
 SLACK_NON_CONVEX, SLACK_CONVEX, SLACK_NONE = 0, 1, 2
 STATUS_STRINGS = {0: "optimal", 1: "optimal_inaccurate", 2: "infeasible", 3: "unbounded", 4: "solver_error"}
-WEIGHT_SCALAR, WEIGHT_DIAG = 0, 1
+WEIGHT_SCALAR, WEIGHT_DIAG, WEIGHT_DENSE = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 GRAM_AUTO, GRAM_DENSE, GRAM_STRUCTURED = 0, 1, 2
 OPT_CLOSED_LOOP_PATH = 1

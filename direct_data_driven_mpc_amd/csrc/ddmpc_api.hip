@@ -5,6 +5,7 @@
 #include "ddmpc_aux_kernels.hpp"
 #include "../../include/ddmpc.h"
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -108,7 +109,7 @@ struct ddmpc_handle {
   bool own_stream = false;
   bool have_data = false, solved = false;
   // parameter tables on device
-  DevBuf d_tabd, d_tabi;
+  DevBuf d_tabd, d_tabi, d_dmat;
   // data (owned copies when the caller passed host memory)
   DevBuf d_ud, d_yd;
   const double* ud = nullptr;
@@ -145,6 +146,40 @@ int ddmpc_device_count(void) {
 //   w, terminal window: ybar = y_s (:615,621), sigma = w - y_s boxed (:659,674)          -> D = 1/lamb_sigma | 0
 //   w, free prediction steps: q (ybar - y_s)^2 + lamb_sigma sigma^2 (:710,716), boxed   -> D = 1/q + 1/lamb_sigma | 1/q
 //   nominal scheme: no sigma (:536-538); ybar rows behave like ubar rows with weight q.
+// Inverse of a symmetric positive definite n x n matrix (row-major) by Cholesky; false if not SPD.
+static bool spd_inverse(std::vector<double>& a, int n) {
+  std::vector<double> l((size_t)n * n, 0.0);
+  for (int j = 0; j < n; ++j) {
+    double d = a[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) d -= l[(size_t)j * n + k] * l[(size_t)j * n + k];
+    if (!(d > 0.0)) return false;
+    const double dj = std::sqrt(d);
+    l[(size_t)j * n + j] = dj;
+    for (int i = j + 1; i < n; ++i) {
+      double v = a[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) v -= l[(size_t)i * n + k] * l[(size_t)j * n + k];
+      l[(size_t)i * n + j] = v / dj;
+    }
+  }
+  // T = L^-1 (lower), then A^-1 = T' T
+  std::vector<double> t((size_t)n * n, 0.0);
+  for (int c = 0; c < n; ++c) {
+    t[(size_t)c * n + c] = 1.0 / l[(size_t)c * n + c];
+    for (int i = c + 1; i < n; ++i) {
+      double v = 0.0;
+      for (int k = c; k < i; ++k) v -= l[(size_t)i * n + k] * t[(size_t)k * n + c];
+      t[(size_t)i * n + c] = v / l[(size_t)i * n + i];
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double v = 0.0;
+      for (int k = i; k < n; ++k) v += t[(size_t)k * n + i] * t[(size_t)k * n + j];
+      a[(size_t)i * n + j] = a[(size_t)j * n + i] = v;
+    }
+  return true;
+}
+
 static int upload_params(ddmpc_handle* h) {
   const ddmpc_params& p = h->prm;
   const KParams& k = h->kp;
@@ -154,6 +189,7 @@ static int upload_params(ddmpc_handle* h) {
   const bool robust = p.controller_type == DDMPC_ROBUST;
   const bool tec = p.use_terminal_constraint != 0;
   const bool diag = p.weight_kind == DDMPC_WEIGHT_DIAG;
+  const bool dense = p.weight_kind == DDMPC_WEIGHT_DENSE;
   for (int rho = 0; rho < RP; ++rho) {
     double D0 = 0, D1 = 0, tb = 0, wq = 0;
     int kind = K_PAD, pidx = -1, oidx = -1;
@@ -166,21 +202,23 @@ static int upload_params(ddmpc_handle* h) {
         tb = h->us_h[ch];
         if (is_int) { kind = K_UFIX; pidx = kk * p.m + ch; }
         else if (is_term) { kind = K_UFIX; }
+        else if (dense) { kind = K_UFREE; }
         else { kind = K_UFREE; wq = diag ? h->Rh[kp * p.m + ch] : h->Rh[0]; D0 = D1 = 1.0 / wq; }
         if (!is_int) oidx = kp * p.m + ch;
       } else {
         const int cy = ch - p.m;
         tb = h->ys_h[cy];
-        const double q = is_int ? 0.0 : (diag ? h->Qh[kp * p.p + cy] : h->Qh[0]);
+        const double q = (is_int || dense) ? 0.0 : (diag ? h->Qh[kp * p.p + cy] : h->Qh[0]);
         wq = q;
         if (!robust) {
           if (is_int) { kind = K_YFIX; pidx = p.n * p.m + kk * p.p + cy; }
           else if (is_term) { kind = K_YFIX; }
-          else { kind = K_YFREE; D0 = D1 = 1.0 / q; }
+          else { kind = K_YFREE; if (!dense) D0 = D1 = 1.0 / q; }
         } else {
           const double ils = 1.0 / p.lamb_sigma;
           if (is_int) { kind = K_WINT; pidx = p.n * p.m + kk * p.p + cy; D0 = D1 = ils; }
           else if (is_term) { kind = K_WTERM; D0 = ils; D1 = 0.0; }
+          else if (dense) { kind = K_WPRED; }
           else { kind = K_WPRED; D0 = 1.0 / q + ils; D1 = 1.0 / q; }
         }
       }
@@ -196,6 +234,40 @@ static int upload_params(ddmpc_handle* h) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->kp.tabd = (const double*)h->d_tabd.p;
   h->kp.tabi = (const int*)h->d_tabi.p;
+  h->kp.dense_w = 0;
+  h->kp.dmat = nullptr;
+  if (dense) {
+    // lam * W^-1 as a full matrix.  Only the free prediction steps carry weights: the terminal steps are
+    // fixed to the setpoint (controller.py:612-627), so their rows/columns of Q, R drop out of the cost.
+    //   ubar free:            W = R_ff                      -> W^-1 = R_ff^-1
+    //   ybar free (nominal):  W = Q_ff                      -> W^-1 = Q_ff^-1
+    //   ybar+sigma free:      min over the split of q-form + lamb_sigma |sigma|^2 -> W^-1 = Q_ff^-1 + I/lamb_sigma
+    // Diagonal-only components (internal / terminal sigma) keep their tabd entries.
+    const int nfree = tec ? p.L - p.n : p.L;
+    std::vector<double> dm((size_t)RP * RP, 0.0);
+    for (int pass = 0; pass < 2; ++pass) {
+      const int nc = pass == 0 ? p.m : p.p, ld = nc * p.L, nn = nc * nfree;
+      const std::vector<double>& W = pass == 0 ? h->Rh : h->Qh;
+      std::vector<double> a((size_t)nn * nn);
+      for (int i = 0; i < nn; ++i)
+        for (int j = 0; j < nn; ++j) a[(size_t)i * nn + j] = 0.5 * (W[(size_t)i * ld + j] + W[(size_t)j * ld + i]);
+      if (!spd_inverse(a, nn))
+        return fail(DDMPC_ERR_UNSUPPORTED, "%s must be positive definite on the free prediction steps (HIP path)",
+                    pass == 0 ? "R" : "Q");
+      for (int i = 0; i < nn; ++i)
+        for (int j = 0; j < nn; ++j) {
+          const int ri = (p.n + i / nc) * k.nch + (pass == 0 ? 0 : p.m) + i % nc;
+          const int rj = (p.n + j / nc) * k.nch + (pass == 0 ? 0 : p.m) + j % nc;
+          double v = a[(size_t)i * nn + j];
+          if (pass == 1 && robust && i == j) v += 1.0 / p.lamb_sigma;
+          dm[(size_t)ri * RP + rj] = v;
+        }
+    }
+    if ((rc = h->d_dmat.ensure(dm.size() * sizeof(double)))) return rc;
+    HIP_TRY(hipMemcpy(h->d_dmat.p, dm.data(), dm.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->kp.dense_w = 1;
+    h->kp.dmat = (const double*)h->d_dmat.p;
+  }
   return DDMPC_OK;
 }
 
@@ -231,14 +303,31 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
                 "system order `n`.");
   if (p.N < p.L + p.n) return fail(DDMPC_ERR_INVALID, "N must be greater than or equal to L.");  // hankel_matrix.py:43-44
   if (!p.Q || !p.R || !p.u_s || !p.y_s) return fail(DDMPC_ERR_INVALID, "Q, R, u_s, y_s must not be null");
-  if (p.weight_kind != DDMPC_WEIGHT_SCALAR && p.weight_kind != DDMPC_WEIGHT_DIAG)
-    return fail(DDMPC_ERR_UNSUPPORTED, "weight_kind must be DDMPC_WEIGHT_SCALAR or DDMPC_WEIGHT_DIAG");
-  const size_t nq = p.weight_kind == DDMPC_WEIGHT_DIAG ? (size_t)p.p * p.L : 1;
-  const size_t nr = p.weight_kind == DDMPC_WEIGHT_DIAG ? (size_t)p.m * p.L : 1;
-  for (size_t i = 0; i < nq; ++i)
-    if (!(p.Q[i] > 0.0)) return fail(DDMPC_ERR_UNSUPPORTED, "Q must have a strictly positive diagonal on the HIP path");
-  for (size_t i = 0; i < nr; ++i)
-    if (!(p.R[i] > 0.0)) return fail(DDMPC_ERR_UNSUPPORTED, "R must have a strictly positive diagonal on the HIP path");
+  if (p.weight_kind != DDMPC_WEIGHT_SCALAR && p.weight_kind != DDMPC_WEIGHT_DIAG && p.weight_kind != DDMPC_WEIGHT_DENSE)
+    return fail(DDMPC_ERR_UNSUPPORTED, "weight_kind must be DDMPC_WEIGHT_SCALAR, _DIAG or _DENSE");
+  const bool wdense = p.weight_kind == DDMPC_WEIGHT_DENSE;
+  const size_t pl = (size_t)p.p * p.L, ml = (size_t)p.m * p.L;
+  const size_t nq = wdense ? pl * pl : (p.weight_kind == DDMPC_WEIGHT_DIAG ? pl : 1);
+  const size_t nr = wdense ? ml * ml : (p.weight_kind == DDMPC_WEIGHT_DIAG ? ml : 1);
+  if (!wdense) {
+    for (size_t i = 0; i < nq; ++i)
+      if (!(p.Q[i] > 0.0)) return fail(DDMPC_ERR_UNSUPPORTED, "Q must have a strictly positive diagonal on the HIP path");
+    for (size_t i = 0; i < nr; ++i)
+      if (!(p.R[i] > 0.0)) return fail(DDMPC_ERR_UNSUPPORTED, "R must have a strictly positive diagonal on the HIP path");
+  } else {
+    if (p.controller_type == DDMPC_ROBUST && p.slack_type == DDMPC_SLACK_CONVEX)
+      return fail(DDMPC_ERR_UNSUPPORTED, "dense Q / R together with the CONVEX slack box are not supported by the HIP path");
+    for (int pass = 0; pass < 2; ++pass) {
+      const double* W = pass ? p.R : p.Q;
+      const size_t nn = pass ? ml : pl;
+      double mx = 0.0;
+      for (size_t i = 0; i < nn * nn; ++i) mx = std::fabs(W[i]) > mx ? std::fabs(W[i]) : mx;
+      for (size_t i = 0; i < nn; ++i)
+        for (size_t j = 0; j < i; ++j)
+          if (std::fabs(W[i * nn + j] - W[j * nn + i]) > 1e-12 * mx)
+            return fail(DDMPC_ERR_INVALID, "%s must be symmetric", pass ? "R" : "Q");
+    }
+  }
   if (p.controller_type == DDMPC_ROBUST) {
     if (!(p.eps_max > 0.0) || !(p.lamb_alpha > 0.0) || !(p.lamb_sigma > 0.0))
       return fail(DDMPC_ERR_INVALID, "robust controller needs eps_max, lamb_alpha, lamb_sigma > 0");
@@ -338,7 +427,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat};
   for (DevBuf* b : bufs) b->release();
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -498,16 +587,22 @@ int ddmpc_prepare(ddmpc_handle* h) {
   if ((rc = launch_cold(h, z, z + B * p.n * p.m, (double*)h->d_uopt.p, (double*)h->d_cost.p,
                         (int32_t*)h->d_prep_status.p, nullptr, (double*)h->d_lfac.p)))
     return rc;
-  const unsigned ch = nrhs <= 32 ? 32u : 64u;
-  const size_t lds = (size_t)k.r * ch * sizeof(double);
-  if (lds > 160 * 1024) return fail(DDMPC_ERR_UNSUPPORTED, "warm path: r = %d too large for the gain kernel", k.r);
-  HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_gain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const size_t ntiles = B * (size_t)(NT * (NT + 1) / 2);
   if (ntiles > 0x7fffffffULL) return fail(DDMPC_ERR_INVALID, "batch too large for ddmpc_prepare");
   hipLaunchKernelGGL(ddmpc_transpose_tiles_kernel, dim3((unsigned)ntiles), dim3(256), 0, h->stream,
                      (const double*)h->d_lfac.p, (double*)h->d_lfacT.p);
-  hipLaunchKernelGGL(ddmpc_gain_kernel, dim3((unsigned)B), dim3(ch), lds, h->stream, k, 16 * NT, NT, nf,
-                     (const double*)h->d_lfac.p, (const double*)h->d_lfacT.p, (double*)h->d_gain.p);
+  if ((rc = h->d_beta.ensure(B * k.rE * sizeof(double)))) return rc;     // beta of the cold launch above
+  bool launched = false;
+#define DDMPC_INSTANCE(NT_, W_)                                                                              \
+  if (!launched && NT == NT_) {                                                                               \
+    hipLaunchKernelGGL(ddmpc_gain_kernel<NT_>, dim3((unsigned)B), dim3(256), 0, h->stream, k, 16 * NT, nf,    \
+                       (const double*)h->d_lfac.p, (const double*)h->d_lfacT.p, (const double*)h->d_beta.p,  \
+                       (double*)h->d_gain.p);                                                                 \
+    launched = true;                                                                                          \
+  }
+#include "ddmpc_instances.inc"
+#undef DDMPC_INSTANCE
+  if (!launched) return fail(DDMPC_ERR_UNSUPPORTED, "no gain kernel for %d tile rows", NT);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->d_lfac.release();                           // the factor is only needed to form the gain

@@ -66,7 +66,13 @@ __global__ void ddmpc_reconstruct_kernel(KParams P, int RPs, int what, const dou
     const double tpast = (pidx >= 0) ? ((pidx < P.npu) ? up[pidx] : yp[pidx - P.npu]) : tb;
     const double t = tpast + s_act * P.bound;
     const double bb = bw[rho];
-    const double z = t - P.lam * D * bb;
+    double z = t - P.lam * D * bb;
+    if (P.dense_w) {
+      const double* dr = P.dmat + (long long)rho * RPs;
+      double sdb = 0.0;
+      for (int j = 0; j < P.r; ++j) sdb += dr[j] * bw[j];
+      z = t - P.lam * (D * bb + sdb);
+    }
     if (ch < P.m) {
       if (what == 1) out[b * (long long)(P.Ln * P.m) + k * P.m + ch] = z;
       continue;
@@ -167,61 +173,101 @@ __global__ void ddmpc_transpose_tiles_kernel(const double* __restrict__ in, doub
   out[base + threadIdx.x] = t[c][r];
 }
 
-__global__ void ddmpc_gain_kernel(KParams P, int RPs, int NT, int nf, const double* __restrict__ lfac,
-                                  const double* __restrict__ lfacT, double* __restrict__ gain) {
-  extern __shared__ __attribute__((aligned(16))) double Y[];
+// Sum over the 16 lanes of a DPP row (all 16 lanes receive the total): four rotate-and-add steps.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_f64<0x128>(v);   // row_ror:8
+  v += dpp_f64<0x124>(v);   // row_ror:4
+  v += dpp_f64<0x122>(v);   // row_ror:2
+  v += dpp_f64<0x121>(v);   // row_ror:1
+  return v;
+}
+
+// Gain kernel: grid = batch, block = 256 = 4 waves x 4 groups of 16 lanes.  One group solves one
+// right-hand side e_rho(f): lane kk of the group owns the unknowns k = 16 J + kk in registers, a row's
+// dot product is <= NT multiply-adds per lane plus a 16-lane DPP sum, and the factor is read in
+// coalesced 128-byte rows (L from `lfac` going forward, L' from the tile-transposed copy going back),
+// the next row prefetched while the current one is reduced.  Column 0 of the gain (the offset
+// A^-1 t0) is the beta of the cold solve that exported the factor (zero past window).
+template <int NT>
+__global__ __launch_bounds__(256) void ddmpc_gain_kernel(KParams P, int RPs, int nf, const double* __restrict__ lfac,
+                                                         const double* __restrict__ lfacT,
+                                                         const double* __restrict__ beta0, double* __restrict__ gain) {
   const long long b = blockIdx.x;
-  const int CH = blockDim.x, tid = threadIdx.x, r = P.r, nrhs = nf + 1;
+  const int tid = threadIdx.x, lane = tid & 63, grp = lane >> 4, kk = lane & 15, wave = tid >> 6;
+  const int r = P.r, nrhs = nf + 1;
   const double* __restrict__ Lb = lfac + b * (long long)(NT * (NT + 1) / 2 * 256);
   const double* __restrict__ Tb = lfacT + b * (long long)(NT * (NT + 1) / 2 * 256);
-  const int ntr = (r + 15) >> 4;            // tile rows that hold real rows
-  for (int j0 = 0; j0 < nrhs; j0 += CH) {
-    const int n = j0 + tid;
-    for (int i = 0; i < r; ++i) {
-      const int pidx = P.tabi[1 * RPs + i];
-      const double tb = P.tabd[2 * RPs + i];
-      Y[i * CH + tid] = (n == 0) ? (pidx >= 0 ? 0.0 : tb) : ((pidx == n - 1) ? 1.0 : 0.0);
+  for (int rho = tid; rho < r; rho += 256) gain[(b * nrhs) * (long long)r + rho] = beta0[b * (long long)P.rE + rho];
+  auto tile = [](int I, int J) { return (I * (I + 1) / 2 + J) << 8; };
+  for (int f0 = 0; f0 < nf; f0 += 16) {
+    const int f = f0 + wave * 4 + grp;                 // this group's right-hand side (idle groups ride along)
+    int rho_f = -1;
+    for (int rho = kk; rho < r; rho += 16) rho_f = (P.tabi[1 * RPs + rho] == f) ? rho : rho_f;
+    {                                                  // max over the group (exactly one lane found it)
+      double t = (double)rho_f;
+      t = fmax(t, dpp_f64<0x128>(t)); t = fmax(t, dpp_f64<0x124>(t));
+      t = fmax(t, dpp_f64<0x122>(t)); t = fmax(t, dpp_f64<0x121>(t));
+      rho_f = (int)t;
     }
-    // forward substitution L y = t: y_i = (t_i - sum_{k<i} L[i][k] y_k) / L[i][i]
+    double y[NT], cur[NT], nxt[NT];
+    static_for<NT>([&](auto J) __attribute__((always_inline)) { y[J] = 0.0; nxt[J] = 0.0; });
+    // ---- forward substitution L y = e: row i of L, tile row I = i >> 4
+    auto load_fwd = [&](int i) __attribute__((always_inline)) {
+      const int I = i >> 4, ii = i & 15;
+      static_for<NT>([&](auto J) __attribute__((always_inline)) {
+        if (J <= I) nxt[J] = Lb[tile(I, J) + ii * 16 + kk];
+      });
+    };
+    load_fwd(0);
     for (int i = 0; i < r; ++i) {
-      double s0 = Y[i * CH + tid], s1 = 0.0;
-      const int I = i >> 4;
-      for (int J = 0; J < I; ++J) {
-        const double* __restrict__ Lr = lfac_row(Lb, i, J);
-        const double* yk = Y + (16 * J) * CH + tid;
-#pragma unroll
-        for (int kk = 0; kk < 16; kk += 2) { s0 -= Lr[kk] * yk[kk * CH]; s1 -= Lr[kk + 1] * yk[(kk + 1) * CH]; }
-      }
-      const double* __restrict__ Lr = lfac_row(Lb, i, I);
-      const double* yk = Y + (16 * I) * CH + tid;
-      for (int kk = 0; kk < (i & 15); ++kk) s0 -= Lr[kk] * yk[kk * CH];
-      Y[i * CH + tid] = (s0 + s1) / Lr[i & 15];
+      const int I = i >> 4, ii = i & 15;
+      static_for<NT>([&](auto J) __attribute__((always_inline)) { cur[J] = nxt[J]; });
+      if (i + 1 < r) load_fwd(i + 1);
+      double s = 0.0, lii = 0.0;
+      static_for<NT>([&](auto J) __attribute__((always_inline)) {
+        if (J < I) s += cur[J] * y[J];
+        if (J == I) { s += (kk < ii) ? cur[J] * y[J] : 0.0; lii = (kk == ii) ? cur[J] : 0.0; }
+      });
+      s = row16_sum(s);
+      lii = row16_sum(lii);                            // only lane ii contributed
+      const double yi = ((i == rho_f ? 1.0 : 0.0) - s) / lii;
+      static_for<NT>([&](auto J) __attribute__((always_inline)) { if (J == I && kk == ii) y[J] = yi; });
     }
-    // back substitution L' beta = y: beta_i = (y_i - sum_{k>i} L[k][i] beta_k) / L[i][i],
-    // L[16I+kk][i] = lfacT tile (I, i>>4), row i&15, entry kk
+    // ---- back substitution L' x = y: x_i = (y_i - sum_{k>i} L[k][i] x_k) / L[i][i];
+    //      L[16 I2 + kk][i] = tile-transposed copy, tile (I2, i >> 4), row i & 15, entry kk
+    auto load_bwd = [&](int i) __attribute__((always_inline)) {
+      const int Ji = i >> 4, ii = i & 15;
+      static_for<NT>([&](auto I2) __attribute__((always_inline)) {
+        if (I2 >= Ji && 16 * I2 < r) nxt[I2] = Tb[tile(I2, Ji) + ii * 16 + kk];
+      });
+    };
+    load_bwd(r - 1);
     for (int i = r - 1; i >= 0; --i) {
-      double s0 = Y[i * CH + tid], s1 = 0.0;
-      const int Ji = i >> 4;
-      for (int I = ntr - 1; I > Ji; --I) {
-        const double* __restrict__ Tr = Tb + ((I * (I + 1) / 2 + Ji) << 8) + ((i & 15) << 4);
-        const double* yk = Y + (16 * I) * CH + tid;
-        const int lim = (r - 16 * I) < 16 ? (r - 16 * I) : 16;      // rows >= r are padding / the rhs row
-        if (lim == 16) {
-#pragma unroll
-          for (int kk = 0; kk < 16; kk += 2) { s0 -= Tr[kk] * yk[kk * CH]; s1 -= Tr[kk + 1] * yk[(kk + 1) * CH]; }
-        } else {
-          for (int kk = 0; kk < lim; ++kk) s0 -= Tr[kk] * yk[kk * CH];
+      const int Ji = i >> 4, ii = i & 15;
+      static_for<NT>([&](auto J) __attribute__((always_inline)) { cur[J] = nxt[J]; });
+      if (i > 0) load_bwd(i - 1);
+      double s = 0.0, lii = 0.0;
+      static_for<NT>([&](auto I2) __attribute__((always_inline)) {
+        if (I2 >= Ji && 16 * I2 < r) {
+          const int k = 16 * I2 + kk;
+          if (k > i && k < r) s += cur[I2] * y[I2];
+          if (k == i) { s -= y[I2]; lii = cur[I2]; }   // the owner lane folds y_i into the sum: no broadcast needed
         }
-      }
-      const double* __restrict__ Tr = Tb + ((Ji * (Ji + 1) / 2 + Ji) << 8) + ((i & 15) << 4);
-      const double* yk = Y + (16 * Ji) * CH + tid;
-      const int lim = (r - 16 * Ji) < 16 ? (r - 16 * Ji) : 16;
-      for (int kk = (i & 15) + 1; kk < lim; ++kk) s0 -= Tr[kk] * yk[kk * CH];
-      Y[i * CH + tid] = (s0 + s1) / Tr[i & 15];
+      });
+      s = row16_sum(s);
+      lii = row16_sum(lii);
+      const double xi = -s / lii;
+      static_for<NT>([&](auto J) __attribute__((always_inline)) { if (J == Ji && kk == ii) y[J] = xi; });
     }
-    if (n < nrhs) {
-      double* g = gain + (b * nrhs + n) * (long long)r;
-      for (int i = 0; i < r; ++i) g[i] = Y[i * CH + tid];
+    if (f < nf) {
+      double* g = gain + (b * nrhs + 1 + f) * (long long)r;
+      static_for<NT>([&](auto J) __attribute__((always_inline)) { if (16 * J + kk < r) g[16 * J + kk] = y[J]; });
     }
   }
 }
@@ -229,15 +275,23 @@ __global__ void ddmpc_gain_kernel(KParams P, int RPs, int NT, int nf, const doub
 // Output stage shared by the warm kernels: z, cost contribution and optimal_u of one component
 // (same formulas as the cold kernel's output stage, active set empty).
 __device__ __forceinline__ double warm_component(const KParams& P, int RPs, int rho, double beta, const double* pv,
-                                                 double* z_out) {
+                                                 const double* bvec, double* z_out) {
   const int kind = P.tabi[0 * RPs + rho];
   const int pidx = P.tabi[1 * RPs + rho];
   const double D = P.tabd[0 * RPs + rho];
   const double tb = P.tabd[2 * RPs + rho];
   const double wq = P.tabd[3 * RPs + rho];
   const double t = (pidx >= 0) ? pv[pidx] : tb;
-  const double z = t - P.lam * D * beta;
+  double z = t - P.lam * D * beta;
+  if (P.dense_w) {                                  // dense weighting matrices: z = t - lam (W^-1 beta)
+    const double* dr = P.dmat + (long long)rho * RPs;
+    double sdb = 0.0;
+    for (int j = 0; j < P.r; ++j) sdb += dr[j] * bvec[j];
+    z = t - P.lam * (D * beta + sdb);
+  }
   double contrib = P.lam * beta * z;
+  if (P.dense_w && (kind == K_UFREE || kind == K_YFREE || kind == K_WPRED)) contrib -= P.lam * beta * (z - tb);
+  else
   if (kind == K_UFREE || kind == K_YFREE) { const double dlt = z - tb; contrib += wq * dlt * dlt; }
   else if (kind == K_WINT) { const double sg = z - t; contrib += P.lamb_sigma * sg * sg; }
   else if (kind == K_WTERM) { const double sg = z - tb; contrib += P.lamb_sigma * sg * sg; }
@@ -251,6 +305,7 @@ __device__ __forceinline__ double warm_component(const KParams& P, int RPs, int 
 }
 
 constexpr int WARM_MAX_NF = 256;
+constexpr int WARM_MAX_R = 288;     // >= 16 * 17 + a little: rows of the largest cold-solve instance
 
 // One warm step for the batch: grid = batch, block = r rounded up to 64.
 // Replaces update_and_solve_data_driven_mpc (controller.py:389-407) once the data are fixed.
@@ -261,6 +316,7 @@ __global__ void ddmpc_warm_step_kernel(KParams P, int RPs, int nf, const double*
                                        double* __restrict__ beta_ws, signed char* __restrict__ act_ws) {
   __shared__ double pv[WARM_MAX_NF];
   __shared__ double red[32];
+  __shared__ double bsh[WARM_MAX_R];
   const long long b = blockIdx.x;
   const int tid = threadIdx.x, r = P.r, nrhs = nf + 1;
   const int nyp = nf - P.npu;
@@ -273,8 +329,13 @@ __global__ void ddmpc_warm_step_kernel(KParams P, int RPs, int nf, const double*
   for (int rho = tid; rho < r; rho += blockDim.x) {
     double beta = g[rho];
     for (int f = 0; f < nf; ++f) beta += pv[f] * g[(long long)(1 + f) * r + rho];
+    bsh[rho] = beta;
+  }
+  __syncthreads();
+  for (int rho = tid; rho < r; rho += blockDim.x) {
+    const double beta = bsh[rho];
     double z;
-    part += warm_component(P, RPs, rho, beta, pv, &z);
+    part += warm_component(P, RPs, rho, beta, pv, bsh, &z);
     finite = finite && (fabs(beta) < 1e300);
     const int oidx = P.tabi[2 * RPs + rho];
     if (oidx >= 0) u_opt[b * (long long)((P.Ln - P.npu / P.m) * P.m) + oidx] = z;
@@ -309,6 +370,7 @@ __global__ void ddmpc_closed_loop_warm_kernel(KParams P, int RPs, int nf, const 
   __shared__ double pv[WARM_MAX_NF];
   __shared__ double uo[WARM_MAX_NF];      // the first n_mpc_step*m entries of optimal_u
   __shared__ double xs[16];
+  __shared__ double bsh[WARM_MAX_R];
   const long long b = blockIdx.x;
   const int tid = threadIdx.x, r = P.r, nrhs = nf + 1, m = P.m, p = P.p;
   const int n = P.npu / m, nyp = nf - P.npu;
@@ -328,16 +390,24 @@ __global__ void ddmpc_closed_loop_warm_kernel(KParams P, int RPs, int nf, const 
   for (int t0 = 0; t0 < n_steps; t0 += n_mpc_step) {
     __syncthreads();
     const bool last = (t0 + n_mpc_step >= n_steps);
+    const bool all_rows = last || P.dense_w;          // dense weights: z needs the whole beta vector
     for (int rho = tid; rho < r; rho += blockDim.x) {
       const int oidx = P.tabi[2 * RPs + rho];
-      if ((oidx >= 0 && oidx < nuse) || last) {
+      if ((oidx >= 0 && oidx < nuse) || all_rows) {
         double beta = g[rho];
         for (int f = 0; f < nf; ++f) beta += pv[f] * g[(long long)(1 + f) * r + rho];
-        double z;
-        (void)warm_component(P, RPs, rho, beta, pv, &z);
-        if (oidx >= 0 && oidx < nuse) uo[oidx] = z;
-        if (last && beta_ws) { beta_ws[b * (long long)P.rE + rho] = beta; act_ws[b * (long long)P.rE + rho] = 0; }
+        bsh[rho] = beta;
       }
+    }
+    __syncthreads();
+    for (int rho = tid; rho < r; rho += blockDim.x) {
+      const int oidx = P.tabi[2 * RPs + rho];
+      if (oidx >= 0 && oidx < nuse) {
+        double z;
+        (void)warm_component(P, RPs, rho, bsh[rho], pv, bsh, &z);
+        uo[oidx] = z;
+      }
+      if (last && beta_ws) { beta_ws[b * (long long)P.rE + rho] = bsh[rho]; act_ws[b * (long long)P.rE + rho] = 0; }
     }
     __syncthreads();
     if (tid == 0) {

@@ -62,6 +62,8 @@ struct KParams {
   double bound;     // c * eps_max
   const double* tabd;
   const int* tabi;
+  int dense_w;          // 1: dense weighting matrices -> lam * W^-1 is the full [RP][RP] matrix `dmat`
+  const double* dmat;   //    (shared by the batch, zero outside the weighted components), tabd D0 = D1 = 0
 };
 
 template <int N, class F>
@@ -420,6 +422,23 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
       });
     });
 
+    // ---- dense weighting matrices (controller.py:708-710 with non-diagonal Q, R): the penalty
+    //      term lam * W^-1 is a full matrix, identical for the whole batch, read from L2
+    if (P.dense_w) {
+      static_for<NT>([&](auto J) __attribute__((always_inline)) {
+        static_for<NT>([&](auto I) __attribute__((always_inline)) {
+          if constexpr (I >= J && TM::wave(I, J) == WAVE) {
+            constexpr int S = TM::slot(I, J);
+            const double* dm = P.dmat + (long long)(16 * I + l4) * RP + 16 * J + l15;
+            static_for<4>([&](auto j) __attribute__((always_inline)) {
+              const double dv = dm[4 * j() * RP];
+              if (I != J || l4 + 4 * j() >= l15) acc[S][j()] -= P.lam * dv;
+            });
+          }
+        });
+      });
+    }
+
     // ---- blocked Cholesky, 4-wide panels, two barriers per step -----------------------
     //   (1) [at the end of the previous step] raw, negated panel columns -> PT
     //   (2) one thread per row: factor the 4x4 diagonal block (redundantly per thread),
@@ -749,13 +768,23 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
       const double b = beta[rho];
       const double D = s_act ? cD1[e()] : cD0[e()];
       const double t = cT[e()] + s_act * P.bound;
-      const double z = t - P.lam * D * b;
+      double z = t - P.lam * D * b;
+      if (P.dense_w) {                              // z = t - lam (W^-1 beta): one row of the dense matrix
+        const double* dr = P.dmat + (long long)rho * RP;
+        double sdb = 0.0;
+        for (int j = 0; j < r; ++j) sdb += dr[j] * beta[j];
+        z = t - P.lam * (D * b + sdb);          // tabd keeps the diagonal-only components
+      }
       const double wq = P.tabd[3 * RP + rho];
       const double tb = P.tabd[2 * RP + rho];       // setpoint of the component (u_s / y_s)
       const int oidx = P.tabi[2 * RP + rho];
       finite = finite && (fabs(b) < 1e300);
       double contrib = P.lam * b * z;
       const int kind = cK[e()];
+      if (P.dense_w && (kind == K_UFREE || kind == K_YFREE || kind == K_WPRED)) {
+        // (z - zs)' W (z - zs) summed over the weighted components equals -lam * beta' (z - zs)
+        contrib -= P.lam * b * (z - tb);
+      } else
       if (kind == K_UFREE || kind == K_YFREE) { const double dlt = z - tb; contrib += wq * dlt * dlt; }
       else if (kind == K_WINT) { const double sg = z - cT[e()]; contrib += P.lamb_sigma * sg * sg; }
       else if (kind == K_WTERM) { const double sg = z - tb; contrib += P.lamb_sigma * sg * sg; }

@@ -25,7 +25,9 @@ def _is_torch(x) -> bool:
 
 
 def _weights(W, size: int, name: str) -> Tuple[int, np.ndarray]:
-    """Accept scalar / 1-D diagonal / 2-D diagonal matrix; return (kind, values)."""
+    """Accept scalar / 1-D diagonal / 2-D matrix; return (kind, values).  A 2-D matrix that is diagonal is
+    passed as its diagonal, anything else as the dense matrix (symmetry and definiteness are checked by
+    `ddmpc_create`)."""
     W = np.asarray(W, dtype=np.float64)
     if W.ndim == 0:
         return L.WEIGHT_SCALAR, W.reshape(1).copy()
@@ -38,13 +40,20 @@ def _weights(W, size: int, name: str) -> Tuple[int, np.ndarray]:
             raise ValueError("%s must be %dx%d" % (name, size, size))
         d = np.diag(W)
         if np.any(W != np.diag(d)):
-            raise NotImplementedError(
-                "%s is not diagonal: dense weighting matrices are not supported by the HIP path yet" % name)
+            return L.WEIGHT_DENSE, np.ascontiguousarray(W, dtype=np.float64)
     else:
         raise ValueError("%s has too many dimensions" % name)
     if np.all(d == d[0]):
         return L.WEIGHT_SCALAR, np.array([d[0]], dtype=np.float64)
     return L.WEIGHT_DIAG, np.ascontiguousarray(d, dtype=np.float64)
+
+
+def _expand_weight(kind: int, v: np.ndarray, size: int, target: int) -> np.ndarray:
+    """Bring a weight to the representation `target` (both weights travel in the same kind)."""
+    if kind == target:
+        return v
+    d = np.full(size, v[0]) if kind == L.WEIGHT_SCALAR else v
+    return d if target == L.WEIGHT_DIAG else np.ascontiguousarray(np.diag(d))
 
 
 class BatchedDDMPC:
@@ -60,12 +69,11 @@ class BatchedDDMPC:
         self.controller_type, self.slack_type = int(controller_type), int(slack_type)
         wk_q, q = _weights(Q, self.p * self.L, "Q")
         wk_r, r = _weights(R, self.m * self.L, "R")
-        if wk_q != wk_r:      # mixed: expand the scalar one
-            if wk_q == L.WEIGHT_SCALAR:
-                q = np.full(self.p * self.L, q[0])
-            else:
-                r = np.full(self.m * self.L, r[0])
-            wk_q = wk_r = L.WEIGHT_DIAG
+        if wk_q != wk_r:      # mixed: bring both to the richer representation
+            target = max(wk_q, wk_r)
+            q = _expand_weight(wk_q, q, self.p * self.L, target)
+            r = _expand_weight(wk_r, r, self.m * self.L, target)
+            wk_q = wk_r = target
         self._q, self._r = q, r
         self._us = np.ascontiguousarray(np.asarray(u_s, dtype=np.float64).reshape(-1))
         self._ys = np.ascontiguousarray(np.asarray(y_s, dtype=np.float64).reshape(-1))

@@ -63,6 +63,8 @@ extern "C" {
 #define DDMPC_WEIGHT_SCALAR 0       /* Q = q*I, R = r*I (what the reference loader builds,
                                        utilities/controller/controller_creation.py:125-127) */
 #define DDMPC_WEIGHT_DIAG   1       /* Q = diag(q[0..p*L)), R = diag(r[0..m*L)) */
+#define DDMPC_WEIGHT_DENSE  2       /* Q [p*L, p*L], R [m*L, m*L] row-major, symmetric, positive definite on the free
+                                       prediction steps (controller.py:121-124,708-710); not with slack CONVEX */
 
 #define DDMPC_MEM_HOST   0
 #define DDMPC_MEM_DEVICE 1
@@ -96,8 +98,8 @@ typedef struct ddmpc_params {
   int32_t slack_type;               /* DDMPC_SLACK_*                                 */
   int32_t use_terminal_constraint;  /* controller.py:229,489-492                     */
   int32_t weight_kind;              /* DDMPC_WEIGHT_*                                */
-  const double* Q;                  /* 1 value (scalar) or p*L values (diag)         */
-  const double* R;                  /* 1 value (scalar) or m*L values (diag)         */
+  const double* Q;                  /* 1 value (scalar), p*L values (diag) or (p*L)^2 (dense) */
+  const double* R;                  /* 1 value (scalar), m*L values (diag) or (m*L)^2 (dense) */
   double eps_max, lamb_alpha, lamb_sigma, c;   /* robust parameters, controller.py:197-205 */
   const double* u_s;                /* [m]                                           */
   const double* y_s;                /* [p]                                           */

@@ -678,3 +678,67 @@ def test_batched_example_script(gpu, tmp_path):
     res = subprocess.run([sys.executable, os.path.join(root, "examples", "batched_data_driven_mpc_example.py"),
                           "--batch", "2", "--slack_var_const_type", "NonConvex"], capture_output=True, text=True, timeout=300)
     assert res.returncode != 0 and "not currently implemented" in res.stderr
+
+
+# -------------------------------------------------- dense weighting matrices (a12)
+def _spd(rng, size, scale, blocks):
+    # block-banded SPD matrix: couples neighbouring prediction steps and channels
+    A = rng.normal(size=(size, size)) * 0.2
+    W = A @ A.T / size + np.eye(size)
+    band = np.abs(np.subtract.outer(np.arange(size), np.arange(size))) <= blocks
+    return scale * (W * band + np.diag(np.abs(W * ~band).sum(axis=1)))        # diagonally dominant -> SPD
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(tec=False), dict(L=10, N=120)], ids=["tec", "ucon", "small"])
+def test_dense_weighting_matrices(gpu, kw):
+    # the class accepts any Q (pL x pL), R (mL x mL) (controller.py:121-124,327-343,708-710); the loader
+    # only builds q*I, r*I.  Dense SPD weights: cold solve, warm step, variables, closed loop vs the oracle.
+    spec = orc.spec_from_params(**kw)
+    rng = np.random.default_rng(11)
+    spec.Q = _spd(rng, spec.p * spec.L, 3.0, 3)
+    spec.R = _spd(rng, spec.m * spec.L, 1e-4, 2)
+    N = kw.get("N", 400)
+    B = 5
+    u_d, y_d, up, yp = _instances(B, N=N, seed0=90)
+    with _engine(spec, N, B) as eng:
+        eng.set_data(u_d, y_d)
+        u, cost, status, iters = eng.solve(up, yp)
+        _check(spec, u_d, y_d, up, yp, u, cost, status, range(B))
+        al, sg, ub, yb = (eng.get_solution(k) for k in ("alpha", "sigma", "ubar", "ybar"))
+        sol = orc.solve_fullspace(spec, u_d[2], y_d[2], up[2], yp[2])
+        assert np.max(np.abs(al[2] - sol.alpha)) < 1e-9 and np.max(np.abs(sg[2] - sol.sigma)) < 1e-10
+        assert np.max(np.abs(ub[2] - sol.ubar.ravel())) / np.max(np.abs(sol.ubar)) < 1e-8
+        assert np.max(np.abs(yb[2] - sol.ybar.ravel())) < 1e-8
+        up2 = rng.uniform(-1.0, 1.0, up.shape); yp2 = rng.uniform(0.0, 1.0, yp.shape)
+        uw, cw, sw, _ = eng.step(up2, yp2)                         # warm step with dense weights
+        _check(spec, u_d, y_d, up2, yp2, uw, cw, sw, range(B))
+    if not kw:
+        insts = [orc.generate_instance(s) for s in range(2)]
+        ud = np.stack([i["u_d"] for i in insts]); yd = np.stack([i["y_d"] for i in insts])
+        x0 = np.stack([i["plant"].x for i in insts]); n_steps = 10
+        w = np.stack([i["plant"].eps_max * i["rng"].uniform(-1.0, 1.0, (n_steps, 2)) for i in insts])
+        P = orc.FOUR_TANK
+        with _engine(spec, 400, 2) as eng:
+            eng.set_data(ud, yd)
+            u_sys, y_sys, st, *_ = eng.closed_loop(P["A"], P["B"], P["C"], P["D"], x0, ud[:, -4:].reshape(2, -1),
+                                                   yd[:, -4:].reshape(2, -1), w, n_mpc_step=2)
+        for b in range(2):
+            u_ref, y_ref = orc.closed_loop(spec, ud[b], yd[b], insts[b]["plant"], w[b], n_mpc_step=2)
+            assert np.max(np.abs(u_sys[b] - u_ref)) / np.max(np.abs(u_ref)) < 1e-8 and np.max(np.abs(y_sys[b] - y_ref)) < 1e-9
+
+
+def test_dense_weights_rejections(gpu):
+    spec = orc.spec_from_params(slack_var_constraint_type=1)
+    spec.Q = spec.Q + 0.01                                           # dense + slack CONVEX: unsupported
+    with pytest.raises(L.DDMPCError, match="CONVEX"):
+        _engine(spec, 400, 1)
+    spec = orc.spec_from_params()
+    Q = spec.Q.copy(); Q[0, 1] = 0.5                                 # not symmetric
+    spec.Q = Q
+    with pytest.raises(L.DDMPCError, match="symmetric"):
+        _engine(spec, 400, 1)
+    spec = orc.spec_from_params()
+    Q = spec.Q.copy(); Q[0, 1] = Q[1, 0] = 10.0                      # symmetric but indefinite
+    spec.Q = Q
+    with pytest.raises(L.DDMPCError, match="positive definite"):
+        _engine(spec, 400, 1)

@@ -57,8 +57,12 @@ def test_weight_handling():
     d = np.linspace(1, 2, 60)
     k, v = _weights(np.diag(d), 60, "Q")
     assert k == L.WEIGHT_DIAG and np.array_equal(v, d)
-    with pytest.raises(NotImplementedError):
-        _weights(np.eye(60) + 0.1, 60, "Q")
+    k, v = _weights(np.eye(60) + 0.1, 60, "Q")                  # non-diagonal: travels as the dense matrix
+    assert k == L.WEIGHT_DENSE and v.shape == (60, 60)
+    from direct_data_driven_mpc_amd.engine import _expand_weight
+    assert np.array_equal(_expand_weight(L.WEIGHT_SCALAR, np.array([2.0]), 3, L.WEIGHT_DENSE), 2.0 * np.eye(3))
+    assert np.array_equal(_expand_weight(L.WEIGHT_DIAG, np.array([1.0, 2.0]), 2, L.WEIGHT_DENSE), np.diag([1.0, 2.0]))
+    assert np.array_equal(_expand_weight(L.WEIGHT_SCALAR, np.array([2.0]), 3, L.WEIGHT_DIAG), np.full(3, 2.0))
     with pytest.raises(ValueError):
         _weights(np.eye(59), 60, "Q")
 
