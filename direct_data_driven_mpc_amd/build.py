@@ -25,7 +25,7 @@ ARCH = "gfx950"
 # -simplifycfg-sink-common=false: the sink-common transform merges per-tile code
 # into PHIs of accumulator pointers, which pins the MFMA accumulators in scratch.
 COMMON_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
-                "-mllvm", "-simplifycfg-sink-common=false", "-I" + CSRC]
+                "-mllvm", "-simplifycfg-sink-common=false", "-I" + CSRC] + os.environ.get("DDMPC_EXTRA_FLAGS", "").split()
 
 
 def _hipcc() -> str:

@@ -398,6 +398,10 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   if (k.xs_len < (p.N + 2) * k.nch) k.xs_len = ((p.N + 2) * k.nch + 1) & ~1;
   const size_t lds_doubles = lds_doubles_for(kc->NT, k.xs_len);
   h->lds_bytes = lds_doubles * sizeof(double);
+  if (const char* pad = getenv("DDMPC_LDS_PAD")) {        // development knob: extra LDS bytes to lower the occupancy
+    const long v = atol(pad);
+    if (v > 0 && h->lds_bytes + (size_t)v <= 160 * 1024) h->lds_bytes += (size_t)v;
+  }
   if (h->lds_bytes > 160 * 1024) {
     delete h;
     return fail(DDMPC_ERR_UNSUPPORTED, "trajectory too long for LDS staging: needs %zu bytes of LDS", h->lds_bytes);
