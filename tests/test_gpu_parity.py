@@ -742,3 +742,22 @@ def test_dense_weights_rejections(gpu):
     spec.Q = Q
     with pytest.raises(L.DDMPCError, match="positive definite"):
         _engine(spec, 400, 1)
+
+
+def test_long_data_trajectory(gpu):
+    # N = 2000 (the data length of BASELINE configs[4]) with the four-tank horizon: c = 1967 Hankel columns,
+    # 86 KB of LDS per workgroup (one workgroup per CU), ragged last k-steps of the lag-block loop
+    for N, slack in ((2000, 0), (1501, 1)):
+        spec = orc.spec_from_params(N=N, slack_var_constraint_type=slack)
+        B = 3
+        u_d, y_d, up, yp = _instances(B, N=N, seed0=77)
+        with _engine(spec, N, B) as eng:
+            eng.set_data(u_d, y_d)
+            u, cost, status, _ = eng.solve(up, yp)
+            _check(spec, u_d, y_d, up, yp, u, cost, status, range(B))
+            if slack == 0:
+                uw, cw, sw, _ = eng.step(up, yp)
+                _check(spec, u_d, y_d, up, yp, uw, cw, sw, range(B))
+    # a trajectory that cannot be staged in LDS is refused at create time, not at launch
+    with pytest.raises(L.DDMPCError, match="LDS"):
+        _engine(orc.spec_from_params(N=6000), 6000, 1)
