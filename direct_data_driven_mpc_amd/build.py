@@ -9,6 +9,7 @@ The shared object stays in-tree (git-ignored, but it travels to the GPU box).
 from __future__ import annotations
 
 import argparse
+import hashlib
 import os
 import re
 import shutil
@@ -45,14 +46,29 @@ def instances():
     return [(nt, w) for nt, w in inst if not (SKIP_LARGE and nt > LARGE_NT)]
 
 
-# what each kind of translation unit is built from (mtime-based rebuild)
+# what each kind of translation unit is built from; an object is rebuilt when the hash of these files
+# and of its command line differs from the one recorded next to it (content-based: immune to
+# checkouts and copies that only change modification times)
 INST_DEPS = ["ddmpc_inst.hip", "ddmpc_kernels.hpp"]
 API_DEPS = ["ddmpc_api.hip", "ddmpc_aux_kernels.hpp", "ddmpc_kernels.hpp", "ddmpc_instances.inc"]
 
 
-def _newest(names, extra=()) -> float:
-    paths = [os.path.join(CSRC, f) for f in names] + list(extra)
-    return max(os.path.getmtime(p) for p in paths)
+def _fingerprint(cmd, names, extra=()) -> str:
+    h = hashlib.sha256()
+    # flags and defines, not the locations (hipcc, -I, source and object paths differ between checkouts)
+    h.update("\0".join(a for a in cmd[1:] if not a.startswith(("-I", "/")) and a not in ("-c", "-o")).encode())
+    for path in [os.path.join(CSRC, f) for f in names] + list(extra):
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _is_current(obj: str, fp: str) -> bool:
+    try:
+        with open(obj + ".hash") as fh:
+            return os.path.exists(obj) and fh.read().strip() == fp
+    except OSError:
+        return False
 
 
 def _compile(cmd, out):
@@ -66,27 +82,38 @@ def build(force: bool = False, jobs: int = 0, verbose: bool = True) -> str:
     """Compile every HIP translation unit for gfx950 and link libddmpc.so."""
     hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
-    newest_inst = _newest(INST_DEPS)
-    newest_api = _newest(API_DEPS, [os.path.join(os.path.dirname(PKG_DIR), "include", "ddmpc.h")])
+    header = os.path.join(os.path.dirname(PKG_DIR), "include", "ddmpc.h")
     tasks = []
     api_obj = os.path.join(OBJ_DIR, "ddmpc_api_nolarge.o" if SKIP_LARGE else "ddmpc_api.o")
     api_flags = ["-DDDMPC_NO_LARGE"] if SKIP_LARGE else []
-    tasks.append(([hipcc] + COMMON_FLAGS + api_flags + ["-c", os.path.join(CSRC, "ddmpc_api.hip"), "-o", api_obj], api_obj))
+    cmd = [hipcc] + COMMON_FLAGS + api_flags + ["-c", os.path.join(CSRC, "ddmpc_api.hip"), "-o", api_obj]
+    tasks.append((cmd, api_obj, _fingerprint(cmd, API_DEPS, [header])))
     for nt, w in instances():
         obj = os.path.join(OBJ_DIR, "ddmpc_inst_%d_%d.o" % (nt, w))
-        tasks.append(([hipcc] + COMMON_FLAGS + ["-DDDMPC_INST_NT=%d" % nt, "-DDDMPC_INST_W=%d" % w, "-c",
-                                                 os.path.join(CSRC, "ddmpc_inst.hip"), "-o", obj], obj))
-    todo = [(c, o) for c, o in tasks if force or not os.path.exists(o) or
-            os.path.getmtime(o) < (newest_inst if "ddmpc_inst_" in o else newest_api)]
+        cmd = [hipcc] + COMMON_FLAGS + ["-DDDMPC_INST_NT=%d" % nt, "-DDDMPC_INST_W=%d" % w, "-c",
+                                        os.path.join(CSRC, "ddmpc_inst.hip"), "-o", obj]
+        tasks.append((cmd, obj, _fingerprint(cmd, INST_DEPS)))
+    todo = [t for t in tasks if force or not _is_current(t[1], t[2])]
     todo.sort(key=lambda t: -int(re.search(r"ddmpc_inst_(\d+)_", t[1]).group(1)) if "ddmpc_inst_" in t[1] else 0)  # longest first
     if todo:
         jobs = jobs or min(len(todo), max(1, (os.cpu_count() or 2) - 1), 8)
         if verbose:
             print("[ddmpc build] compiling %d translation unit(s) for %s with %d job(s)" % (len(todo), ARCH, jobs),
                   flush=True)
+
+        def run(t):
+            cmd, obj, fp = t
+            if os.path.exists(obj + ".hash"):
+                os.remove(obj + ".hash")
+            _compile(cmd, obj)
+            with open(obj + ".hash", "w") as fh:
+                fh.write(fp + "\n")
+            if verbose:
+                print("[ddmpc build]   %s done" % os.path.basename(obj), flush=True)
+
         with ThreadPoolExecutor(max_workers=jobs) as ex:
-            list(ex.map(lambda t: _compile(*t), todo))
-    objs = [o for _, o in tasks]
+            list(ex.map(run, todo))
+    objs = [t[1] for t in tasks]
     if todo or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(o) for o in objs):
         _compile([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs, LIB_PATH)
         if verbose:
