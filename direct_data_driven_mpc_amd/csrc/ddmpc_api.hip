@@ -21,7 +21,7 @@ namespace ddmpc {
 #define DDMPC_INSTANCE(NT, W)                                                                        \
   extern template __global__ void ddmpc_cold_solve_kernel<NT, W>(                                    \
       KParams, const double*, const double*, const double*, const double*, double*, double*, int*,  \
-      int*, double*, signed char*, unsigned long long*, double*);
+      int*, double*, signed char*, unsigned long long*, double*, const int*);
 #include "ddmpc_instances.inc"
 #undef DDMPC_INSTANCE
 }  // namespace ddmpc
@@ -68,7 +68,7 @@ struct DevBuf {
 };
 
 typedef void (*cold_kernel_t)(KParams, const double*, const double*, const double*, const double*, double*,
-                              double*, int*, int*, double*, signed char*, unsigned long long*, double*);
+                              double*, int*, int*, double*, signed char*, unsigned long long*, double*, const int*);
 
 struct KernelChoice {
   int NT, W;
@@ -118,7 +118,7 @@ struct ddmpc_handle {
   DevBuf d_up, d_yp, d_uopt, d_cost, d_status, d_iters, d_beta, d_act, d_out, d_stamps;
   DevBuf d_pl, d_x, d_w, d_usys, d_ysys, d_stacc;
   // warm path: per-instance affine law (ddmpc_prepare)
-  DevBuf d_lfac, d_lfacT, d_gain, d_prep_status, d_zero;
+  DevBuf d_lfac, d_lfacT, d_gain, d_prep_status, d_zero, d_need;
   bool prepared = false;
   int closed_loop_path = DDMPC_PATH_AUTO;
   bool stamps_on = false;
@@ -431,7 +431,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need};
   for (DevBuf* b : bufs) b->release();
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -482,21 +482,25 @@ int ddmpc_set_data(ddmpc_handle* h, const double* u_d, const double* y_d, int me
 }
 
 static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
-                       int32_t* status, int32_t* iters, double* lfac = nullptr) {
+                       int32_t* status, int32_t* iters, double* lfac = nullptr, const int* only = nullptr,
+                       const KParams* kp_override = nullptr) {
   int rc;
   if ((rc = h->d_beta.ensure((size_t)h->batch * h->kp.rE * sizeof(double)))) return rc;
   if ((rc = h->d_act.ensure((size_t)h->batch * h->kp.rE))) return rc;
   dim3 grid((unsigned)h->batch), block(64 * h->kc.W);
-  hipLaunchKernelGGL(h->kc.fn, grid, block, h->lds_bytes, h->stream, h->kp, h->ud, h->yd, up, yp, uo, cost,
-                     (int*)status, (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p,
-                     h->stamps_on ? (unsigned long long*)h->d_stamps.p : (unsigned long long*)nullptr, lfac);
+  hipLaunchKernelGGL(h->kc.fn, grid, block, h->lds_bytes, h->stream, kp_override ? *kp_override : h->kp, h->ud, h->yd,
+                     up, yp, uo, cost, (int*)status, (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p,
+                     h->stamps_on ? (unsigned long long*)h->d_stamps.p : (unsigned long long*)nullptr, lfac, only);
   HIP_TRY(hipGetLastError());
   return DDMPC_OK;
 }
 
 static bool warm_capable(const ddmpc_handle* h) {
-  // the affine law exists when the QP has no inequality: nominal, or robust with slack NONE
-  return !h->kp.convex;
+  // Without an inequality (nominal, robust with slack NONE) the solution is an affine law.  With the slack
+  // box the same law is the first active-set iterate: optimal for every instance it keeps inside the box,
+  // the others are re-solved cold.
+  (void)h;
+  return true;
 }
 
 static int launch_warm(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
@@ -506,10 +510,17 @@ static int launch_warm(ddmpc_handle* h, const double* up, const double* yp, doub
   if ((rc = h->d_act.ensure((size_t)h->batch * h->kp.rE))) return rc;
   const int nf = h->prm.n * h->kp.nch;
   const unsigned threads = (unsigned)(((h->kp.r + 63) / 64) * 64 > 1024 ? 1024 : ((h->kp.r + 63) / 64) * 64);
+  int* need = nullptr;
+  if (h->kp.convex) {
+    if ((rc = h->d_need.ensure((size_t)h->batch * sizeof(int)))) return rc;
+    need = (int*)h->d_need.p;
+  }
   hipLaunchKernelGGL(ddmpc_warm_step_kernel, dim3((unsigned)h->batch), dim3(threads), 0, h->stream, h->kp,
                      16 * h->kc.NT, nf, (const double*)h->d_gain.p, (const int*)h->d_prep_status.p, up, yp, uo, cost,
-                     (int*)status, (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p);
+                     (int*)status, (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, need);
   HIP_TRY(hipGetLastError());
+  if (need)       // instances with an active slack bound: full active-set solve, same launch geometry, others exit at once
+    return launch_cold(h, up, yp, uo, cost, status, iters, nullptr, need);
   return DDMPC_OK;
 }
 
@@ -572,7 +583,6 @@ int ddmpc_prepare(ddmpc_handle* h) {
   if (!h->have_data) return fail(DDMPC_ERR_NOT_READY, "ddmpc_set_data must be called before ddmpc_prepare");
   if (h->batch > 0x7fffffffLL) return fail(DDMPC_ERR_INVALID, "batch too large for one launch");
   if (h->prepared) return DDMPC_OK;
-  if (!warm_capable(h)) return DDMPC_OK;          // slack CONVEX: every step is a cold solve
   HIP_TRY(hipSetDevice(h->device));
   const ddmpc_params& p = h->prm;
   const KParams& k = h->kp;
@@ -588,8 +598,10 @@ int ddmpc_prepare(ddmpc_handle* h) {
   HIP_TRY(hipMemsetAsync(h->d_zero.p, 0, B * nf * sizeof(double), h->stream));
   const double* z = (const double*)h->d_zero.p;
   // one cold factorisation with the factor exported (its solution for a zero past window is discarded)
+  KParams k0 = h->kp;                              // slack box: factor of the EMPTY active set (one iteration)
+  k0.convex = 0;
   if ((rc = launch_cold(h, z, z + B * p.n * p.m, (double*)h->d_uopt.p, (double*)h->d_cost.p,
-                        (int32_t*)h->d_prep_status.p, nullptr, (double*)h->d_lfac.p)))
+                        (int32_t*)h->d_prep_status.p, nullptr, (double*)h->d_lfac.p, nullptr, &k0)))
     return rc;
   const size_t ntiles = B * (size_t)(NT * (NT + 1) / 2);
   if (ntiles > 0x7fffffffULL) return fail(DDMPC_ERR_INVALID, "batch too large for ddmpc_prepare");
@@ -620,7 +632,6 @@ int ddmpc_step(ddmpc_handle* h, const double* u_past, const double* y_past, doub
                int32_t* status, int32_t* iters, int mem) {
   if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
   if (!h->have_data) return fail(DDMPC_ERR_NOT_READY, "ddmpc_set_data must be called before ddmpc_step");
-  if (!warm_capable(h)) return solve_impl(h, u_past, y_past, u_opt, cost, status, iters, mem, &launch_cold_plain);
   if (!h->prepared) {
     int rc = ddmpc_prepare(h);
     if (rc) return rc;
@@ -630,7 +641,6 @@ int ddmpc_step(ddmpc_handle* h, const double* u_past, const double* y_past, doub
 
 int ddmpc_get_gain(ddmpc_handle* h, double* out, int mem) {
   if (!h || !out) return fail(DDMPC_ERR_INVALID, "null argument");
-  if (!warm_capable(h)) return fail(DDMPC_ERR_UNSUPPORTED, "no affine control law with the CONVEX slack box");
   if (!h->prepared) return fail(DDMPC_ERR_NOT_READY, "ddmpc_prepare must be called before ddmpc_get_gain");
   HIP_TRY(hipSetDevice(h->device));
   const size_t bytes = (size_t)h->batch * (h->prm.n * h->kp.nch + 1) * h->kp.r * sizeof(double);
@@ -646,8 +656,6 @@ int ddmpc_set_option(ddmpc_handle* h, int option, int value) {
     case DDMPC_OPT_CLOSED_LOOP_PATH:
       if (value != DDMPC_PATH_AUTO && value != DDMPC_PATH_COLD && value != DDMPC_PATH_WARM)
         return fail(DDMPC_ERR_INVALID, "closed-loop path must be DDMPC_PATH_AUTO, _COLD or _WARM");
-      if (value == DDMPC_PATH_WARM && !warm_capable(h))
-        return fail(DDMPC_ERR_UNSUPPORTED, "no warm path with the CONVEX slack box");
       h->closed_loop_path = value;
       return DDMPC_OK;
     default: return fail(DDMPC_ERR_INVALID, "unknown option %d", option);
@@ -815,8 +823,11 @@ int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps
     dx = (double*)h->d_x.p; dup = (double*)h->d_up.p; dyp = (double*)h->d_yp.p; dw = (const double*)h->d_w.p;
     dus = (double*)h->d_usys.p; dys = (double*)h->d_ysys.p;
   }
-  const bool warm = warm_capable(h) && h->closed_loop_path != DDMPC_PATH_COLD &&
-                    (size_t)n_mpc_step * m <= (size_t)WARM_MAX_NF && n * h->kp.nch <= WARM_MAX_NF;
+  const bool warm_ok = warm_capable(h) && h->closed_loop_path != DDMPC_PATH_COLD &&
+                       (size_t)n_mpc_step * m <= (size_t)WARM_MAX_NF && n * h->kp.nch <= WARM_MAX_NF;
+  const bool warm = warm_ok && !h->kp.convex;        // no inequality: fused loop, one launch
+  const bool warm_box = warm_ok && h->kp.convex;     // slack box: per step, affine iterate + cold re-solve where a bound is active
+  if (warm_box && (rc = ddmpc_prepare(h))) return rc;
   if (warm) {
     // affine control law: the whole loop of an instance runs inside one workgroup
     if ((rc = ddmpc_prepare(h))) return rc;
@@ -830,8 +841,9 @@ int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps
   }
   const unsigned pblocks = (unsigned)((B + 127) / 128);
   for (int t = 0; !warm && t < n_steps; t += n_mpc_step) {
-    if ((rc = launch_cold(h, dup, dyp, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int32_t*)h->d_status.p, nullptr)))
-      return rc;
+    rc = warm_box ? launch_warm(h, dup, dyp, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int32_t*)h->d_status.p, nullptr)
+                  : launch_cold(h, dup, dyp, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int32_t*)h->d_status.p, nullptr);
+    if (rc) return rc;
     const int nsub = (t + n_mpc_step <= n_steps) ? n_mpc_step : n_steps - t;
     hipLaunchKernelGGL(ddmpc_plant_kernel, dim3(pblocks), dim3(128), 0, h->stream, (long long)B, ns, m, pp, n,
                        p.L * m, (const double*)h->d_pl.p, t, nsub, n_steps, (const double*)h->d_uopt.p,

@@ -313,10 +313,12 @@ __global__ void ddmpc_warm_step_kernel(KParams P, int RPs, int nf, const double*
                                        const int* __restrict__ prep_status, const double* __restrict__ u_past,
                                        const double* __restrict__ y_past, double* __restrict__ u_opt,
                                        double* __restrict__ cost, int* __restrict__ status, int* __restrict__ iters,
-                                       double* __restrict__ beta_ws, signed char* __restrict__ act_ws) {
+                                       double* __restrict__ beta_ws, signed char* __restrict__ act_ws,
+                                       int* __restrict__ need_cold) {
   __shared__ double pv[WARM_MAX_NF];
   __shared__ double red[32];
   __shared__ double bsh[WARM_MAX_R];
+  __shared__ int viol;
   const long long b = blockIdx.x;
   const int tid = threadIdx.x, r = P.r, nrhs = nf + 1;
   const int nyp = nf - P.npu;
@@ -331,7 +333,21 @@ __global__ void ddmpc_warm_step_kernel(KParams P, int RPs, int nf, const double*
     for (int f = 0; f < nf; ++f) beta += pv[f] * g[(long long)(1 + f) * r + rho];
     bsh[rho] = beta;
   }
+  if (tid == 0) viol = 0;
   __syncthreads();
+  if (need_cold != nullptr) {
+    // slack box (controller.py:659,674): the affine law is the first primal-dual active-set iterate (empty
+    // active set).  It is optimal iff no boxed sigma leaves the box; otherwise the instance is handed to
+    // the cold kernel, which runs the full active-set iteration.
+    const double scale = -P.lam / P.lamb_sigma;
+    for (int rho = tid; rho < r; rho += blockDim.x) {
+      const int kind = P.tabi[0 * RPs + rho];
+      if ((kind == K_WPRED || kind == K_WTERM) && fabs(scale * bsh[rho]) > P.bound) viol = 1;
+    }
+    __syncthreads();
+    if (tid == 0) need_cold[b] = viol;
+    if (viol) return;                                 // uniform: the cold kernel produces this instance's outputs
+  }
   for (int rho = tid; rho < r; rho += blockDim.x) {
     const double beta = bsh[rho];
     double z;

@@ -4,5 +4,5 @@
 namespace ddmpc {
 template __global__ void ddmpc_cold_solve_kernel<DDMPC_INST_NT, DDMPC_INST_W>(
     KParams, const double*, const double*, const double*, const double*, double*, double*, int*, int*,
-    double*, signed char*, unsigned long long*, double*);
+    double*, signed char*, unsigned long long*, double*, const int*);
 }

@@ -823,9 +823,12 @@ __global__ __launch_bounds__(64 * W, DDMPC_MIN_WAVES(NT, W)) void ddmpc_cold_sol
     const double* __restrict__ u_past, const double* __restrict__ y_past, double* __restrict__ u_opt,
     double* __restrict__ cost, int* __restrict__ status, int* __restrict__ iters,
     double* __restrict__ beta_ws, signed char* __restrict__ act_ws, unsigned long long* __restrict__ stamps,
-    double* __restrict__ lfac) {
+    double* __restrict__ lfac, const int* __restrict__ only) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const long long b = blockIdx.x;
+  // optional instance filter (ddmpc_step with the slack box: only the instances whose warm step found
+  // an active bound are solved cold); uniform per workgroup
+  if (only != nullptr && only[b] == 0) return;
   const int tid = threadIdx.x;
   constexpr int NTHR = 64 * W;
   unsigned long long* st = stamps ? stamps + b * 16 : nullptr;

@@ -158,7 +158,8 @@ class BatchedDDMPC:
         """One QP solve per instance.  Returns (u_opt, cost, status, iters).
 
         warm=False: cold solve (Hankel -> Gram -> KKT -> Cholesky -> solve), `ddmpc_solve`.
-        warm=True : `ddmpc_step`, the affine law prepared once per data set (cold solve with slack CONVEX)."""
+        warm=True : `ddmpc_step`, the affine law prepared once per data set; with slack CONVEX the instances
+                    whose affine iterate leaves the slack box are re-solved cold inside the same call."""
         B = self.batch
         dev = _is_torch(u_past)
         if u_opt is None:
@@ -193,7 +194,7 @@ class BatchedDDMPC:
         return u_opt, cost, status, iters
 
     def prepare(self) -> None:
-        """Factor once per data set and form the affine law used by `step` (no-op with slack CONVEX)."""
+        """Factor once per data set and form the affine law used by `step`."""
         if "data" in self._keep and self._keep["data"][0] is not None and _is_torch(self._keep["data"][0]):
             self._use_torch_stream()
         L.check(self._lib.ddmpc_prepare(self._h))

@@ -82,7 +82,7 @@ extern "C" {
 
 /* ddmpc_set_option */
 #define DDMPC_OPT_CLOSED_LOOP_PATH 1
-#define DDMPC_PATH_AUTO 0           /* warm (affine law) when the QP has no inequality, else cold */
+#define DDMPC_PATH_AUTO 0           /* warm: fused loop without inequality; per-step warm + cold re-solves with the slack box */
 #define DDMPC_PATH_COLD 1           /* a full cold solve per control step                         */
 #define DDMPC_PATH_WARM 2
 
@@ -147,12 +147,15 @@ int ddmpc_solve(ddmpc_handle* h, const double* u_past, const double* y_past,
  * [u_past; y_past].
  *
  * ddmpc_prepare: one cold factorisation per instance with the Cholesky factor exported, then
- *   nf+1 = n*(m+p)+1 triangular solves per instance give the affine law
+ *   nf = n*(m+p) triangular solves per instance give the affine law
  *   beta = gain[:,0] + gain[:,1:] [u_past; y_past].  Invalidated by ddmpc_set_data /
- *   ddmpc_set_setpoints.  With slack CONVEX it does nothing (no affine law exists).
+ *   ddmpc_set_setpoints.  With slack CONVEX the law is that of the EMPTY active set (no sigma at its
+ *   bound), i.e. the first primal-dual active-set iterate.
  * ddmpc_step: same contract and outputs as ddmpc_solve; uses the affine law (preparing on first
- *   use); with slack CONVEX it is a cold solve.  The status of a warm step is the status of the
- *   factorisation it rests on.
+ *   use).  With slack CONVEX an instance whose affine iterate keeps every boxed sigma inside
+ *   |sigma| <= c*eps_max is optimal as it is (iters = 1); the others are re-solved by the cold kernel
+ *   in the same call (full active-set iteration, iters >= 2), so the results equal ddmpc_solve's.
+ *   The status of a warm step is the status of the factorisation it rests on.
  * ddmpc_get_gain: out [batch, nf+1, r] doubles, r = (m+p)(L+n) components in the internal
  *   time-major order rho = k*(m+p) + ch (ch < m: ubar, else ybar+sigma). */
 int ddmpc_prepare(ddmpc_handle* h);

@@ -543,22 +543,35 @@ def test_warm_step_affine_law_full_batch(gpu):
     assert np.max(np.abs(z - r1[0][:, : 2 * (spec.L - 4)])) / np.max(np.abs(z)) < 1e-10
 
 
-def test_warm_step_with_slack_box_is_a_cold_solve(gpu):
-    # slack CONVEX has an inequality: no affine law; ddmpc_step must give exactly the cold result
+def test_warm_step_with_slack_box(gpu):
+    # slack CONVEX: the affine law is the first active-set iterate; instances it keeps inside the box are
+    # final (iters 1), the rest are re-solved cold inside the same ddmpc_step call -> same results as ddmpc_solve
     spec = orc.spec_from_params(slack_var_constraint_type=1)
-    B = 8
+    B = 64
     u_d, y_d, up, yp = _instances(B, seed0=5)
+    rng = np.random.default_rng(2)
     with _engine(spec, 400, B) as eng:
         eng.set_data(u_d, y_d)
-        eng.prepare()                                           # no-op
-        uw, cw, sw, iw = eng.step(up, yp); uw = uw.copy(); iw = iw.copy()
-        uc, cc, sc, ic = eng.solve(up, yp)
-        assert np.array_equal(uw, uc) and np.array_equal(iw, ic) and np.max(ic) >= 2
-        with pytest.raises(L.DDMPCError):
-            eng.gain()
-        with pytest.raises(L.DDMPCError):
-            eng.set_closed_loop_path("warm")
-    _check(spec, u_d, y_d, up, yp, uw, cw, sw, range(B))
+        eng.prepare()
+        seen = set()
+        for trial in range(3):
+            if trial == 1:      # windows near the setpoint: the box is mostly inactive
+                up = np.tile(spec.u_s, 4)[None] + 0.01 * rng.uniform(-1, 1, up.shape)
+                yp = np.tile(spec.y_s, 4)[None] + 0.002 * rng.uniform(-1, 1, yp.shape)
+            if trial == 2:
+                up = rng.uniform(-1.0, 1.0, up.shape); yp = rng.uniform(0.0, 1.0, yp.shape)
+            uw, cw, sw, iw = (x.copy() for x in eng.step(up, yp))
+            sg = eng.get_solution("sigma")
+            uc, cc, sc, ic = eng.solve(up, yp)
+            assert np.array_equal(iw, ic) and np.array_equal(sw, sc)
+            assert np.max(np.abs(uw - uc)) / np.max(np.abs(uc)) < 1e-10 and np.max(np.abs(cw - cc) / np.abs(cc)) < 1e-10
+            assert np.max(np.abs(sg[:, 8:])) <= spec.c * spec.eps_max * (1 + 1e-12)
+            _check(spec, u_d, y_d, up, yp, uw, cw, sw, range(0, B, 7))
+            seen |= set(int(i) for i in iw)
+        assert 1 in seen and max(seen) >= 2                     # both the warm-only and the re-solved branch ran
+        g = eng.gain()                                          # the law of the empty active set
+        assert g.shape == (B, 17, 136)
+        eng.set_closed_loop_path("warm")
 
 
 def test_warm_path_invalidation_and_bad_instance(gpu):
@@ -586,8 +599,9 @@ def test_warm_path_invalidation_and_bad_instance(gpu):
     assert L.STATUS_STRINGS[int(status[2])] == "solver_error" and [int(s) for s in status[[0, 1, 3]]] == [0, 0, 0]
 
 
-@pytest.mark.parametrize("kw,n_mpc_step", [(dict(), 1), (dict(), 4), (dict(tec=False), 1), (dict(controller_type=0), 2)],
-                         ids=["tec-1step", "tec-nstep4", "ucon-1step", "nominal-2step"])
+@pytest.mark.parametrize("kw,n_mpc_step", [(dict(), 1), (dict(), 4), (dict(tec=False), 1), (dict(controller_type=0), 2),
+                                           (dict(slack_var_constraint_type=1), 1), (dict(slack_var_constraint_type=1), 3)],
+                         ids=["tec-1step", "tec-nstep4", "ucon-1step", "nominal-2step", "convex-1step", "convex-3step"])
 def test_closed_loop_warm_and_cold_paths_agree(gpu, kw, n_mpc_step):
     # the fused one-workgroup-per-instance loop (affine law) vs one cold solve per control step
     spec = orc.spec_from_params(**kw)
