@@ -775,3 +775,60 @@ def test_long_data_trajectory(gpu):
     # a trajectory that cannot be staged in LDS is refused at create time, not at launch
     with pytest.raises(L.DDMPCError, match="LDS"):
         _engine(orc.spec_from_params(N=6000), 6000, 1)
+
+
+# ------------------------------------------------------------- randomized systems
+def _random_plant(rng, ns, m, p, eps):
+    A = rng.normal(size=(ns, ns))
+    A *= 0.85 / max(abs(np.linalg.eigvals(A)))                      # stable, spectral radius 0.85
+    return dict(A=A, B=rng.normal(size=(ns, m)), C=rng.normal(size=(p, ns)), D=np.zeros((p, m)), eps_max=eps)
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_systems_against_oracle(gpu, case):
+    # seeded sweep over plant sizes (m + p != 4 takes the dense-MFMA Gram), horizons that land on every kernel
+    # instance, both schemes, all slack / terminal-constraint modes and scalar / diagonal / dense weights
+    rng = np.random.default_rng(1000 + case)
+    m, p = [(1, 1), (2, 1), (1, 2), (2, 2), (3, 2), (2, 3)][case % 6]
+    ns = int(rng.integers(2, 5))
+    n = ns
+    robust = case % 4 != 3
+    Lh = int(rng.integers(2 * n, 2 * n + 9))
+    if (m + p) * (Lh + n) > 200:
+        Lh = max(2 * n, 200 // (m + p) - n)
+    # comfortably above N_min of controller.py:275: with barely enough columns H is nearly rank-deficient
+    # (cond(H) ~ 5e5 was seen) and the Gram formulation, which squares it, drops to ~3e-9 in the cost
+    N = (m + 1) * (Lh + 2 * n) + int(rng.integers(80, 200))
+    eps = 0.002
+    slack = "convex" if (robust and case % 3 == 1) else "none"
+    tec = case % 5 != 4
+    wkind = case % 3 if slack == "none" else case % 2                # dense weights only without the box
+    if wkind == 0:
+        Q = 2.0 * np.eye(p * Lh); R = 0.05 * np.eye(m * Lh)
+    elif wkind == 1:
+        Q = np.diag(rng.uniform(1.0, 4.0, p * Lh)); R = np.diag(rng.uniform(0.01, 0.1, m * Lh))
+    else:
+        Q = _spd(rng, p * Lh, 2.0, 2); R = _spd(rng, m * Lh, 0.05, 2)
+    plant = _random_plant(rng, ns, m, p, eps)
+    spec = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=Q, R=R, u_s=rng.uniform(-0.5, 0.5, m), y_s=rng.uniform(-0.5, 0.5, p),
+                      robust=robust, eps_max=eps, lamb_alpha=20.0, lamb_sigma=500.0, c=1.0, slack=slack, tec=tec)
+    B = 3
+    d = generate_batch(range(case * 10, case * 10 + B), N=N, plant=plant)
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    with _engine(spec, N, B) as eng:
+        eng.set_data(d["u_d"], d["y_d"])
+        u, cost, status, iters = eng.solve(up, yp)
+        uw, cw, sw, iw = eng.step(up, yp)
+    for b in range(B):
+        sol = orc.solve_fullspace(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
+        assert L.STATUS_STRINGS[int(status[b])] == sol.status == "optimal"
+        scale = max(np.max(np.abs(sol.optimal_u)), 1e-3)
+        # Random plants have output gains of order 1-10 against a noise level of 0.002, so the y rows of H are
+        # nearly dependent on its u rows: cond(H) reaches 1e5-5e5 (four-tank data: ~1e2).  The kernels factor the
+        # Gram matrix, which squares that; the cost then agrees with the full-space oracle to ~3e-9 (GPU and numpy
+        # reduced form alike), hence 10x wider tolerances in this sweep only.
+        assert np.max(np.abs(u[b] - sol.optimal_u)) / scale < 10 * TOL_U, (case, b)
+        assert abs(cost[b] - sol.cost) <= 20 * TOL_COST * max(abs(sol.cost), 1e-6), (case, b)
+        if spec.slack == "convex":
+            assert int(iters[b]) == sol.iters
+    assert np.max(np.abs(uw - u)) <= 1e-10 * max(np.max(np.abs(u)), 1e-3) and np.array_equal(sw, status) and np.array_equal(iw, iters)
