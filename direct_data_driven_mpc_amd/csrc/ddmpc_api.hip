@@ -611,7 +611,10 @@ int ddmpc_prepare(ddmpc_handle* h) {
   bool launched = false;
 #define DDMPC_INSTANCE(NT_, W_)                                                                              \
   if (!launched && NT == NT_) {                                                                               \
-    hipLaunchKernelGGL(ddmpc_gain_kernel<NT_>, dim3((unsigned)B), dim3(256), 0, h->stream, k, 16 * NT, nf,    \
+    const size_t glds = (size_t)(2 * NT_ * 256 + 32) * sizeof(double);                                        \
+    if (glds > 64 * 1024)                                                                                     \
+      HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_gain_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds)); \
+    hipLaunchKernelGGL(ddmpc_gain_kernel<NT_>, dim3((unsigned)B), dim3(256), glds, h->stream, k, 16 * NT, nf, \
                        (const double*)h->d_lfac.p, (const double*)h->d_lfacT.p, (const double*)h->d_beta.p,  \
                        (double*)h->d_gain.p);                                                                 \
     launched = true;                                                                                          \

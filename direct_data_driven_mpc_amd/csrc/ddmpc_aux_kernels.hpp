@@ -189,15 +189,20 @@ __device__ __forceinline__ double row16_sum(double v) {
 }
 
 // Gain kernel: grid = batch, block = 256 = 4 waves x 4 groups of 16 lanes.  One group solves one
-// right-hand side e_rho(f): lane kk of the group owns the unknowns k = 16 J + kk in registers, a row's
-// dot product is <= NT multiply-adds per lane plus a 16-lane DPP sum, and the factor is read in
-// coalesced 128-byte rows (L from `lfac` going forward, L' from the tile-transposed copy going back),
-// the next row prefetched while the current one is reduced.  Column 0 of the gain (the offset
-// A^-1 t0) is the beta of the cold solve that exported the factor (zero past window).
+// right-hand side e_rho(f): lane kk of the group owns the unknowns k = 16 J + kk in registers, and a row's
+// dot product is <= NT multiply-adds per lane plus a 16-lane DPP sum.  The factor streams through LDS one
+// tile row at a time (L from `lfac` going forward, L' from the tile-transposed copy going back): the whole
+// workgroup copies the next tile row (coalesced, <= NT x 2 KB) into registers while the 16 rows of the
+// current one are processed, so HBM latency is paid once per 16 rows; the 16 reciprocal pivots of a tile
+// row are formed once, by lane.  Column 0 of the gain (the offset A^-1 t0) is the beta of the cold solve
+// that exported the factor (zero past window).
 template <int NT>
 __global__ __launch_bounds__(256) void ddmpc_gain_kernel(KParams P, int RPs, int nf, const double* __restrict__ lfac,
                                                          const double* __restrict__ lfacT,
                                                          const double* __restrict__ beta0, double* __restrict__ gain) {
+  extern __shared__ __attribute__((aligned(16))) double gsm[];      // 2 x NT x 256 (tile rows) + 2 x 16 (reciprocal pivots)
+  auto Lbuf = [&](int buf) __attribute__((always_inline)) -> double* { return gsm + buf * (NT * 256); };
+  auto rinv = [&](int buf) __attribute__((always_inline)) -> double* { return gsm + 2 * NT * 256 + buf * 16; };
   const long long b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, grp = lane >> 4, kk = lane & 15, wave = tid >> 6;
   const int r = P.r, nrhs = nf + 1;
@@ -205,6 +210,19 @@ __global__ __launch_bounds__(256) void ddmpc_gain_kernel(KParams P, int RPs, int
   const double* __restrict__ Tb = lfacT + b * (long long)(NT * (NT + 1) / 2 * 256);
   for (int rho = tid; rho < r; rho += 256) gain[(b * nrhs) * (long long)r + rho] = beta0[b * (long long)P.rE + rho];
   auto tile = [](int I, int J) { return (I * (I + 1) / 2 + J) << 8; };
+  const int ntr = (r + 15) >> 4;                      // tile rows that hold real rows
+  double stage[NT];
+  // forward: tile row I = tiles (I, 0..I), contiguous in lfac; slot J of the buffer = tile (I, J)
+  auto fetch_fwd = [&](int I) __attribute__((always_inline)) {
+    static_for<NT>([&](auto J) __attribute__((always_inline)) { if (J <= I) stage[J] = Lb[tile(I, J) + tid]; });
+  };
+  // backward: tile column Ji of the transposed copy = tiles (I2, Ji), I2 >= Ji; slot I2 of the buffer
+  auto fetch_bwd = [&](int Ji) __attribute__((always_inline)) {
+    static_for<NT>([&](auto I2) __attribute__((always_inline)) { if (I2 >= Ji && I2 < ntr) stage[I2] = Tb[tile(I2, Ji) + tid]; });
+  };
+  auto commit = [&](int buf, int lo, int hi) __attribute__((always_inline)) {      // slots lo..hi of `stage` -> LDS
+    static_for<NT>([&](auto J) __attribute__((always_inline)) { if (J >= lo && J <= hi) Lbuf(buf)[J * 256 + tid] = stage[J]; });
+  };
   for (int f0 = 0; f0 < nf; f0 += 16) {
     const int f = f0 + wave * 4 + grp;                 // this group's right-hand side (idle groups ride along)
     int rho_f = -1;
@@ -215,55 +233,59 @@ __global__ __launch_bounds__(256) void ddmpc_gain_kernel(KParams P, int RPs, int
       t = fmax(t, dpp_f64<0x122>(t)); t = fmax(t, dpp_f64<0x121>(t));
       rho_f = (int)t;
     }
-    double y[NT], cur[NT], nxt[NT];
-    static_for<NT>([&](auto J) __attribute__((always_inline)) { y[J] = 0.0; nxt[J] = 0.0; });
-    // ---- forward substitution L y = e: row i of L, tile row I = i >> 4
-    auto load_fwd = [&](int i) __attribute__((always_inline)) {
-      const int I = i >> 4, ii = i & 15;
-      static_for<NT>([&](auto J) __attribute__((always_inline)) {
-        if (J <= I) nxt[J] = Lb[tile(I, J) + ii * 16 + kk];
-      });
-    };
-    load_fwd(0);
-    for (int i = 0; i < r; ++i) {
-      const int I = i >> 4, ii = i & 15;
-      static_for<NT>([&](auto J) __attribute__((always_inline)) { cur[J] = nxt[J]; });
-      if (i + 1 < r) load_fwd(i + 1);
-      double s = 0.0, lii = 0.0;
-      static_for<NT>([&](auto J) __attribute__((always_inline)) {
-        if (J < I) s += cur[J] * y[J];
-        if (J == I) { s += (kk < ii) ? cur[J] * y[J] : 0.0; lii = (kk == ii) ? cur[J] : 0.0; }
-      });
-      s = row16_sum(s);
-      lii = row16_sum(lii);                            // only lane ii contributed
-      const double yi = ((i == rho_f ? 1.0 : 0.0) - s) / lii;
-      static_for<NT>([&](auto J) __attribute__((always_inline)) { if (J == I && kk == ii) y[J] = yi; });
+    double y[NT];
+    static_for<NT>([&](auto J) __attribute__((always_inline)) { y[J] = 0.0; });
+    // ---- forward substitution L y = e ------------------------------------------------------
+    __syncthreads();                                   // buffers free (previous pass done)
+    fetch_fwd(0);
+    commit(0, 0, 0);
+    for (int I = 0; I < ntr; ++I) {
+      const int buf = I & 1;
+      __syncthreads();                                 // tile row I visible; the other buffer is free
+      if (I + 1 < ntr) fetch_fwd(I + 1);               // in flight while this tile row is processed
+      if (wave == 0 && lane < 16) rinv(buf)[lane] = 1.0 / Lbuf(buf)[I * 256 + lane * 17];
+      __syncthreads();
+      const double* Lr = Lbuf(buf) + kk;
+      const int nrow = (r - 16 * I) < 16 ? (r - 16 * I) : 16;
+      for (int ii = 0; ii < nrow; ++ii) {
+        double s = 0.0;
+        static_for<NT>([&](auto J) __attribute__((always_inline)) {
+          if (J < I) s += Lr[J * 256 + ii * 16] * y[J];
+          if (J == I) s += (kk < ii) ? Lr[J * 256 + ii * 16] * y[J] : 0.0;
+        });
+        s = row16_sum(s);
+        const double yi = ((16 * I + ii == rho_f ? 1.0 : 0.0) - s) * rinv(buf)[ii];
+        static_for<NT>([&](auto J) __attribute__((always_inline)) { if (J == I && kk == ii) y[J] = yi; });
+      }
+      if (I + 1 < ntr) commit(buf ^ 1, 0, I + 1);
     }
-    // ---- back substitution L' x = y: x_i = (y_i - sum_{k>i} L[k][i] x_k) / L[i][i];
-    //      L[16 I2 + kk][i] = tile-transposed copy, tile (I2, i >> 4), row i & 15, entry kk
-    auto load_bwd = [&](int i) __attribute__((always_inline)) {
-      const int Ji = i >> 4, ii = i & 15;
-      static_for<NT>([&](auto I2) __attribute__((always_inline)) {
-        if (I2 >= Ji && 16 * I2 < r) nxt[I2] = Tb[tile(I2, Ji) + ii * 16 + kk];
-      });
-    };
-    load_bwd(r - 1);
-    for (int i = r - 1; i >= 0; --i) {
-      const int Ji = i >> 4, ii = i & 15;
-      static_for<NT>([&](auto J) __attribute__((always_inline)) { cur[J] = nxt[J]; });
-      if (i > 0) load_bwd(i - 1);
-      double s = 0.0, lii = 0.0;
-      static_for<NT>([&](auto I2) __attribute__((always_inline)) {
-        if (I2 >= Ji && 16 * I2 < r) {
-          const int k = 16 * I2 + kk;
-          if (k > i && k < r) s += cur[I2] * y[I2];
-          if (k == i) { s -= y[I2]; lii = cur[I2]; }   // the owner lane folds y_i into the sum: no broadcast needed
-        }
-      });
-      s = row16_sum(s);
-      lii = row16_sum(lii);
-      const double xi = -s / lii;
-      static_for<NT>([&](auto J) __attribute__((always_inline)) { if (J == Ji && kk == ii) y[J] = xi; });
+    // ---- back substitution L' x = y: x_i = (y_i - sum_{k>i} L[k][i] x_k) / L[i][i] -------------
+    __syncthreads();
+    fetch_bwd(ntr - 1);
+    commit(0, ntr - 1, ntr - 1);
+    for (int Ji = ntr - 1; Ji >= 0; --Ji) {
+      const int buf = (ntr - 1 - Ji) & 1;
+      __syncthreads();
+      if (Ji > 0) fetch_bwd(Ji - 1);
+      if (wave == 0 && lane < 16) rinv(buf)[lane] = 1.0 / Lbuf(buf)[Ji * 256 + lane * 17];
+      __syncthreads();
+      const double* Tr = Lbuf(buf) + kk;
+      const int nrow = (r - 16 * Ji) < 16 ? (r - 16 * Ji) : 16;
+      for (int ii = nrow - 1; ii >= 0; --ii) {
+        const int i = 16 * Ji + ii;
+        double s = 0.0;
+        static_for<NT>([&](auto I2) __attribute__((always_inline)) {
+          if (I2 >= Ji && I2 < ntr) {
+            const int k = 16 * I2 + kk;
+            if (k > i && k < r) s += Tr[I2 * 256 + ii * 16] * y[I2];
+            if (k == i) s -= y[I2];                    // the owner lane folds y_i into the sum: no broadcast needed
+          }
+        });
+        s = row16_sum(s);
+        const double xi = -s * rinv(buf)[ii];
+        static_for<NT>([&](auto J) __attribute__((always_inline)) { if (J == Ji && kk == ii) y[J] = xi; });
+      }
+      if (Ji > 0) commit(buf ^ 1, Ji - 1, ntr - 1);
     }
     if (f < nf) {
       double* g = gain + (b * nrhs + 1 + f) * (long long)r;
