@@ -26,9 +26,9 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 2.4 GHz x 2048 flop / 64 clk 
                                # measured 64 clk/instr/SIMD in profiles/r01_mfma_f64_probe.log
 # HBM traffic of one default launch (4096 instances, slack NONE, structured Gram) from separate
 # rocprofv3 --pmc passes of this same command (profiles/r01_final_pmc_fetch.csv / _write.csv):
-# FETCH_SIZE 28,874 KB x2 (gfx950 counts wide reads at half) + WRITE_SIZE 12,783 KB.
+# FETCH_SIZE 28,855 KB x2 (gfx950 counts wide reads at half) + WRITE_SIZE 12,803 KB.
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_TRAFFIC_BYTES_DEFAULT = (2 * 28874 + 12783) * 1024
+PMC_TRAFFIC_BYTES_DEFAULT = (2 * 28855 + 12803) * 1024
 
 
 def cpu_baseline(cfg, u_d, y_d, up, yp, u_gpu, cost_gpu, n_sample):
@@ -74,7 +74,17 @@ def cpu_baseline(cfg, u_d, y_d, up, yp, u_gpu, cost_gpu, n_sample):
         red_t = run_reduced()
     eu = max(np.max(np.abs(u_gpu[b] - s.optimal_u)) / np.max(np.abs(s.optimal_u)) for b, s in enumerate(sols))
     ec = max(abs(cost_gpu[b] - s.cost) / abs(s.cost) for b, s in enumerate(sols))
-    return dict(value=n_sample / run_t, unit="QP solves/s", cores=cores, kind="port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return dict(value=n_sample / run_t, unit="QP solves/s", cores=cores, kind="port", cpu_model=cpu_model,
+                host_cpus=os.cpu_count(),
                 sample="%d cold solves (first %d instances of the batch), full-space dense KKT in numpy/LAPACK, "
                        "%.1f s" % (n_sample, n_sample, run_t),
                 reduced_form_value=n_red / red_t,
