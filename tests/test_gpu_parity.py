@@ -832,3 +832,30 @@ def test_random_systems_against_oracle(gpu, case):
         if spec.slack == "convex":
             assert int(iters[b]) == sol.iters
     assert np.max(np.abs(uw - u)) <= 1e-10 * max(np.max(np.abs(u)), 1e-3) and np.array_equal(sw, status) and np.array_equal(iw, iters)
+
+
+def test_noise_free_data(gpu):
+    # Exact LTI data: H has rank m(L+n) + n_sys = 72 of 136, the Gram matrix is singular.
+    # Robust scheme: G + lam*D stays positive definite (D > 0 on every y component, the hard u rows are
+    # independent for persistently exciting inputs) -> same parity as with noisy data.
+    # Nominal scheme: needs a rank-revealing solve the engine does not have -> every instance must come back
+    # "solver_error", never a silently wrong "optimal" (DESIGN.md section 9).
+    from direct_data_driven_mpc_amd.harness import FOUR_TANK
+    plant = dict(FOUR_TANK); plant["eps_max"] = 0.0
+    B = 6
+    d = generate_batch(range(B), N=400, plant=plant)
+    up = d["u_d"][:, -4:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -4:, :].reshape(B, -1).copy()
+    for kw in (dict(), dict(slack_var_constraint_type=1)):
+        spec = orc.spec_from_params(**kw)
+        with _engine(spec, 400, B) as eng:
+            eng.set_data(d["u_d"], d["y_d"])
+            u, cost, status, _ = eng.solve(up, yp)
+            uw, cw, sw, _ = eng.step(up, yp)
+        _check(spec, d["u_d"], d["y_d"], up, yp, u, cost, status, range(B))
+        assert np.max(np.abs(uw - u)) / np.max(np.abs(u)) < 1e-9
+    spec = orc.spec_from_params(controller_type=0)
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(d["u_d"], d["y_d"])
+        u, cost, status, _ = eng.solve(up, yp)
+        uw, cw, sw, _ = eng.step(up, yp)
+    assert all(L.STATUS_STRINGS[int(s)] == "solver_error" for s in status) and np.array_equal(sw, status)
