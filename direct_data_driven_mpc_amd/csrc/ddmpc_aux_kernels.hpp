@@ -351,8 +351,18 @@ __global__ void ddmpc_warm_step_kernel(KParams P, int RPs, int nf, const double*
   bool finite = true;
   const double* g = gain + b * (long long)nrhs * r;
   for (int rho = tid; rho < r; rho += blockDim.x) {
+    // all loads of a chunk of 8 columns are issued before they are consumed (HBM-bound kernel: keep bytes in flight)
     double beta = g[rho];
-    for (int f = 0; f < nf; ++f) beta += pv[f] * g[(long long)(1 + f) * r + rho];
+    const double* gc = g + r + rho;
+    int f = 0;
+    for (; f + 8 <= nf; f += 8) {
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = __builtin_nontemporal_load(gc + (long long)(f + q) * r);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) beta += pv[f + q] * v[q];
+    }
+    for (; f < nf; ++f) beta += pv[f] * gc[(long long)f * r];
     bsh[rho] = beta;
   }
   if (tid == 0) viol = 0;
