@@ -6,14 +6,15 @@
 //   trajectory (u_d,y_d) --coalesced--> LDS  (channel-interleaved "xflat")
 //   G = H H'   : never materialises H.  H[rho][i] = xflat[i*nch + rho], so
 //                * structured mode (nch == 4): G(k,l) depends on (k-l, l) only through a
-//                  sliding-window recurrence; base sums C_d = G(d,0) by VALU, then every
-//                  wave walks its own tile diagonals in registers (no barriers);
+//                  sliding-window recurrence; lag blocks C_d = G(d,0) by v_mfma_f64_4x4x4, then every
+//                  wave walks its own tile diagonals in registers with 2 MFMAs per tile (no barriers);
 //                * dense mode: fp64 MFMA (v_mfma_f64_16x16x4_f64) over the implicit operand.
-//   K = G + lam*D, rhs t: diagonal / extra-row fix-up in registers
+//   K = G + lam*D, rhs t: diagonal / extra-row fix-up in registers (dense weights: lam*W^-1 from L2)
 //   K = L L'   : right-looking blocked Cholesky on register tiles (MFMA accumulators),
-//                4-wide panels through LDS, rank-4 trailing updates by MFMA, ONE barrier/step
+//                4-wide panels through LDS, rank-4 trailing updates by MFMA, two barriers per step
 //   L y = t    : free -- t rides along as an extra matrix row
-//   L' beta = y: column-oriented back substitution, 4 rows per step, ONE barrier/step
+//   L' beta = y: back substitution per 16-row tile row: diagonal tile in registers, the tiles left of it
+//                by MFMA with the accumulator registers as operand
 //   slack box  : primal-dual active set around the above (CONVEX only)
 //   outputs    : optimal_u, cost, status (+ beta / active-set workspace)
 //
@@ -136,8 +137,7 @@ struct Lds {
   static constexpr int tvec = dvec + RP;
   static constexpr int beta = tvec + RP;
   static constexpr int msave = beta + RP;              // per step: i0..i3, m10, m20, m21, m30, m31, m32 (12 slots)
-  static constexpr int yc = msave + 3 * RP;            // 2 x 4
-  static constexpr int red = yc + 8;                   // 32
+  static constexpr int red = msave + 3 * RP;           // 32
   static constexpr int ints = red + 32;                // int act[RP], int flags[8]
   static constexpr int U = (ints + (RP + 8 + 1) / 2 + 2) & ~1;
   static constexpr int RS = RP + 4;                    // row stride of PT/LT: +4 doubles spreads the 4 k-rows over the banks
@@ -177,7 +177,6 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
   double* tvec = sm + LD::tvec;
   double* beta = sm + LD::beta;
   double* msave = sm + LD::msave;
-  double* yc = sm + LD::yc;
   double* red = sm + LD::red;
   double* ctab = sm + LD::ctab;
   int* act = reinterpret_cast<int*>(sm + LD::ints);
