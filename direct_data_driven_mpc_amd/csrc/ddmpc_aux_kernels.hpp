@@ -358,7 +358,7 @@ __global__ void ddmpc_warm_step_kernel(KParams P, int RPs, int nf, const double*
     for (; f + 8 <= nf; f += 8) {
       double v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = __builtin_nontemporal_load(gc + (long long)(f + q) * r);
+      for (int q = 0; q < 8; ++q) v[q] = gc[(long long)(f + q) * r];
 #pragma unroll
       for (int q = 0; q < 8; ++q) beta += pv[f + q] * v[q];
     }
