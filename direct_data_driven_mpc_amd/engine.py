@@ -210,6 +210,10 @@ class BatchedDDMPC:
         L.check(self._lib.ddmpc_get_gain(self._h, C.c_void_p(out.ctypes.data), L.MEM_HOST))
         return out
 
+    def set_closed_loop_graph(self, on: bool) -> None:
+        """Record the per-step launches of `closed_loop` into one HIP graph and replay it (default off)."""
+        L.check(self._lib.ddmpc_set_option(self._h, L.OPT_CLOSED_LOOP_GRAPH, 1 if on else 0))
+
     def set_closed_loop_path(self, path: str) -> None:
         """'auto' | 'cold' | 'warm' (DDMPC_OPT_CLOSED_LOOP_PATH)."""
         L.check(self._lib.ddmpc_set_option(self._h, L.OPT_CLOSED_LOOP_PATH, {"auto": 0, "cold": 1, "warm": 2}[path]))

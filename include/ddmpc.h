@@ -85,6 +85,8 @@ extern "C" {
 #define DDMPC_PATH_AUTO 0           /* warm: fused loop without inequality; per-step warm + cold re-solves with the slack box */
 #define DDMPC_PATH_COLD 1           /* a full cold solve per control step                         */
 #define DDMPC_PATH_WARM 2
+#define DDMPC_OPT_CLOSED_LOOP_GRAPH 2 /* 1: record the per-step launches of ddmpc_closed_loop into a HIP graph and replay it
+                                         (default 0: measured slower than plain asynchronous launches) */
 
 typedef struct ddmpc_handle ddmpc_handle;
 

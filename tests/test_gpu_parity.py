@@ -859,3 +859,25 @@ def test_noise_free_data(gpu):
         u, cost, status, _ = eng.solve(up, yp)
         uw, cw, sw, _ = eng.step(up, yp)
     assert all(L.STATUS_STRINGS[int(s)] == "solver_error" for s in status) and np.array_equal(sw, status)
+
+
+def test_closed_loop_graph_replay_matches_direct_launches(gpu):
+    # the per-step paths (slack box: warm + filtered cold + plant; forced cold: cold + plant) are recorded into a
+    # HIP graph and replayed; results must be identical to launching the same kernels one by one
+    B, n_steps = 32, 45
+    d = generate_batch(range(200, 200 + B))
+    w = 0.002 * np.random.default_rng(4).uniform(-1.0, 1.0, (B, n_steps, 2))
+    up = d["u_d"][:, -4:, :].reshape(B, -1); yp = d["y_d"][:, -4:, :].reshape(B, -1)
+    P = orc.FOUR_TANK
+    for kw, path in ((dict(slack_var_constraint_type=1), "auto"), (dict(), "cold")):
+        spec = orc.spec_from_params(**kw)
+        out = {}
+        with _engine(spec, 400, B) as eng:
+            eng.set_data(d["u_d"], d["y_d"])
+            eng.set_closed_loop_path(path)
+            for graph in (True, False):
+                eng.set_closed_loop_graph(graph)
+                out[graph] = eng.closed_loop(P["A"], P["B"], P["C"], P["D"], d["x_end"], up, yp, w, n_mpc_step=2)
+        for a, b in zip(out[True], out[False]):
+            assert np.array_equal(a, b)
+        assert np.all(out[True][2] == 0)
