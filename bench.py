@@ -26,9 +26,9 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 2.4 GHz x 2048 flop / 64 clk 
                                # measured 64 clk/instr/SIMD in profiles/r01_mfma_f64_probe.log
 # HBM traffic of one default launch (4096 instances, slack NONE, structured Gram) from separate
 # rocprofv3 --pmc passes of this same command (profiles/r01_final_pmc_fetch.csv / _write.csv):
-# FETCH_SIZE 28,866 KB x2 (gfx950 counts wide reads at half) + WRITE_SIZE 12,957 KB.
+# FETCH_SIZE 28,911 KB x2 (gfx950 counts wide reads at half) + WRITE_SIZE 13,050 KB.
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_TRAFFIC_BYTES_DEFAULT = (2 * 28866 + 12957) * 1024
+PMC_TRAFFIC_BYTES_DEFAULT = (2 * 28911 + 13050) * 1024
 
 
 def cpu_baseline(cfg, u_d, y_d, up, yp, u_gpu, cost_gpu, n_sample):

@@ -278,63 +278,66 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
       // i.e. one rank-4 downdate and one rank-4 update = 2 MFMAs (the Hankel sliding-window
       // recurrence in matrix form).  Only the first tile of each diagonal needs the full sum.
       const int c = P.c, Ln = P.Ln;
-      // (explicit definition of every tile: keeps the previous active-set iteration's values from
-      //  being considered live across the loop back-edge)
-      static_for<TM::MAXS>([&](auto S) __attribute__((always_inline)) { acc[S] = d4{0.0, 0.0, 0.0, 0.0}; });
       // (1) lag blocks C_d(a,b) = sum_{t<c} x_a[t+d] x_b[t] (= G(d,0)) by v_mfma_f64_4x4x4_4b: one
       //     instruction does 4 lags x 4 time steps with no wasted outputs (17 clk vs 64 for a
       //     16x16x4).  Lane layout (probed, tools/mfma_f64_4x4_probe.hip): A_blk[i][k] at lane
       //     (k<<4 | blk<<2 | i), B_blk[k][j] at (k<<4 | blk<<2 | j), D_blk[i][j] at (i<<4 | blk<<2 | j).
       {
-        constexpr int MAXG = (NT + W - 1) / W;             // lag groups (4 lags each) per wave
+        // Wave w takes the MAXG CONSECUTIVE lag groups g = w*MAXG + gi (4 lags each).  The A operand of
+        // group g at k-step u is x[.. + 16 (g + u)]: it depends on g + u only, so one trip of 4 k-steps needs
+        // MAXG + 3 A loads instead of 4 MAXG (this phase is bound by the LDS pipe, not by the MFMAs), and a
+        // wave whose groups all lie past the last lag skips the phase.
+        constexpr int MAXG = (NT + W - 1) / W;             // lag groups per wave
         const int ngroups = (Ln + 3) >> 2;
         const int kq = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
-        double cacc[MAXG];
-        static_for<MAXG>([&](auto gi) __attribute__((always_inline)) { cacc[gi()] = 0.0; });
-        const double* pB = xs + 4 * kq + ij;               // B[k][j] = x_j[t0 + k]
-        const double* pA = xs + 4 * (kq + blk) + ij;       // A[i][k] = x_i[t0 + k + 4g + blk]
-        const int cfull = c & ~3;
-        // Groups past the last lag (4g >= Ln) just compute unused lags: no branches in the loop
-        // (reads stay inside the zero-padded trajectory region).
-        int t0 = 0;
-        for (; t0 + 16 <= cfull; t0 += 16) {               // 4 k-steps per trip: all loads first, then the MFMAs
-          double bv[4], av[MAXG][4];
-          static_for<4>([&](auto u) __attribute__((always_inline)) {
-            bv[u()] = pB[16 * u];
-            static_for<MAXG>([&](auto gi) __attribute__((always_inline)) { av[gi()][u()] = pA[16 * (WAVE + gi * W) + 16 * u]; });
-          });
-          static_for<4>([&](auto u) __attribute__((always_inline)) {
-            static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
-              cacc[gi()] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[gi()][u()], bv[u()], cacc[gi()], 0, 0, 0);
+        if (WAVE * MAXG < ngroups) {
+          double cacc[MAXG];
+          static_for<MAXG>([&](auto gi) __attribute__((always_inline)) { cacc[gi()] = 0.0; });
+          const double* pB = xs + 4 * kq + ij;                                   // B[k][j] = x_j[t0 + k]
+          const double* pA = xs + 4 * (kq + blk) + ij + 16 * (WAVE * MAXG);      // A[i][k] = x_i[t0 + k + 4g + blk]
+          const int cfull = c & ~3;
+          // Groups past the last lag (4g >= Ln) just compute unused lags: no branches in the loop
+          // (reads stay inside the zero-padded trajectory region).
+          int t0 = 0;
+          for (; t0 + 16 <= cfull; t0 += 16) {             // 4 k-steps per trip: all loads first, then the MFMAs
+            double bv[4], av[MAXG + 3];
+            static_for<4>([&](auto u) __attribute__((always_inline)) { bv[u()] = pB[16 * u]; });
+            static_for<MAXG + 3>([&](auto q) __attribute__((always_inline)) { av[q()] = pA[16 * q]; });
+            static_for<4>([&](auto u) __attribute__((always_inline)) {
+              static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
+                cacc[gi()] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[gi() + u()], bv[u()], cacc[gi()], 0, 0, 0);
+              });
             });
-          });
-          pA += 64; pB += 64;
-        }
-        for (; t0 < cfull; t0 += 4) {
-          const double bv = pB[0];
-          double av[MAXG];
-          static_for<MAXG>([&](auto gi) __attribute__((always_inline)) { av[gi()] = pA[16 * (WAVE + gi * W)]; });
+            pA += 64; pB += 64;
+          }
+          for (; t0 < cfull; t0 += 4) {
+            const double bv = pB[0];
+            static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
+              cacc[gi()] = __builtin_amdgcn_mfma_f64_4x4x4f64(pA[16 * gi], bv, cacc[gi()], 0, 0, 0);
+            });
+            pA += 16; pB += 16;
+          }
+          if (cfull < c) {
+            const bool kok = (cfull + kq) < c;
+            const double bv = kok ? pB[0] : 0.0;
+            static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
+              const double a1 = pA[16 * gi];
+              cacc[gi()] = __builtin_amdgcn_mfma_f64_4x4x4f64(kok ? a1 : 0.0, bv, cacc[gi()], 0, 0, 0);
+            });
+          }
           static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
-            cacc[gi()] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[gi()], bv, cacc[gi()], 0, 0, 0);
-          });
-          pA += 16; pB += 16;
-        }
-        if (cfull < c) {
-          const bool kok = (cfull + kq) < c;
-          const double bv = kok ? pB[0] : 0.0;
-          static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
-            const double a1 = pA[16 * (WAVE + gi * W)];
-            cacc[gi()] = __builtin_amdgcn_mfma_f64_4x4x4f64(kok ? a1 : 0.0, bv, cacc[gi()], 0, 0, 0);
+            constexpr int g = WAVE * MAXG + gi;
+            const int d = 4 * g + blk;                     // D layout: i = lane>>4, j = lane&3
+            if (g < ngroups && d < Ln) ctab[d * 16 + kq * 4 + ij] = cacc[gi()];
           });
         }
-        static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
-          constexpr int g = WAVE + gi * W;
-          const int d = 4 * g + blk;                       // D layout: i = lane>>4, j = lane&3
-          if (g < ngroups && d < Ln) ctab[d * 16 + kq * 4 + ij] = cacc[gi()];
-        });
       }
       __syncthreads();
       stamp();   // 2
+      // (explicit definition of every tile: keeps the previous active-set iteration's values from
+      //  being considered live across the loop back-edge; placed after the lag blocks so that the
+      //  accumulator registers are free during that phase)
+      static_for<TM::MAXS>([&](auto S) __attribute__((always_inline)) { acc[S] = d4{0.0, 0.0, 0.0, 0.0}; });
       // (2) first tile of every owned tile diagonal from the lag blocks:
       //     G(l+d, l)(a,b) = C_d(a,b) + sum_{j<l} ( x_a[j+c+d] x_b[j+c] - x_a[j+d] x_b[j] ),  l = lo <= 3.
       //     Lane (a = l4, b = l3, lo), register j of tile (d,0): k = 4d+j, l = lo, lag 4d+j-lo.
