@@ -881,3 +881,40 @@ def test_closed_loop_graph_replay_matches_direct_launches(gpu):
         for a, b in zip(out[True], out[False]):
             assert np.array_equal(a, b)
         assert np.all(out[True][2] == 0)
+
+
+def test_api_misuse_is_reported_not_crashing(gpu):
+    # error behaviour of the C ABI: every misuse returns a code and a message, nothing is launched
+    import ctypes as C
+    spec = orc.spec_from_params()
+    B = 2
+    u_d, y_d, up, yp = _instances(B)
+    lib = L.load()
+    with _engine(spec, 400, B) as eng:
+        h = eng._h
+        vp = lambda a: C.c_void_p(a.ctypes.data)
+        u = np.empty((B, 60)); cost = np.empty(B); st = np.empty(B, np.int32)
+        assert lib.ddmpc_solve(h, vp(up), vp(yp), vp(u), vp(cost), vp(st), C.c_void_p(), L.MEM_HOST) == L.ERR_NOT_READY
+        assert "ddmpc_set_data" in L.last_error()
+        assert lib.ddmpc_step(h, vp(up), vp(yp), vp(u), vp(cost), vp(st), C.c_void_p(), L.MEM_HOST) == L.ERR_NOT_READY
+        assert lib.ddmpc_prepare(h) == L.ERR_NOT_READY
+        eng.set_data(u_d, y_d)
+        out = np.empty((B, 367))
+        assert lib.ddmpc_get_solution(h, L.SOL_ALPHA, vp(out), L.MEM_HOST) == L.ERR_NOT_READY
+        g = np.empty((B, 17, 136))
+        assert lib.ddmpc_get_gain(h, vp(g), L.MEM_HOST) == L.ERR_NOT_READY
+        assert lib.ddmpc_solve(h, C.c_void_p(), vp(yp), vp(u), vp(cost), vp(st), C.c_void_p(), L.MEM_HOST) == L.ERR_INVALID
+        assert lib.ddmpc_solve(h, vp(up), vp(yp), vp(u), vp(cost), vp(st), C.c_void_p(), 7) == L.ERR_INVALID
+        assert lib.ddmpc_set_option(h, 99, 0) == L.ERR_INVALID
+        assert lib.ddmpc_set_option(h, L.OPT_CLOSED_LOOP_PATH, 5) == L.ERR_INVALID
+        assert lib.ddmpc_get_solution(h, 9, vp(out), L.MEM_HOST) in (L.ERR_INVALID, L.ERR_NOT_READY)
+        P = orc.FOUR_TANK
+        with pytest.raises(L.DDMPCError, match="n_mpc_step"):
+            eng.closed_loop(P["A"], P["B"], P["C"], P["D"], np.zeros((B, 4)), up, yp, np.zeros((B, 5, 2)), n_mpc_step=31)
+        with pytest.raises(ValueError):
+            eng.closed_loop(P["A"][:3, :3], P["B"], P["C"], P["D"], np.zeros((B, 4)), up, yp, np.zeros((B, 5, 2)))
+        # the handle is still usable after all of that
+        u2, c2, s2, _ = eng.solve(up, yp)
+        _check(spec, u_d, y_d, up, yp, u2, c2, s2, range(B))
+    assert lib.ddmpc_solve(None, vp(up), vp(yp), vp(u), vp(cost), vp(st), C.c_void_p(), L.MEM_HOST) == L.ERR_INVALID
+    assert lib.ddmpc_destroy(None) == L.OK
