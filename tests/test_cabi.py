@@ -91,3 +91,34 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".inc")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("no oracle", ""), os.path.join(dirpath, f)
+
+
+def test_header_is_plain_c_and_matches_the_ctypes_struct(tmp_path):
+    # include/ddmpc.h must compile as C (the boundary is a C ABI: plain pointers and sizes), and the ctypes
+    # mirror of ddmpc_params / ddmpc_plant must have the same size and field offsets as the C structs
+    import os, shutil, subprocess
+    import ctypes as C
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "probe.c"
+    fields = [n for n, _ in L.Params._fields_]
+    pfields = [n for n, _ in L.Plant._fields_]
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "ddmpc.h"\nint main(void) {\n'
+        '  printf("%zu\\n", sizeof(ddmpc_params));\n'
+        + "".join('  printf("%%zu\\n", offsetof(ddmpc_params, %s));\n' % f for f in fields)
+        + '  printf("%zu\\n", sizeof(ddmpc_plant));\n'
+        + "".join('  printf("%%zu\\n", offsetof(ddmpc_plant, %s));\n' % f for f in pfields)
+        + '  printf("%d\\n", DDMPC_ABI_VERSION);\n  return 0;\n}\n')
+    exe = tmp_path / "probe"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)],
+                   check=True, capture_output=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    n = len(fields)
+    assert out[0] == C.sizeof(L.Params)
+    assert out[1:1 + n] == [getattr(L.Params, f).offset for f in fields]
+    assert out[1 + n] == C.sizeof(L.Plant)
+    assert out[2 + n:2 + n + len(pfields)] == [getattr(L.Plant, f).offset for f in pfields]
+    assert out[-1] == L.ABI_VERSION
