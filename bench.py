@@ -31,49 +31,74 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROA
 PMC_TRAFFIC_BYTES_DEFAULT = (2 * 28911 + 13050) * 1024
 
 
-def cpu_baseline(cfg, u_d, y_d, up, yp, u_gpu, cost_gpu, n_sample):
-    """Time the CPU oracle (full-space KKT restatement of the reference QP) on a bounded
-    sample of the same workload and check the GPU results against it."""
+_ORACLE = {}      # inputs of the CPU baseline, inherited by the forked workers
+
+
+def _oracle_spec(cfg):
     from oracle import ddmpc_oracle as orc
+    return orc.QPSpec(n=cfg["n"], m=cfg["m"], p=cfg["p"], L=cfg["L"], Q=cfg["Q"] * np.eye(cfg["p"] * cfg["L"]),
+                      R=cfg["R"] * np.eye(cfg["m"] * cfg["L"]), u_s=cfg["u_s"], y_s=cfg["y_s"], robust=cfg["robust"],
+                      eps_max=cfg["eps_max"], lamb_alpha=cfg["lamb_alpha"], lamb_sigma=cfg["lamb_sigma"], c=cfg["c"],
+                      slack=cfg["slack"], tec=cfg["tec"])
+
+
+def _oracle_chunk(bounds):
+    """Worker: full-space oracle solves of instances [lo, hi), one BLAS thread."""
+    from oracle import ddmpc_oracle as orc
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=1)
+    except Exception:       # pragma: no cover
+        pass
+    lo, hi = bounds
+    g = _ORACLE
+    u = np.empty((hi - lo, g["spec"].L * g["spec"].m)); c = np.empty(hi - lo)
+    for i, b in enumerate(range(lo, hi)):
+        sol = orc.solve_fullspace(g["spec"], g["u_d"][b], g["y_d"][b], g["up"][b], g["yp"][b])
+        u[i] = sol.optimal_u; c[i] = sol.cost
+    return u, c
+
+
+def cpu_baseline(cfg, u_d, y_d, up, yp, n_sample):
+    """Time the CPU oracle (full-space KKT restatement of the reference QP) on a bounded sample of the same
+    workload, instances spread over `cores` single-threaded worker processes (forked BEFORE the GPU runtime is
+    initialised).  Returns the baseline record and the oracle's (optimal_u, cost) for the parity check."""
+    import multiprocessing as mp
+    from oracle import ddmpc_oracle as orc
+    from oracle import reduced_form as rf
     try:
         from threadpoolctl import threadpool_limits
     except Exception:       # pragma: no cover
         threadpool_limits = None
     cores = min(16, os.cpu_count() or 1)
-    spec = orc.QPSpec(n=cfg["n"], m=cfg["m"], p=cfg["p"], L=cfg["L"], Q=cfg["Q"] * np.eye(cfg["p"] * cfg["L"]),
-                      R=cfg["R"] * np.eye(cfg["m"] * cfg["L"]), u_s=cfg["u_s"], y_s=cfg["y_s"], robust=cfg["robust"],
-                      eps_max=cfg["eps_max"], lamb_alpha=cfg["lamb_alpha"], lamb_sigma=cfg["lamb_sigma"], c=cfg["c"],
-                      slack=cfg["slack"], tec=cfg["tec"])
-
-    def run():
+    spec = _oracle_spec(cfg)
+    _ORACLE.update(spec=spec, u_d=u_d, y_d=y_d, up=up, yp=yp)
+    edges = np.linspace(0, n_sample, 4 * cores + 1).astype(int)
+    chunks = [(int(edges[i]), int(edges[i + 1])) for i in range(4 * cores) if edges[i + 1] > edges[i]]
+    with mp.get_context("fork").Pool(cores) as pool:
+        pool.map(_oracle_chunk, [(0, 1)] * cores)              # start the workers outside the timed region
         t0 = time.perf_counter()
-        sols = [orc.solve_fullspace(spec, u_d[b], y_d[b], up[b], yp[b]) for b in range(n_sample)]
-        return time.perf_counter() - t0, sols
+        parts = pool.map(_oracle_chunk, chunks, chunksize=1)
+        run_t = time.perf_counter() - t0
+    u_ref = np.concatenate([p[0] for p in parts]); c_ref = np.concatenate([p[1] for p in parts])
 
-    if threadpool_limits is not None:
-        with threadpool_limits(limits=cores):
-            run_t, sols = run()
-    else:
-        run_t, sols = run()
-    # context: the same CPU running the REDUCED r x r formulation the GPU kernels use
-    # (oracle/reduced_form.py: dense Gram by BLAS + Cholesky by LAPACK), i.e. the algorithmic change
-    # alone, without the GPU.  Not the baseline (the reference solves the full-space QP through CVXPY).
-    from oracle import reduced_form as rf
-    n_red = min(n_sample, 256)
-
-    def run_reduced():
+    def timed(fn, n):
         t0 = time.perf_counter()
-        for b in range(n_red):
-            rf.solve_reduced(spec, u_d[b], y_d[b], up[b], yp[b])
+        for b in range(n):
+            fn(spec, u_d[b], y_d[b], up[b], yp[b])
         return time.perf_counter() - t0
 
+    # the same oracle on ONE thread of one process (SURVEY 8d asks for both), and -- for context only -- the same
+    # CPU on the REDUCED r x r formulation the GPU kernels use (oracle/reduced_form.py: numpy BLAS Gram + LAPACK
+    # Cholesky): the algorithmic change alone, without the GPU
+    n_one, n_red = min(n_sample, 128), min(n_sample, 256)
     if threadpool_limits is not None:
-        with threadpool_limits(limits=cores):
-            red_t = run_reduced()
+        with threadpool_limits(limits=1):
+            one_t = timed(orc.solve_fullspace, n_one)
+            red_t = timed(rf.solve_reduced, n_red)
     else:
-        red_t = run_reduced()
-    eu = max(np.max(np.abs(u_gpu[b] - s.optimal_u)) / np.max(np.abs(s.optimal_u)) for b, s in enumerate(sols))
-    ec = max(abs(cost_gpu[b] - s.cost) / abs(s.cost) for b, s in enumerate(sols))
+        one_t = timed(orc.solve_fullspace, n_one)
+        red_t = timed(rf.solve_reduced, n_red)
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as fh:
@@ -83,14 +108,15 @@ def cpu_baseline(cfg, u_d, y_d, up, yp, u_gpu, cost_gpu, n_sample):
                     break
     except OSError:
         pass
-    return dict(value=n_sample / run_t, unit="QP solves/s", cores=cores, kind="port", cpu_model=cpu_model,
-                host_cpus=os.cpu_count(),
-                sample="%d cold solves (first %d instances of the batch), full-space dense KKT in numpy/LAPACK, "
-                       "%.1f s" % (n_sample, n_sample, run_t),
-                reduced_form_value=n_red / red_t,
-                reduced_form_note="same CPU, the reduced r x r formulation of oracle/reduced_form.py (numpy BLAS Gram + "
-                                  "LAPACK Cholesky) on %d instances: context for the algorithmic share of the speed-up" % n_red), \
-        dict(max_rel_err_u=eu, max_rel_err_cost=ec, checked=n_sample, tol_u=1e-8, tol_cost=1e-9)
+    rec = dict(value=n_sample / run_t, unit="QP solves/s", cores=cores, kind="port", cpu_model=cpu_model,
+               host_cpus=os.cpu_count(),
+               sample="%d cold solves (first %d instances of the batch), full-space dense KKT in numpy/LAPACK, %d worker "
+                      "processes x 1 thread, %.1f s" % (n_sample, n_sample, cores, run_t),
+               single_thread_value=n_one / one_t,
+               reduced_form_single_thread_value=n_red / red_t,
+               reduced_form_note="same CPU, one thread, the reduced r x r formulation of oracle/reduced_form.py (numpy BLAS "
+                                 "Gram + LAPACK Cholesky) on %d instances: context for the algorithmic share of the speed-up" % n_red)
+    return rec, u_ref, c_ref
 
 
 def main():
@@ -121,6 +147,20 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    # synthetic inputs (host) and, at N=1, the CPU baseline -- before anything touches the GPU runtime, so
+    # that the baseline's worker processes can simply be forked
+    cfg = controller_params(dict(slack_var_constraint_type=1 if a.slack == "convex" else 0))
+    total = a.batch_per_gpu * world
+    lo, hi = shard_bounds(total, rank, world)
+    B = hi - lo
+    data = generate_batch(range(lo, hi), N=cfg["N"])           # seeds = global instance ids
+    u_d_h, y_d_h = data["u_d"], data["y_d"]
+    n, m, p = cfg["n"], cfg["m"], cfg["p"]
+    up_h = u_d_h[:, -n:, :].reshape(B, -1).copy()
+    yp_h = y_d_h[:, -n:, :].reshape(B, -1).copy()
+    cpu = None
+    if world == 1 and rank == 0 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, u_d_h, y_d_h, up_h, yp_h, min(a.cpu_sample, B))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
     if a.rehearse_on_one_gpu:
@@ -132,16 +172,6 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
-
-    cfg = controller_params(dict(slack_var_constraint_type=1 if a.slack == "convex" else 0))
-    total = a.batch_per_gpu * world
-    lo, hi = shard_bounds(total, rank, world)
-    B = hi - lo
-    data = generate_batch(range(lo, hi), N=cfg["N"])           # seeds = global instance ids
-    u_d_h, y_d_h = data["u_d"], data["y_d"]
-    n, m, p = cfg["n"], cfg["m"], cfg["p"]
-    up_h = u_d_h[:, -n:, :].reshape(B, -1).copy()
-    yp_h = y_d_h[:, -n:, :].reshape(B, -1).copy()
 
     eng = BatchedDDMPC(n=n, m=m, p=p, L_=cfg["L"], N=cfg["N"], Q=cfg["Q"], R=cfg["R"], u_s=cfg["u_s"], y_s=cfg["y_s"],
                        batch=B, controller_type=L.ROBUST, slack_type=L.SLACK_CONVEX if a.slack == "convex" else L.SLACK_NONE,
@@ -239,11 +269,14 @@ def main():
         }
         if warm is not None:
             out["warm_step"] = warm
-        if world == 1 and not a.no_cpu_baseline:
-            ns = min(a.cpu_sample, B)
-            base, parity = cpu_baseline(cfg, u_d_h, y_d_h, up_h, yp_h, u_opt.cpu().numpy(), cost.cpu().numpy(), ns)
+        if cpu is not None:
+            base, u_ref, c_ref = cpu
+            ns = u_ref.shape[0]
+            u_gpu, c_gpu = u_opt.cpu().numpy()[:ns], cost.cpu().numpy()[:ns]
+            eu = float(np.max(np.max(np.abs(u_gpu - u_ref), axis=1) / np.max(np.abs(u_ref), axis=1)))
+            ec = float(np.max(np.abs(c_gpu - c_ref) / np.abs(c_ref)))
             out["cpu_baseline"] = base
-            out["parity"] = parity
+            out["parity"] = dict(max_rel_err_u=eu, max_rel_err_cost=ec, checked=ns, tol_u=1e-8, tol_cost=1e-9)
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
