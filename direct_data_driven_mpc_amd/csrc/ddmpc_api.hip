@@ -67,6 +67,25 @@ struct DevBuf {
   }
 };
 
+struct HostBuf {            // pinned host staging
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return DDMPC_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    bytes = 0;
+    HIP_TRY(hipHostMalloc(&p, need, hipHostMallocDefault));
+    bytes = need;
+    return DDMPC_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
 typedef void (*cold_kernel_t)(KParams, const double*, const double*, const double*, const double*, double*,
                               double*, int*, int*, double*, signed char*, unsigned long long*, double*, const int*);
 
@@ -119,6 +138,9 @@ struct ddmpc_handle {
   DevBuf d_pl, d_x, d_w, d_usys, d_ysys, d_stacc;
   // warm path: per-instance affine law (ddmpc_prepare)
   DevBuf d_lfac, d_lfacT, d_gain, d_prep_status, d_zero, d_need;
+  // host-pointer solves: one packed device buffer and its pinned host mirror (two copies per solve instead of six)
+  DevBuf d_io;
+  HostBuf h_io;
   bool prepared = false;
   int closed_loop_path = DDMPC_PATH_AUTO;
   bool closed_loop_graph = false;
@@ -432,8 +454,9 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io};
   for (DevBuf* b : bufs) b->release();
+  h->h_io.release();
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return DDMPC_OK;
@@ -551,25 +574,29 @@ static int solve_impl(ddmpc_handle* h, const double* u_past, const double* y_pas
     return DDMPC_OK;
   }
   if (mem != DDMPC_MEM_HOST) return fail(DDMPC_ERR_INVALID, "mem must be DDMPC_MEM_HOST or DDMPC_MEM_DEVICE");
-  if ((rc = h->d_up.ensure(n_up))) return rc;
-  if ((rc = h->d_yp.ensure(n_yp))) return rc;
-  if ((rc = h->d_uopt.ensure(n_uo))) return rc;
-  if ((rc = h->d_cost.ensure((size_t)h->batch * sizeof(double)))) return rc;
-  if ((rc = h->d_status.ensure((size_t)h->batch * sizeof(int32_t)))) return rc;
-  if ((rc = h->d_iters.ensure((size_t)h->batch * sizeof(int32_t)))) return rc;
-  HIP_TRY(hipMemcpyAsync(h->d_up.p, u_past, n_up, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->d_yp.p, y_past, n_yp, hipMemcpyHostToDevice, h->stream));
-  if ((rc = launch(h, (const double*)h->d_up.p, (const double*)h->d_yp.p, (double*)h->d_uopt.p,
-                   (double*)h->d_cost.p, (int32_t*)h->d_status.p, (int32_t*)h->d_iters.p)))
+  // packed staging: [u_past | y_past | u_opt | cost | status | iters], every section 16-byte aligned
+  auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  const size_t B = (size_t)h->batch;
+  const size_t o_up = 0, o_yp = al(o_up + n_up), o_uo = al(o_yp + n_yp), o_cost = al(o_uo + n_uo),
+               o_st = al(o_cost + B * sizeof(double)), o_it = al(o_st + B * sizeof(int32_t)),
+               total = al(o_it + B * sizeof(int32_t));
+  if ((rc = h->d_io.ensure(total)) || (rc = h->h_io.ensure(total))) return rc;
+  char* hb = (char*)h->h_io.p;
+  char* db = (char*)h->d_io.p;
+  memcpy(hb + o_up, u_past, n_up);
+  memcpy(hb + o_yp, y_past, n_yp);
+  HIP_TRY(hipMemcpyAsync(db, hb, o_uo, hipMemcpyHostToDevice, h->stream));                 // both inputs, one copy
+  if ((rc = launch(h, (const double*)(db + o_up), (const double*)(db + o_yp), (double*)(db + o_uo),
+                   (double*)(db + o_cost), (int32_t*)(db + o_st), (int32_t*)(db + o_it))))
     return rc;
-  HIP_TRY(hipMemcpyAsync(u_opt, h->d_uopt.p, n_uo, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(cost, h->d_cost.p, (size_t)h->batch * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(status, h->d_status.p, (size_t)h->batch * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-  if (iters)
-    HIP_TRY(hipMemcpyAsync(iters, h->d_iters.p, (size_t)h->batch * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(hb + o_uo, db + o_uo, total - o_uo, hipMemcpyDeviceToHost, h->stream));   // all outputs, one copy
   HIP_TRY(hipStreamSynchronize(h->stream));
-  h->last_up = (const double*)h->d_up.p;
-  h->last_yp = (const double*)h->d_yp.p;
+  memcpy(u_opt, hb + o_uo, n_uo);
+  memcpy(cost, hb + o_cost, B * sizeof(double));
+  memcpy(status, hb + o_st, B * sizeof(int32_t));
+  if (iters) memcpy(iters, hb + o_it, B * sizeof(int32_t));
+  h->last_up = (const double*)(db + o_up);
+  h->last_yp = (const double*)(db + o_yp);
   h->solved = true;
   return DDMPC_OK;
 }
