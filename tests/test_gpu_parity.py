@@ -824,7 +824,7 @@ def test_random_systems_against_oracle(gpu, case):
         assert L.STATUS_STRINGS[int(status[b])] == sol.status == "optimal"
         scale = max(np.max(np.abs(sol.optimal_u)), 1e-3)
         # Random plants have output gains of order 1-10 against a noise level of 0.002, so the y rows of H are
-        # nearly dependent on its u rows: cond(H) reaches 1e5-5e5 (four-tank data: ~1e2).  The kernels factor the
+        # nearly dependent on its u rows: cond(H) reaches 1e5-5e5 (four-tank data: ~1.3e3).  The kernels factor the
         # Gram matrix, which squares that; the cost then agrees with the full-space oracle to ~3e-9 (GPU and numpy
         # reduced form alike), hence 10x wider tolerances in this sweep only.
         assert np.max(np.abs(u[b] - sol.optimal_u)) / scale < 10 * TOL_U, (case, b)
