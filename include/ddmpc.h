@@ -231,7 +231,8 @@ const char* ddmpc_kernel_name(ddmpc_handle* h);
 /* Diagnostics only: in-kernel phase stamps (shader-clock ticks) of the next solves.
  * `enable` != 0 turns stamping on (zeroing the buffer); `out` (host, [batch,16] uint64,
  * may be NULL) receives the stamps of the last solve: [0] kernel entry, [1..6] phase
- * ends (tables, base sums, Gram, fix-up, Cholesky, back substitution), [14] exit,
+ * ends (staging + tables, lag blocks, base tiles + diagonal walks, Cholesky, [5] = [4], back substitution);
+ * [7..11] Cholesky sub-phase sums of wave 0, [14] exit,
  * [15]/[13] the 100 MHz real-time counter at entry/exit.  Off by default; a stamping
  * run must not be used for timing claims. */
 int ddmpc_debug_stamps(ddmpc_handle* h, int enable, uint64_t* out);
