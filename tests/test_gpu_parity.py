@@ -918,3 +918,26 @@ def test_api_misuse_is_reported_not_crashing(gpu):
         _check(spec, u_d, y_d, up, yp, u2, c2, s2, range(B))
     assert lib.ddmpc_solve(None, vp(up), vp(yp), vp(u), vp(cost), vp(st), C.c_void_p(), L.MEM_HOST) == L.ERR_INVALID
     assert lib.ddmpc_destroy(None) == L.OK
+
+
+@pytest.mark.parametrize("kw,B,n_steps,n_mpc_step", [(dict(), 4, 201, 1), (dict(slack_var_constraint_type=1), 2, 101, 2)],
+                         ids=["fused-warm-201", "slack-box-101"])
+def test_long_closed_loop_matches_oracle(gpu, kw, B, n_steps, n_mpc_step):
+    # long horizons: errors would accumulate through the plant if a step were off; the device loop must stay on
+    # the oracle's trajectory from the transient into the steady state
+    spec = orc.spec_from_params(**kw)
+    insts = [orc.generate_instance(s) for s in range(20, 20 + B)]
+    u_d = np.stack([i["u_d"] for i in insts]); y_d = np.stack([i["y_d"] for i in insts])
+    x0 = np.stack([i["plant"].x for i in insts])
+    w = np.stack([i["plant"].eps_max * i["rng"].uniform(-1.0, 1.0, (n_steps, 2)) for i in insts])
+    up = u_d[:, -4:, :].reshape(B, -1); yp = y_d[:, -4:, :].reshape(B, -1)
+    P = orc.FOUR_TANK
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(u_d, y_d)
+        u_sys, y_sys, status, *_ = eng.closed_loop(P["A"], P["B"], P["C"], P["D"], x0, up, yp, w, n_mpc_step=n_mpc_step)
+    assert np.all(status == 0)
+    for b in range(B):
+        u_ref, y_ref = orc.closed_loop(spec, u_d[b], y_d[b], insts[b]["plant"], w[b], n_mpc_step=n_mpc_step)
+        assert np.max(np.abs(u_sys[b] - u_ref)) / np.max(np.abs(u_ref)) < 1e-8
+        assert np.max(np.abs(y_sys[b] - y_ref)) < 1e-9
+        assert np.all(np.abs(y_sys[b, -1] - spec.y_s) < 0.05)      # near the setpoint (the 1-step scheme wanders with the noise)
