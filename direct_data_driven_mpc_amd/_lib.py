@@ -30,7 +30,7 @@ EXPORTS = (
     "ddmpc_set_stream", "ddmpc_synchronize", "ddmpc_set_data", "ddmpc_solve", "ddmpc_set_setpoints",
     "ddmpc_get_solution", "ddmpc_hankel", "ddmpc_cost_model", "ddmpc_kernel_name", "ddmpc_debug_stamps",
     "ddmpc_closed_loop", "ddmpc_prepare", "ddmpc_step", "ddmpc_get_gain", "ddmpc_set_option",
-    "ddmpc_pe_guard",
+    "ddmpc_pe_guard", "ddmpc_solve_from_host",
 )
 
 c_double_p = C.POINTER(C.c_double)
@@ -100,6 +100,8 @@ def load() -> C.CDLL:
     lib.ddmpc_get_gain.argtypes = [vp, vp, C.c_int]
     lib.ddmpc_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.ddmpc_pe_guard.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int, C.c_int]
+    lib.ddmpc_solve_from_host.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32p, i32p]
+    lib.ddmpc_solve_from_host.restype = C.c_int
     for name in ("ddmpc_prepare", "ddmpc_step", "ddmpc_get_gain", "ddmpc_set_option", "ddmpc_pe_guard"):
         getattr(lib, name).restype = C.c_int
     for name in ("ddmpc_create", "ddmpc_destroy", "ddmpc_set_stream", "ddmpc_synchronize", "ddmpc_set_data",

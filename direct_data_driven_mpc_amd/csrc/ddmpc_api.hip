@@ -126,6 +126,7 @@ struct ddmpc_handle {
   size_t lds_bytes = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t copy_stream = nullptr;      // uploads of ddmpc_solve_from_host, overlapped with the solves on `stream`
   bool have_data = false, solved = false;
   // parameter tables on device
   DevBuf d_tabd, d_tabi, d_dmat;
@@ -457,6 +458,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
                     &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return DDMPC_OK;
@@ -604,6 +606,68 @@ static int solve_impl(ddmpc_handle* h, const double* u_past, const double* y_pas
 int ddmpc_solve(ddmpc_handle* h, const double* u_past, const double* y_past, double* u_opt, double* cost,
                 int32_t* status, int32_t* iters, int mem) {
   return solve_impl(h, u_past, y_past, u_opt, cost, status, iters, mem, &launch_cold_plain);
+}
+
+int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d, const double* u_past,
+                          const double* y_past, double* u_opt, double* cost, int32_t* status, int32_t* iters) {
+  if (!h || !u_d || !y_d || !u_past || !y_past || !u_opt || !cost || !status)
+    return fail(DDMPC_ERR_INVALID, "null argument");
+  if (h->batch > 0x7fffffffLL) return fail(DDMPC_ERR_INVALID, "batch too large for one launch");
+  HIP_TRY(hipSetDevice(h->device));
+  const ddmpc_params& p = h->prm;
+  const size_t B = (size_t)h->batch;
+  const size_t su = (size_t)p.N * p.m, sy = (size_t)p.N * p.p;                 // doubles per instance
+  const size_t sup = (size_t)p.n * p.m, syp = (size_t)p.n * p.p, suo = (size_t)p.L * p.m;
+  int rc;
+  if ((rc = h->d_ud.ensure(B * su * sizeof(double))) || (rc = h->d_yd.ensure(B * sy * sizeof(double))) ||
+      (rc = h->d_up.ensure(B * sup * sizeof(double))) || (rc = h->d_yp.ensure(B * syp * sizeof(double))) ||
+      (rc = h->d_uopt.ensure(B * suo * sizeof(double))) || (rc = h->d_cost.ensure(B * sizeof(double))) ||
+      (rc = h->d_status.ensure(B * sizeof(int32_t))) || (rc = h->d_iters.ensure(B * sizeof(int32_t))) ||
+      (rc = h->d_beta.ensure(B * h->kp.rE * sizeof(double))) || (rc = h->d_act.ensure(B * h->kp.rE)))
+    return rc;
+  if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+  double *dud = (double*)h->d_ud.p, *dyd = (double*)h->d_yd.p, *dup = (double*)h->d_up.p, *dyp = (double*)h->d_yp.p;
+  double *duo = (double*)h->d_uopt.p, *dco = (double*)h->d_cost.p;
+  int32_t *dst = (int32_t*)h->d_status.p, *dit = (int32_t*)h->d_iters.p;
+  HIP_TRY(hipMemcpyAsync(dup, u_past, B * sup * sizeof(double), hipMemcpyHostToDevice, h->copy_stream));
+  HIP_TRY(hipMemcpyAsync(dyp, y_past, B * syp * sizeof(double), hipMemcpyHostToDevice, h->copy_stream));
+  // chunks of instances: upload chunk k+1 on the copy stream while chunk k is being solved on the compute stream
+  const size_t nchunks = B >= 2048 ? 8 : (B >= 256 ? 4 : 1);
+  hipEvent_t ev[8];
+  for (size_t k = 0; k < nchunks; ++k) HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+  int rcl = DDMPC_OK;
+  for (size_t k = 0; k < nchunks && rcl == DDMPC_OK; ++k) {
+    const size_t b0 = B * k / nchunks, b1 = B * (k + 1) / nchunks, nb = b1 - b0;
+    if (hipMemcpyAsync(dud + b0 * su, u_d + b0 * su, nb * su * sizeof(double), hipMemcpyHostToDevice, h->copy_stream) != hipSuccess ||
+        hipMemcpyAsync(dyd + b0 * sy, y_d + b0 * sy, nb * sy * sizeof(double), hipMemcpyHostToDevice, h->copy_stream) != hipSuccess ||
+        hipEventRecord(ev[k], h->copy_stream) != hipSuccess || hipStreamWaitEvent(h->stream, ev[k], 0) != hipSuccess) {
+      rcl = fail(DDMPC_ERR_HIP, "ddmpc_solve_from_host: upload of chunk %zu failed", k);
+      break;
+    }
+    hipLaunchKernelGGL(h->kc.fn, dim3((unsigned)nb), dim3(64 * h->kc.W), h->lds_bytes, h->stream, h->kp,
+                       (const double*)(dud + b0 * su), (const double*)(dyd + b0 * sy), (const double*)(dup + b0 * sup),
+                       (const double*)(dyp + b0 * syp), duo + b0 * suo, dco + b0, (int*)(dst + b0), (int*)(dit + b0),
+                       (double*)h->d_beta.p + b0 * h->kp.rE, (signed char*)h->d_act.p + b0 * h->kp.rE,
+                       (unsigned long long*)nullptr, (double*)nullptr, (const int*)nullptr);
+    if (hipGetLastError() != hipSuccess) rcl = fail(DDMPC_ERR_HIP, "ddmpc_solve_from_host: launch of chunk %zu failed", k);
+  }
+  if (rcl == DDMPC_OK) {
+    if (hipMemcpyAsync(u_opt, duo, B * suo * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipMemcpyAsync(cost, dco, B * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipMemcpyAsync(status, dst, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        (iters && hipMemcpyAsync(iters, dit, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess))
+      rcl = fail(DDMPC_ERR_HIP, "ddmpc_solve_from_host: download failed");
+  }
+  (void)hipStreamSynchronize(h->copy_stream);
+  (void)hipStreamSynchronize(h->stream);
+  for (size_t k = 0; k < nchunks; ++k) (void)hipEventDestroy(ev[k]);
+  if (rcl != DDMPC_OK) return rcl;
+  h->ud = dud; h->yd = dyd;
+  h->have_data = true;
+  h->prepared = false;
+  h->last_up = dup; h->last_yp = dyp;
+  h->solved = true;
+  return DDMPC_OK;
 }
 
 int ddmpc_prepare(ddmpc_handle* h) {

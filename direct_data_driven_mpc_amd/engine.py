@@ -193,6 +193,23 @@ class BatchedDDMPC:
         self._keep["solve"] = (k1, k2, k3, k4, k5, k6)
         return u_opt, cost, status, iters
 
+    def solve_from_host(self, u_d, y_d, u_past, y_past):
+        """`set_data` + `solve` for host arrays in one pipelined call (uploads overlapped with the solves)."""
+        B = self.batch
+        arrs = []
+        for a, shape, name in ((u_d, (B, self.N, self.m), "u_d"), (y_d, (B, self.N, self.p), "y_d"),
+                               (u_past, (B, self.n * self.m), "u_past"), (y_past, (B, self.n * self.p), "y_past")):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            if a.shape != shape:
+                raise ValueError("%s must have shape %s" % (name, (shape,)))
+            arrs.append(a)
+        u_opt = np.empty((B, self.L * self.m)); cost = np.empty((B,))
+        status = np.empty((B,), dtype=np.int32); iters = np.empty((B,), dtype=np.int32)
+        vp = lambda x: C.c_void_p(x.ctypes.data)
+        L.check(self._lib.ddmpc_solve_from_host(self._h, *(vp(a) for a in arrs), vp(u_opt), vp(cost), vp(status), vp(iters)))
+        self._keep["data"] = (None, None)
+        return u_opt, cost, status, iters
+
     def prepare(self) -> None:
         """Factor once per data set and form the affine law used by `step`."""
         if "data" in self._keep and self._keep["data"][0] is not None and _is_torch(self._keep["data"][0]):

@@ -141,6 +141,14 @@ int ddmpc_set_data(ddmpc_handle* h, const double* u_d, const double* y_d, int me
 int ddmpc_solve(ddmpc_handle* h, const double* u_past, const double* y_past,
                 double* u_opt, double* cost, int32_t* status, int32_t* iters, int mem);
 
+/* ddmpc_set_data + ddmpc_solve for HOST buffers in one call, pipelined: the batch is cut into chunks of
+ * instances, chunk k+1 is uploaded on a copy stream while chunk k is solved on the compute stream.  Same
+ * outputs as ddmpc_solve; afterwards the handle holds the uploaded data (ddmpc_step / ddmpc_get_solution
+ * work as after ddmpc_set_data + ddmpc_solve).  All pointers are host pointers. */
+int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
+                          const double* u_past, const double* y_past,
+                          double* u_opt, double* cost, int32_t* status, int32_t* iters);
+
 /* Warm path = what the reference's per-step entry point could reuse but does not:
  * update_and_solve_data_driven_mpc (controller.py:389-407) rebuilds and re-solves the whole QP
  * although only u_past / y_past changed (:404-407, :577-581); the Hankel matrices, weights and

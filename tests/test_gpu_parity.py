@@ -941,3 +941,20 @@ def test_long_closed_loop_matches_oracle(gpu, kw, B, n_steps, n_mpc_step):
         assert np.max(np.abs(u_sys[b] - u_ref)) / np.max(np.abs(u_ref)) < 1e-8
         assert np.max(np.abs(y_sys[b] - y_ref)) < 1e-9
         assert np.all(np.abs(y_sys[b, -1] - spec.y_s) < 0.05)      # near the setpoint (the 1-step scheme wanders with the noise)
+
+
+def test_pipelined_host_solve(gpu):
+    # ddmpc_solve_from_host = set_data + solve with the uploads overlapped with the solves (8 chunks at this size)
+    spec = orc.spec_from_params(slack_var_constraint_type=1)
+    B = 2500                                               # not a multiple of the chunk count
+    u_d, y_d, up, yp = _instances(B)
+    with _engine(spec, 400, B) as eng:
+        u1, c1, s1, i1 = eng.solve_from_host(u_d, y_d, up, yp)
+        uw, cw, sw, iw = eng.step(up, yp)                  # the handle now owns the uploaded data
+        sg = eng.get_solution("sigma")
+        eng.set_data(u_d, y_d)
+        u2, c2, s2, i2 = eng.solve(up, yp)
+    assert np.array_equal(u1, u2) and np.array_equal(c1, c2) and np.array_equal(s1, s2) and np.array_equal(i1, i2)
+    assert np.max(np.abs(uw - u1)) / np.max(np.abs(u1)) < 1e-10 and np.array_equal(iw, i1)
+    assert np.max(np.abs(sg[:, 8:])) <= spec.c * spec.eps_max * (1 + 1e-12)
+    _check(spec, u_d, y_d, up, yp, u1, c1, s1, range(0, B, 311))

@@ -7,7 +7,7 @@ from direct_data_driven_mpc_amd import _lib as L
 from direct_data_driven_mpc_amd.engine import BatchedDDMPC
 from direct_data_driven_mpc_amd.harness import controller_params, generate_batch
 
-def run(tag, B, Lh, N, slack, gram=0, steps=10, host=False):
+def run(tag, B, Lh, N, slack, gram=0, steps=10, host=False, pipelined=False):
     cfg = controller_params(dict(L=Lh, N=N, slack_var_constraint_type=slack))
     d = generate_batch(range(B), N=N)
     n, m, p = 4, 2, 2
@@ -17,9 +17,13 @@ def run(tag, B, Lh, N, slack, gram=0, steps=10, host=False):
                        eps_max=cfg["eps_max"], lamb_alpha=cfg["lamb_alpha"], lamb_sigma=cfg["lamb_sigma"], c=cfg["c"], gram_mode=gram)
     dev = torch.device("cuda", 0)
     if host:
+        eng.solve_from_host(d["u_d"], d["y_d"], up, yp)          # buffers allocated outside the timed region
         t0 = time.perf_counter()
         for _ in range(steps):
-            eng.set_data(d["u_d"], d["y_d"]); eng.solve(up, yp)
+            if pipelined:
+                eng.solve_from_host(d["u_d"], d["y_d"], up, yp)
+            else:
+                eng.set_data(d["u_d"], d["y_d"]); eng.solve(up, yp)
         dt = (time.perf_counter() - t0) / steps
     else:
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -45,3 +49,4 @@ run("cfg3 shard: robust NONE, 32768 per GPU", 32768, 30, 400, 0, steps=5)
 run("cfg4 robust NONE L=60 N=1000", 1024, 60, 1000, 0)
 run("cfg4 robust CONVEX L=60 N=1000", 1024, 60, 1000, 1)
 run("cfg2 PCIe-inclusive (host pointers: upload u_d,y_d + solve + download)", 4096, 30, 400, 0, host=True, steps=5)
+run("cfg2 PCIe-inclusive, pipelined (ddmpc_solve_from_host: chunked upload overlapped with the solves)", 4096, 30, 400, 0, host=True, steps=5, pipelined=True)
