@@ -132,3 +132,33 @@ def generate_batch(seeds: Sequence[int], N: int = 400, plant: Optional[Dict] = N
     x_0 = (y_i.reshape(nb, -1) - u_i.reshape(nb, -1) @ T.T) @ Opinv.T
     y_d, x_end = simulate_batch(A, Bm, C, D, x_0, u_d, w_d)
     return dict(u_d=u_d, y_d=y_d, x_0=x_0, x_end=x_end, rngs=rngs)
+
+
+def equilibrium_input_from_output(plant: Dict, y_eq) -> np.ndarray:
+    """Input holding the output at `y_eq` in steady state: u = pinv(C (I - A)^-1 B + D) y
+    (utilities/initial_state_estimation.py:171-204)."""
+    A, Bm, C, D = plant["A"], plant["B"], plant["C"], plant["D"]
+    M = C @ np.linalg.inv(np.eye(A.shape[0]) - A) @ Bm + D
+    return np.linalg.pinv(M) @ np.asarray(y_eq, dtype=float)
+
+
+def initial_state_from_trajectory(plant: Dict, U, Y) -> np.ndarray:
+    """Least-squares observer x0 = pinv(O)(Y - T U) from `ns` steps of inputs U [ns*m] and outputs Y [ns*p]
+    (utilities/initial_state_estimation.py:3-24,72-93,131)."""
+    Opinv, T = _observer(plant["A"], plant["B"], plant["C"], plant["D"])
+    return Opinv @ (np.asarray(Y, dtype=float).reshape(-1) - T @ np.asarray(U, dtype=float).reshape(-1))
+
+
+def reproduction_start(plant: Dict, rngs, y_0, u_s, n: int):
+    """Start of the paper-reproduction runs for a batch of instances (utilities/reproduction/
+    paper_reproduction.py:80-116 and utilities/controller/controller_operation.py:190-197): the plant is put at
+    the equilibrium of output `y_0`, then the input setpoint `u_s` is applied for `n` noisy steps (noise drawn
+    from each instance's generator, after the data generation).  Returns (x_start [B,ns], U_n [B,n*m], Y_n [B,n*p])."""
+    Bt = len(rngs)
+    m, p = plant["B"].shape[1], plant["C"].shape[0]
+    u_eq = equilibrium_input_from_output(plant, y_0)
+    x_eq = initial_state_from_trajectory(plant, np.tile(u_eq, plant["A"].shape[0]), np.tile(np.asarray(y_0, float), plant["A"].shape[0]))
+    U = np.tile(np.asarray(u_s, dtype=float), (Bt, n, 1))
+    W = np.stack([plant["eps_max"] * rng.uniform(-1.0, 1.0, (n, p)) for rng in rngs])
+    Y, x_start = simulate_batch(plant["A"], plant["B"], plant["C"], plant["D"], np.tile(x_eq, (Bt, 1)), U, W)
+    return x_start, U.reshape(Bt, n * m), Y.reshape(Bt, n * p)

@@ -958,3 +958,19 @@ def test_pipelined_host_solve(gpu):
     assert np.max(np.abs(uw - u1)) / np.max(np.abs(u1)) < 1e-10 and np.array_equal(iw, i1)
     assert np.max(np.abs(sg[:, 8:])) <= spec.c * spec.eps_max * (1 + 1e-12)
     _check(spec, u_d, y_d, up, yp, u1, c1, s1, range(0, B, 311))
+
+
+def test_batched_reproduction_script(gpu, tmp_path):
+    # the reproduction flow as a script: seed 4 must print the reference figure's known answers
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "repro.npz"
+    res = subprocess.run([sys.executable, os.path.join(root, "examples", "batched_robust_reproduction.py"),
+                          "--batch", "3", "--seed", "4", "--out", str(out)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    z = np.load(out)
+    assert np.allclose(z["TEC_1-step_u"][0, 0], [8.6604991, 8.53323249], atol=2e-7)
+    assert np.allclose(z["TEC_n-step_u"][0, 0], [8.6604991, 8.53323249], atol=2e-7)
+    assert np.allclose(z["UCON_1-step_u"][0, 0], [7.89630434, 9.2946719], atol=2e-7)
+    assert "instance 0 at step 384" in res.stdout
+    assert np.all(z["TEC_1-step_status"] == 0) and z["TEC_1-step_u"].shape == (3, 596, 2)

@@ -118,3 +118,17 @@ def test_yaml_config_helpers(tmp_path):
         hs.load_yaml_config_params(ctrl, "nope")
     with pytest.raises(ValueError):
         hs.controller_params_from_yaml(ctrl, m=3, p=2)
+
+
+def test_reproduction_start_helpers(golden):
+    # equilibrium / observer helpers of the reproduction flow (utilities/initial_state_estimation.py,
+    # utilities/reproduction/paper_reproduction.py:80-116) against values captured from the reference
+    from direct_data_driven_mpc_amd import harness as hs
+    u_eq = hs.equilibrium_input_from_output(hs.FOUR_TANK, [0.4, 0.4])
+    assert np.allclose(u_eq, golden["eq_u"], atol=1e-12)
+    x_eq = hs.initial_state_from_trajectory(hs.FOUR_TANK, np.tile(u_eq, 4), np.tile([0.4, 0.4], 4))
+    assert np.allclose(x_eq, [0.4, 0.4, 0.57975222, 0.4778383], atol=1e-8)
+    rngs = [np.random.default_rng(s) for s in (1, 2)]
+    x_start, U_n, Y_n = hs.reproduction_start(hs.FOUR_TANK, rngs, [0.4, 0.4], [1.0, 1.0], 4)
+    assert x_start.shape == (2, 4) and U_n.shape == (2, 8) and Y_n.shape == (2, 8)
+    assert np.allclose(Y_n[:, :2], 0.4, atol=0.0021)                                 # first output = y_0 + noise
