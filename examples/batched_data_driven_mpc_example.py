@@ -18,6 +18,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "examples"))
 
 from direct_data_driven_mpc_amd import _lib as L                                  # noqa: E402
 from direct_data_driven_mpc_amd.engine import BatchedDDMPC                        # noqa: E402
@@ -42,6 +43,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=1024, help="number of independent controller instances")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--out", default=None, help="write u_sys / y_sys / status of all instances to this .npz")
+    ap.add_argument("--plot", default=None, help="write a PNG of the closed-loop inputs/outputs (median, band, instance 0)")
     ap.add_argument("--verbose", type=int, choices=[0, 1, 2], default=1)
     return ap.parse_args()
 
@@ -118,6 +120,10 @@ def main():
         print(f"instance 0: y[-1] = {y_sys[0, -1]}, u[-1] = {u_sys[0, -1]}")
     if a.out:
         np.savez_compressed(a.out, u_sys=u_sys, y_sys=y_sys, status=status, u_s=cfg["u_s"], y_s=cfg["y_s"])
+    if a.plot:
+        from _plot import plot_closed_loops
+        plot_closed_loops(a.plot, {"closed loop": (u_sys, y_sys)}, cfg["u_s"], cfg["y_s"],
+                          title=f"{B} controllers, {'robust' if cfg['robust'] else 'nominal'} scheme, slack {cfg['slack']}")
     eng.close()
 
 

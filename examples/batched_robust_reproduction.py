@@ -17,6 +17,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "examples"))
 
 from direct_data_driven_mpc_amd import _lib as L                                  # noqa: E402
 from direct_data_driven_mpc_amd.engine import BatchedDDMPC                        # noqa: E402
@@ -39,6 +40,7 @@ def main():
     ap.add_argument("--y_0", type=float, nargs="+", default=[0.4, 0.4], help="output the plant starts from")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--plot", default=None, help="write a PNG comparing the three schemes")
     a = ap.parse_args()
 
     plant = plant_from_yaml(a.model_config_path, a.model_key_value)
@@ -69,6 +71,10 @@ def main():
               f"final |y - y_s| median {np.median(err, axis=0)}; |u| > 15 in {int((first_big >= 0).sum())} instance(s)"
               + (f", instance 0 at step {int(first_big[0])}" if first_big[0] >= 0 else ""))
         results[tag] = (u_sys, y_sys, status)
+    if a.plot:
+        from _plot import plot_closed_loops
+        plot_closed_loops(a.plot, {k: (r[0], r[1]) for k, r in results.items()}, cfg["u_s"], cfg["y_s"], t0=n,
+                          title=f"robust Data-Driven MPC, {B} noise realisations from seed {a.seed}")
     if a.out:
         np.savez_compressed(a.out, **{k.replace(" ", "_") + "_" + nm: v for k, r in results.items()
                                       for nm, v in zip(("u", "y", "status"), r)})

@@ -132,3 +132,18 @@ def test_reproduction_start_helpers(golden):
     x_start, U_n, Y_n = hs.reproduction_start(hs.FOUR_TANK, rngs, [0.4, 0.4], [1.0, 1.0], 4)
     assert x_start.shape == (2, 4) and U_n.shape == (2, 8) and Y_n.shape == (2, 8)
     assert np.allclose(Y_n[:, :2], 0.4, atol=0.0021)                                 # first output = y_0 + noise
+
+
+def test_example_plot_helper(tmp_path):
+    # the minimal plotting of the batched examples (median + band + instance 0); needs matplotlib only
+    import os, sys
+    pytest.importorskip("matplotlib")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "examples"))
+    from _plot import plot_closed_loops
+    rng = np.random.default_rng(0)
+    u = 1.0 + 0.1 * rng.normal(size=(16, 50, 2)); y = 0.7 + 0.01 * rng.normal(size=(16, 50, 2))
+    ydiv = y.copy(); ydiv[:, 30:, :] = np.nan                     # a stopped instance is NaN from there on
+    out = tmp_path / "p.png"
+    plot_closed_loops(str(out), {"a": (u, y), "b": (u * 2, ydiv)}, [1.0, 1.0], [0.65, 0.77], t0=4, title="t")
+    assert out.stat().st_size > 10000
