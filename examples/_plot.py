@@ -32,7 +32,11 @@ def plot_closed_loops(path, runs, u_s, y_s, t0=0, title=None):
                 xs = x[:, :, ch]
                 finite = np.where(np.isfinite(xs), xs, np.nan)
                 if xs.shape[0] > 1:
-                    lo, mid, hi = np.nanpercentile(finite, [5, 50, 95], axis=0)
+                    with np.errstate(all="ignore"):
+                        import warnings
+                        with warnings.catch_warnings():
+                            warnings.simplefilter("ignore", RuntimeWarning)      # columns where every loop has stopped
+                            lo, mid, hi = np.nanpercentile(finite, [5, 50, 95], axis=0)
                     ax.fill_between(t, lo, hi, color=col, alpha=0.2, linewidth=0)
                     ax.plot(t, mid, color=col, linewidth=1.0, label=f"{label} (median, 5-95 %)")
                 ax.plot(t, finite[0], color=col, linewidth=0.7, linestyle=":" if xs.shape[0] > 1 else "-",
