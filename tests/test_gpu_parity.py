@@ -974,3 +974,59 @@ def test_batched_reproduction_script(gpu, tmp_path):
     assert np.allclose(z["UCON_1-step_u"][0, 0], [7.89630434, 9.2946719], atol=2e-7)
     assert "instance 0 at step 384" in res.stdout
     assert np.all(z["TEC_1-step_status"] == 0) and z["TEC_1-step_u"].shape == (3, 596, 2)
+
+
+def test_device_memory_variants_of_every_entry_point(gpu):
+    # every entry point that takes a `mem` flag, called with DEVICE pointers (torch tensors), must agree with its
+    # HOST-pointer form
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    spec = orc.spec_from_params()
+    B, n_steps = 6, 9
+    d = generate_batch(range(B))
+    u_d, y_d = d["u_d"], d["y_d"]
+    up = u_d[:, -4:, :].reshape(B, -1).copy(); yp = y_d[:, -4:, :].reshape(B, -1).copy()
+    w = 0.002 * np.random.default_rng(0).uniform(-1, 1, (B, n_steps, 2))
+    P = orc.FOUR_TANK
+    lib = L.load()
+    t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
+    ptr = lambda x: C.c_void_p(x.data_ptr())
+    with _engine(spec, 400, B) as eng:
+        h = eng._h
+        # host references
+        eng.set_data(u_d, y_d)
+        u_h, c_h, s_h, i_h = (x.copy() for x in eng.step(up, yp))
+        al_h = eng.get_solution("alpha"); g_h = eng.gain()
+        loop_h = eng.closed_loop(P["A"], P["B"], P["C"], P["D"], d["x_end"], up, yp, w, n_mpc_step=2)
+        # device forms
+        tud, tyd, tup, typ = t(u_d), t(y_d), t(up), t(yp)
+        eng.set_data(tud, tyd)
+        u_t, c_t, s_t, i_t = eng.step(tup, typ)
+        torch.cuda.synchronize()
+        assert np.array_equal(u_t.cpu().numpy(), u_h) and np.array_equal(c_t.cpu().numpy(), c_h) and np.array_equal(s_t.cpu().numpy(), s_h)
+        al_t = torch.empty((B, 367), dtype=torch.float64, device=dev)
+        L.check(lib.ddmpc_get_solution(h, L.SOL_ALPHA, ptr(al_t), L.MEM_DEVICE)); L.check(lib.ddmpc_synchronize(h))
+        assert np.array_equal(al_t.cpu().numpy(), al_h)
+        g_t = torch.empty((B, 17, 136), dtype=torch.float64, device=dev)
+        L.check(lib.ddmpc_get_gain(h, ptr(g_t), L.MEM_DEVICE))
+        assert np.array_equal(g_t.cpu().numpy(), g_h)
+        x_t, upl, ypl, w_t = t(d["x_end"]), t(up), t(yp), t(w)
+        us_t = torch.empty((B, n_steps, 2), dtype=torch.float64, device=dev); ys_t = torch.empty_like(us_t)
+        st_t = torch.empty((B,), dtype=torch.int32, device=dev)
+        A, Bm, Cm, D = (np.ascontiguousarray(P[k], dtype=np.float64) for k in ("A", "B", "C", "D"))
+        pl = L.Plant(4, A.ctypes.data_as(L.c_double_p), Bm.ctypes.data_as(L.c_double_p), Cm.ctypes.data_as(L.c_double_p),
+                     D.ctypes.data_as(L.c_double_p))
+        L.check(lib.ddmpc_closed_loop(h, C.byref(pl), n_steps, 2, ptr(x_t), ptr(upl), ptr(ypl), ptr(w_t), ptr(us_t), ptr(ys_t),
+                                      ptr(st_t), L.MEM_DEVICE))
+        L.check(lib.ddmpc_synchronize(h)); torch.cuda.synchronize()
+        for a, b in zip(loop_h, (us_t, ys_t, st_t, x_t, upl, ypl)):
+            assert np.array_equal(np.asarray(a), b.cpu().numpy())
+    # stand-alone entry points
+    H_t = torch.empty((B, 34 * 2, 400 - 34 + 1), dtype=torch.float64, device=dev)
+    L.check(lib.ddmpc_hankel(ptr(tud), B, 400, 2, 34, ptr(H_t), L.MEM_DEVICE, 0)); torch.cuda.synchronize()
+    assert np.array_equal(H_t.cpu().numpy()[0], orc.hankel_matrix(u_d[0], 34))
+    r_t = torch.empty((B,), dtype=torch.float64, device=dev); r_h = np.empty((B,))
+    L.check(lib.ddmpc_pe_guard(ptr(tud), B, 400, 2, 38, ptr(r_t), L.MEM_DEVICE, 0)); torch.cuda.synchronize()
+    L.check(lib.ddmpc_pe_guard(C.c_void_p(u_d.ctypes.data), B, 400, 2, 38, C.c_void_p(r_h.ctypes.data), L.MEM_HOST, 0))
+    assert np.array_equal(r_t.cpu().numpy(), r_h)
