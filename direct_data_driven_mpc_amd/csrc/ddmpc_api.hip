@@ -145,6 +145,7 @@ struct ddmpc_handle {
   bool prepared = false;
   int closed_loop_path = DDMPC_PATH_AUTO;
   bool closed_loop_graph = false;
+  int n_free = 0;                          // weighted (free) components, nominal scheme: rows of the reduced normal matrix
   bool stamps_on = false;
   const double* last_up = nullptr;
   const double* last_yp = nullptr;
@@ -258,6 +259,9 @@ static int upload_params(ddmpc_handle* h) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->kp.tabd = (const double*)h->d_tabd.p;
   h->kp.tabi = (const int*)h->d_tabi.p;
+  h->n_free = 0;
+  for (int rho = 0; rho < k.r; ++rho)
+    if (ti[0 * RP + rho] == K_UFREE || ti[0 * RP + rho] == K_YFREE) ++h->n_free;
   h->kp.dense_w = 0;
   h->kp.dmat = nullptr;
   if (dense) {
@@ -550,10 +554,32 @@ static int launch_warm(ddmpc_handle* h, const double* up, const double* yp, doub
   return DDMPC_OK;
 }
 
+// Nominal scheme: instances whose Gram matrix is singular (exact data) are re-solved by the rank-revealing
+// kernel; it only touches instances the fast path marked SOLVER_ERROR.
+static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
+                                 int32_t* status, int32_t* iters) {
+  if (h->prm.controller_type != DDMPC_NOMINAL || h->prm.weight_kind == DDMPC_WEIGHT_DENSE) return DDMPC_OK;
+  const size_t r = (size_t)h->kp.r, nR = (size_t)h->n_free;
+  const size_t lds = (r * (r + 1) / 2 + nR * (nR + 1) / 2) * sizeof(double);
+  if (lds + 20 * 1024 > 160 * 1024) return DDMPC_OK;          // does not fit one workgroup: such instances keep their error status
+  HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_nominal_rr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(ddmpc_nominal_rr_kernel, dim3((unsigned)h->batch), dim3(256), lds, h->stream, h->kp, 16 * h->kc.NT,
+                     h->ud, h->yd, up, yp, uo, cost, (int*)status, (int*)iters, 1e-10, 1e-7);
+  HIP_TRY(hipGetLastError());
+  return DDMPC_OK;
+}
+
 typedef int (*launch_fn)(ddmpc_handle*, const double*, const double*, double*, double*, int32_t*, int32_t*);
 static int launch_cold_plain(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
                              int32_t* status, int32_t* iters) {
-  return launch_cold(h, up, yp, uo, cost, status, iters, nullptr);
+  int rc = launch_cold(h, up, yp, uo, cost, status, iters, nullptr);
+  return rc ? rc : launch_nominal_rescue(h, up, yp, uo, cost, status, iters);
+}
+
+static int launch_warm_plain(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
+                             int32_t* status, int32_t* iters) {
+  int rc = launch_warm(h, up, yp, uo, cost, status, iters);
+  return rc ? rc : launch_nominal_rescue(h, up, yp, uo, cost, status, iters);
 }
 
 static int solve_impl(ddmpc_handle* h, const double* u_past, const double* y_past, double* u_opt, double* cost,
@@ -731,7 +757,7 @@ int ddmpc_step(ddmpc_handle* h, const double* u_past, const double* y_past, doub
     int rc = ddmpc_prepare(h);
     if (rc) return rc;
   }
-  return solve_impl(h, u_past, y_past, u_opt, cost, status, iters, mem, &launch_warm);
+  return solve_impl(h, u_past, y_past, u_opt, cost, status, iters, mem, &launch_warm_plain);
 }
 
 int ddmpc_get_gain(ddmpc_handle* h, double* out, int mem) {
@@ -923,9 +949,18 @@ int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps
   }
   const bool warm_ok = warm_capable(h) && h->closed_loop_path != DDMPC_PATH_COLD &&
                        (size_t)n_mpc_step * m <= (size_t)WARM_MAX_NF && n * h->kp.nch <= WARM_MAX_NF;
-  const bool warm = warm_ok && !h->kp.convex;        // no inequality: fused loop, one launch
+  bool warm = warm_ok && !h->kp.convex;              // no inequality: fused loop, one launch
   const bool warm_box = warm_ok && h->kp.convex;     // slack box: per step, affine iterate + cold re-solve where a bound is active
   if (warm_box && (rc = ddmpc_prepare(h))) return rc;
+  if (warm && p.controller_type == DDMPC_NOMINAL) {
+    // nominal scheme: an instance with a singular Gram matrix (exact data) has no affine law; if there is one,
+    // run the per-step path, whose solves go through the rank-revealing rescue kernel
+    if ((rc = ddmpc_prepare(h))) return rc;
+    std::vector<int32_t> ps(B);
+    HIP_TRY(hipMemcpy(ps.data(), h->d_prep_status.p, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < B; ++i)
+      if (ps[i] != 0) { warm = false; break; }
+  }
   if (warm) {
     // affine control law: the whole loop of an instance runs inside one workgroup
     if ((rc = ddmpc_prepare(h))) return rc;
@@ -958,7 +993,7 @@ int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps
   auto enqueue_steps = [&]() -> int {
     for (int t = 0; !warm && t < n_steps; t += n_mpc_step) {
       int rcs = warm_box ? launch_warm(h, dup, dyp, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int32_t*)h->d_status.p, nullptr)
-                         : launch_cold(h, dup, dyp, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int32_t*)h->d_status.p, nullptr);
+                         : launch_cold_plain(h, dup, dyp, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int32_t*)h->d_status.p, nullptr);
       if (rcs) return rcs;
       const int nsub = (t + n_mpc_step <= n_steps) ? n_mpc_step : n_steps - t;
       hipLaunchKernelGGL(ddmpc_plant_kernel, dim3(pblocks), dim3(128), 0, h->stream, (long long)B, ns, m, pp, n,

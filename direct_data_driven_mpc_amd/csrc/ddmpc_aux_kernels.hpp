@@ -598,4 +598,217 @@ __global__ void ddmpc_pe_guard_kernel(const double* __restrict__ X, int N, int m
   }
 }
 
+// --------------------------------------------------------------------------
+// Rank-revealing solve of the NOMINAL scheme (controller.py:506-538,549-629,679-711) for instances whose
+// Gram matrix is singular -- exact (noise-free) data, where rank H = m(L+n) + n_sys < r and the plain
+// G beta = t of the cold kernel breaks down.  Only instances with status[b] == SOLVER_ERROR are processed.
+//
+//   order the components fixed-first:  G = [[G_FF, G_FR], [G_RF, G_RR]]   (F: hard values f, R: weighted)
+//   semi-definite Cholesky with skipped (numerically zero) pivots, G = L L'
+//   L_FF w = f  (consistency of the hard constraints is checked: otherwise "infeasible")
+//   z_R = z0 + C v,  z0 = L_RF w,  C = L_RR  (its columns span what is left of range(H))
+//   (C' W C) v = C' W (z_s - z0),  W = diag(weights)                  -> optimal_u = z on the free ubar rows
+//
+// Everything lives in LDS in packed lower storage ((i,j) at i(i+1)/2 + j): G (r rows) and the reduced normal
+// matrix T (nR rows); plain VALU code, one workgroup per instance.  A set-up-time / rescue path, not a
+// throughput kernel.  Diagonal weights only.
+// --------------------------------------------------------------------------
+__device__ __forceinline__ int tri_row(int e) {
+  int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+  while ((i + 1) * (i + 2) / 2 <= e) ++i;
+  while (i * (i + 1) / 2 > e) --i;
+  return i;
+}
+
+// in-place Cholesky of a packed lower matrix with `n` rows; pivots <= tol * dmax are skipped (column zeroed,
+// skip[k] = 1).  All threads of the workgroup must call it.
+__device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol_abs, int* skip, double* col) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int k = 0; k < n; ++k) {
+    const double dk = A[k * (k + 1) / 2 + k];
+    const bool sk = !(dk > tol_abs);                    // uniform: every thread reads the same value
+    if (tid == 0) skip[k] = sk ? 1 : 0;
+    const double inv = sk ? 0.0 : 1.0 / sqrt(dk);
+    for (int i = k + tid; i < n; i += nthr) col[i] = A[i * (i + 1) / 2 + k] * inv;
+    __syncthreads();
+    for (int i = k + tid; i < n; i += nthr) A[i * (i + 1) / 2 + k] = col[i];
+    if (!sk) {
+      const int nt = n - k - 1, ne = nt * (nt + 1) / 2;
+      for (int e = tid; e < ne; e += nthr) {
+        const int ii = tri_row(e), jj = e - ii * (ii + 1) / 2;
+        const int i = k + 1 + ii, j = k + 1 + jj;
+        A[i * (i + 1) / 2 + j] -= col[i] * col[j];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RPs, const double* __restrict__ u_d,
+                                                               const double* __restrict__ y_d,
+                                                               const double* __restrict__ u_past,
+                                                               const double* __restrict__ y_past,
+                                                               double* __restrict__ u_opt, double* __restrict__ cost,
+                                                               int* __restrict__ status, int* __restrict__ iters,
+                                                               double rank_tol, double feas_tol) {
+  extern __shared__ __attribute__((aligned(16))) double rsm[];
+  const long long b = blockIdx.x;
+  if (status[b] != 4) return;                           // uniform: only instances the fast path gave up on
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int r = P.r, m = P.m, p = P.p, nch = P.nch, c = P.c;
+  const int n = P.npu / m;
+  // LDS carve-up
+  double* G = rsm;                                      // r(r+1)/2
+  double* T = G + r * (r + 1) / 2;                      // up to r(r+1)/2 would be safe; sized nR(nR+1)/2 by the host
+  __shared__ int perm[WARM_MAX_R], skip[WARM_MAX_R], skipT[WARM_MAX_R];
+  __shared__ double fv[WARM_MAX_R], wv[WARM_MAX_R], zs[WARM_MAX_R], z0[WARM_MAX_R], vv[WARM_MAX_R], col[WARM_MAX_R];
+  __shared__ double red[8];
+  __shared__ int cnt[2];
+  const double* ud = u_d + b * (long long)P.N * m;
+  const double* yd = y_d + b * (long long)P.N * p;
+  const double* up = u_past + b * (long long)P.npu;
+  const double* yp = y_past + b * (long long)(n * p);
+  // ---- components, fixed first ------------------------------------------------------------
+  if (tid == 0) {
+    int nF = 0;
+    for (int rho = 0; rho < r; ++rho) {
+      const int kind = P.tabi[0 * RPs + rho];
+      if (kind == K_UFIX || kind == K_YFIX) {
+        const int pidx = P.tabi[1 * RPs + rho];
+        perm[nF] = rho;
+        fv[nF] = (pidx >= 0) ? ((pidx < P.npu) ? up[pidx] : yp[pidx - P.npu]) : P.tabd[2 * RPs + rho];
+        ++nF;
+      }
+    }
+    int nR = 0;
+    for (int rho = 0; rho < r; ++rho) {
+      const int kind = P.tabi[0 * RPs + rho];
+      if (kind == K_UFREE || kind == K_YFREE) {
+        perm[nF + nR] = rho;
+        wv[nR] = P.tabd[3 * RPs + rho];
+        zs[nR] = P.tabd[2 * RPs + rho];
+        ++nR;
+      }
+    }
+    cnt[0] = nF; cnt[1] = nR;
+  }
+  __syncthreads();
+  const int nF = cnt[0], nR = cnt[1];
+  // ---- Gram in the permuted order: G(i,j) = sum_t x_{perm i}[t] x_{perm j}[t] ----------------
+  const int npk = r * (r + 1) / 2;
+  for (int e = tid; e < npk; e += nthr) {
+    const int i = tri_row(e), j = e - i * (i + 1) / 2;
+    const int ri = perm[i], rj = perm[j];
+    const int ki = ri / nch, ci = ri - ki * nch, kj = rj / nch, cj = rj - kj * nch;
+    const double* xi = (ci < m) ? ud + (long long)ki * m + ci : yd + (long long)ki * p + (ci - m);
+    const double* xj = (cj < m) ? ud + (long long)kj * m + cj : yd + (long long)kj * p + (cj - m);
+    const int si = (ci < m) ? m : p, sj = (cj < m) ? m : p;
+    double s0 = 0.0, s1 = 0.0;
+    int t = 0;
+    for (; t + 1 < c; t += 2) { s0 += xi[t * si] * xj[t * sj]; s1 += xi[(t + 1) * si] * xj[(t + 1) * sj]; }
+    if (t < c) s0 += xi[t * si] * xj[t * sj];
+    G[e] = s0 + s1;
+  }
+  __syncthreads();
+  double dmx = 0.0;
+  for (int i = tid; i < r; i += nthr) dmx = fmax(dmx, G[i * (i + 1) / 2 + i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) dmx = fmax(dmx, __shfl_xor(dmx, off, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = dmx;
+  __syncthreads();
+  double dmax = 0.0;
+  for (int w = 0; w < (nthr >> 6); ++w) dmax = fmax(dmax, red[w]);
+  __syncthreads();
+  packed_psd_cholesky(G, r, rank_tol * dmax, skip, col);
+  // ---- hard constraints: L_FF w = f (skipped pivots carry no unknown); residual of the dependent rows ----
+  if (tid == 0) {
+    for (int k = 0; k < nF; ++k) {
+      double s = fv[k];
+      const double* Lk = G + k * (k + 1) / 2;
+      for (int j = 0; j < k; ++j) s -= Lk[j] * col[j];
+      col[k] = skip[k] ? 0.0 : s / Lk[k];
+      vv[k] = skip[k] ? fabs(s) : 0.0;                  // what a dependent constraint row is off by
+    }
+  }
+  __syncthreads();
+  double resid = 0.0, fmaxv = 1.0;
+  for (int k = 0; k < nF; ++k) { resid = fmax(resid, vv[k]); fmaxv = fmax(fmaxv, fabs(fv[k])); }
+  // ---- z0 = L_RF w ------------------------------------------------------------------------------
+  for (int i = tid; i < nR; i += nthr) {
+    const double* Li = G + (nF + i) * (nF + i + 1) / 2;
+    double s = 0.0;
+    for (int k = 0; k < nF; ++k) s += Li[k] * col[k];
+    z0[i] = s;
+  }
+  __syncthreads();
+  // ---- reduced normal equations T = C' W C, rhs = C' W (zs - z0), C(i,a) = L(nF+i, nF+a), i >= a ----
+  const int npt = nR * (nR + 1) / 2;
+  for (int e = tid; e < npt; e += nthr) {
+    const int a = tri_row(e), bb = e - a * (a + 1) / 2;                 // a >= bb
+    double s = 0.0;
+    if (!skip[nF + a] && !skip[nF + bb]) {
+      for (int i = a; i < nR; ++i) {
+        const double* Li = G + (nF + i) * (nF + i + 1) / 2 + nF;
+        s += Li[a] * wv[i] * Li[bb];
+      }
+    } else if (a == bb) {
+      s = 1.0;                                                        // a skipped direction: identity row, zero rhs
+    }
+    T[e] = s;
+  }
+  for (int a = tid; a < nR; a += nthr) {
+    double s = 0.0;
+    if (!skip[nF + a])
+      for (int i = a; i < nR; ++i) s += G[(nF + i) * (nF + i + 1) / 2 + nF + a] * wv[i] * (zs[i] - z0[i]);
+    vv[a] = s;
+  }
+  __syncthreads();
+  double tmx = 0.0;
+  for (int a = 0; a < nR; ++a) tmx = fmax(tmx, T[a * (a + 1) / 2 + a]);
+  packed_psd_cholesky(T, nR, 1e-14 * tmx, skipT, col);
+  // ---- T v = rhs by the factor (thread 0: nR <= 272, a few thousand multiply-adds) ---------------------
+  if (tid == 0) {
+    for (int a = 0; a < nR; ++a) {
+      double s = vv[a];
+      const double* Ta = T + a * (a + 1) / 2;
+      for (int j = 0; j < a; ++j) s -= Ta[j] * vv[j];
+      vv[a] = skipT[a] ? 0.0 : s / Ta[a];
+    }
+    for (int a = nR - 1; a >= 0; --a) {
+      double s = vv[a];
+      for (int i = a + 1; i < nR; ++i) s -= T[i * (i + 1) / 2 + a] * vv[i];
+      vv[a] = skipT[a] ? 0.0 : s / T[a * (a + 1) / 2 + a];
+    }
+  }
+  __syncthreads();
+  // ---- z_R = z0 + C v; outputs -------------------------------------------------------------------
+  double part = 0.0;
+  double* uo = u_opt + b * (long long)((P.Ln - n) * m);
+  for (int i = tid; i < nR; i += nthr) {
+    const double* Li = G + (nF + i) * (nF + i + 1) / 2 + nF;
+    double z = z0[i];
+    for (int a = 0; a <= i; ++a) z += Li[a] * vv[a];
+    const double dlt = z - zs[i];
+    part += wv[i] * dlt * dlt;
+    const int oidx = P.tabi[2 * RPs + perm[nF + i]];
+    if (oidx >= 0) uo[oidx] = z;
+  }
+  for (int k = tid; k < nF; k += nthr) {
+    const int oidx = P.tabi[2 * RPs + perm[k]];
+    if (oidx >= 0) uo[oidx] = fv[k];                    // terminal inputs are part of optimal_u
+  }
+  part = wave_sum(part);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = part;
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < (nthr >> 6); ++w) tot += red[w];
+    cost[b] = tot;
+    const bool feasible = resid <= feas_tol * fmaxv;
+    status[b] = !(fabs(tot) < 1e300) ? 4 : (feasible ? 0 : 2);      // 2 = "infeasible"
+    if (iters) iters[b] = 1;
+  }
+}
+
 }  // namespace ddmpc

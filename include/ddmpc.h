@@ -137,7 +137,10 @@ int ddmpc_set_data(ddmpc_handle* h, const double* u_d, const double* y_d, int me
  *   u_opt  [batch, L*m]  = ubar[n*m:]          (controller.py:799-805)
  *   cost   [batch]       = problem.value       (controller.py:778)
  *   status [batch] int32 DDMPC_STATUS_*        (controller.py:755)
- *   iters  [batch] int32 factorisations used (may be NULL) */
+ *   iters  [batch] int32 factorisations used (may be NULL)
+ * NOMINAL controllers: an instance whose Gram matrix is singular (noise-free data) is re-solved in the same
+ * call by a rank-revealing kernel; it comes back "optimal", or "infeasible" when the hard constraints cannot be
+ * met by any trajectory in the range of the Hankel matrix. */
 int ddmpc_solve(ddmpc_handle* h, const double* u_past, const double* y_past,
                 double* u_opt, double* cost, int32_t* status, int32_t* iters, int mem);
 

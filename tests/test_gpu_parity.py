@@ -200,8 +200,8 @@ def test_variables_and_kkt_certificate(gpu):
 
 
 def test_bad_instance_gets_status_not_exception(gpu):
-    # a constant (non-exciting) trajectory makes G singular: that instance must come back
-    # "solver_error" while its batch neighbours are solved normally
+    # a constant (non-exciting) trajectory makes G singular: that instance must come back with an error
+    # status while its batch neighbours are solved normally
     spec = orc.spec_from_params(controller_type=0)
     B = 4
     u_d, y_d, up, yp = _instances(B)
@@ -210,7 +210,9 @@ def test_bad_instance_gets_status_not_exception(gpu):
     with _engine(spec, 400, B) as eng:
         eng.set_data(u_d, y_d)
         u, cost, status, _ = eng.solve(up, yp)
-    assert L.STATUS_STRINGS[int(status[2])] == "solver_error"
+    # (the rank-revealing rescue kernel takes the singular instance: a constant trajectory cannot reach the
+    #  setpoint, so the QP is infeasible -- the status CVXPY would report)
+    assert L.STATUS_STRINGS[int(status[2])] == "infeasible"
     assert [int(s) for s in status[[0, 1, 3]]] == [0, 0, 0]
     assert np.max(np.abs(u[[0, 1, 3]] - 1.0)) < 1e-12
 
@@ -596,7 +598,7 @@ def test_warm_path_invalidation_and_bad_instance(gpu):
     with _engine(specn, 400, B) as eng:
         eng.set_data(u_d, y_d)
         u, cost, status, _ = eng.step(up, yp)
-    assert L.STATUS_STRINGS[int(status[2])] == "solver_error" and [int(s) for s in status[[0, 1, 3]]] == [0, 0, 0]
+    assert L.STATUS_STRINGS[int(status[2])] == "infeasible" and [int(s) for s in status[[0, 1, 3]]] == [0, 0, 0]
 
 
 @pytest.mark.parametrize("kw,n_mpc_step", [(dict(), 1), (dict(), 4), (dict(tec=False), 1), (dict(controller_type=0), 2),
@@ -838,8 +840,9 @@ def test_noise_free_data(gpu):
     # Exact LTI data: H has rank m(L+n) + n_sys = 72 of 136, the Gram matrix is singular.
     # Robust scheme: G + lam*D stays positive definite (D > 0 on every y component, the hard u rows are
     # independent for persistently exciting inputs) -> same parity as with noisy data.
-    # Nominal scheme: needs a rank-revealing solve the engine does not have -> every instance must come back
-    # "solver_error", never a silently wrong "optimal" (DESIGN.md section 9).
+    # Nominal scheme: the fast path breaks down and the rank-revealing rescue kernel takes over; with the example's
+    # rounded setpoint it must report "infeasible" (see test_nominal_scheme_on_exact_data_rank_revealing), never a
+    # silently wrong "optimal".
     from direct_data_driven_mpc_amd.harness import FOUR_TANK
     plant = dict(FOUR_TANK); plant["eps_max"] = 0.0
     B = 6
@@ -858,7 +861,8 @@ def test_noise_free_data(gpu):
         eng.set_data(d["u_d"], d["y_d"])
         u, cost, status, _ = eng.solve(up, yp)
         uw, cw, sw, _ = eng.step(up, yp)
-    assert all(L.STATUS_STRINGS[int(s)] == "solver_error" for s in status) and np.array_equal(sw, status)
+    # (rounded setpoint: the terminal equality is infeasible for exact data, which the rescue kernel detects)
+    assert all(L.STATUS_STRINGS[int(s)] == "infeasible" for s in status) and np.array_equal(sw, status)
 
 
 def test_closed_loop_graph_replay_matches_direct_launches(gpu):
@@ -1030,3 +1034,59 @@ def test_device_memory_variants_of_every_entry_point(gpu):
     L.check(lib.ddmpc_pe_guard(ptr(tud), B, 400, 2, 38, ptr(r_t), L.MEM_DEVICE, 0)); torch.cuda.synchronize()
     L.check(lib.ddmpc_pe_guard(C.c_void_p(u_d.ctypes.data), B, 400, 2, 38, C.c_void_p(r_h.ctypes.data), L.MEM_HOST, 0))
     assert np.array_equal(r_t.cpu().numpy(), r_h)
+
+
+def test_nominal_scheme_on_exact_data_rank_revealing(gpu):
+    # Exact LTI data: rank H = 72 of 136.  With a setpoint that is a true equilibrium the nominal QP is feasible
+    # and the rank-revealing rescue kernel must reproduce the SVD-based CPU solve (oracle/nominal_exact.py, an
+    # orthogonal-factorisation route that shares nothing with the Gram/Cholesky kernels); with the example's
+    # rounded setpoint the terminal equality cannot be met by any exact trajectory -> "infeasible".
+    from direct_data_driven_mpc_amd.harness import FOUR_TANK
+    from oracle.nominal_exact import solve_nominal_exact
+    plant = dict(FOUR_TANK); plant["eps_max"] = 0.0
+    B = 5
+    d = generate_batch(range(B), N=400, plant=plant)
+    up = d["u_d"][:, -4:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -4:, :].reshape(B, -1).copy()
+    A, Bm, Cm, D = (FOUR_TANK[k] for k in "ABCD")
+    spec = orc.spec_from_params(controller_type=0)
+    spec.y_s = (Cm @ np.linalg.inv(np.eye(4) - A) @ Bm + D) @ spec.u_s          # the model's equilibrium output for u_s
+    rng = np.random.default_rng(3)
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(d["u_d"], d["y_d"])
+        for trial in range(2):
+            if trial:       # another valid past window of the same plant: 4 steps further along a fresh trajectory
+                d2 = generate_batch(range(50, 50 + B), N=400, plant=plant)
+                up = d2["u_d"][:, -4:, :].reshape(B, -1).copy(); yp = d2["y_d"][:, -4:, :].reshape(B, -1).copy()
+            u, cost, status, iters = eng.solve(up, yp)
+            uw, cw, sw, _ = eng.step(up, yp)
+            for b in range(B):
+                ref = solve_nominal_exact(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
+                assert ref["status"] == "optimal" and L.STATUS_STRINGS[int(status[b])] == "optimal", (trial, b, ref["residual"])
+                assert np.max(np.abs(u[b] - ref["optimal_u"])) / np.max(np.abs(ref["optimal_u"])) < 1e-8, (trial, b)
+                assert abs(cost[b] - ref["cost"]) <= 1e-8 * max(abs(ref["cost"]), 1e-6)
+            assert np.array_equal(uw, u) and np.array_equal(sw, status)
+    spec = orc.spec_from_params(controller_type=0)                               # y_s = (0.65, 0.77): not an equilibrium
+    up = d["u_d"][:, -4:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -4:, :].reshape(B, -1).copy()
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(d["u_d"], d["y_d"])
+        u, cost, status, _ = eng.solve(up, yp)
+    assert all(L.STATUS_STRINGS[int(s)] == "infeasible" for s in status)
+    assert solve_nominal_exact(spec, d["u_d"][0], d["y_d"][0], up[0], yp[0])["status"] == "infeasible"
+
+
+def test_nominal_closed_loop_on_exact_data(gpu):
+    # the nominal scheme driving a noise-free plant from exact data (the basic scheme of the paper): every
+    # solve goes through the rescue kernel; the loop must settle at the equilibrium setpoint
+    from direct_data_driven_mpc_amd.harness import FOUR_TANK
+    plant = dict(FOUR_TANK); plant["eps_max"] = 0.0
+    B, n_steps = 4, 120
+    d = generate_batch(range(B), N=400, plant=plant)
+    A, Bm, Cm, D = (FOUR_TANK[k] for k in "ABCD")
+    spec = orc.spec_from_params(controller_type=0)
+    spec.y_s = (Cm @ np.linalg.inv(np.eye(4) - A) @ Bm + D) @ spec.u_s
+    up = d["u_d"][:, -4:, :].reshape(B, -1); yp = d["y_d"][:, -4:, :].reshape(B, -1)
+    with _engine(spec, 400, B) as eng:
+        eng.set_data(d["u_d"], d["y_d"])
+        u_sys, y_sys, status, *_ = eng.closed_loop(A, Bm, Cm, D, d["x_end"], up, yp, np.zeros((B, n_steps, 2)), n_mpc_step=1)
+    assert np.all(status == 0)
+    assert np.max(np.abs(y_sys[:, -1, :] - spec.y_s)) < 1e-3 and np.max(np.abs(u_sys[:, -1, :] - spec.u_s)) < 1e-2
