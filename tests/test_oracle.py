@@ -134,3 +134,28 @@ def test_closed_loop_converges_to_setpoint():
     assert np.allclose(u_sys[0], [21.22188171, 20.30350327], atol=5e-9)
     assert np.all(np.abs(y_sys[-1] - spec.y_s) < 0.03)
     assert np.all(np.abs(u_sys[-1] - spec.u_s) < 0.2)
+
+
+def test_nominal_exact_oracle():
+    # oracle/nominal_exact.py (SVD route for rank-deficient data) against the cases with an independent answer:
+    # full-row-rank noisy data -> u = u_s, cost 0; exact data + rounded setpoint -> infeasible, and its least-squares
+    # compromise is what the full-space minimum-norm KKT solve returns; exact data + equilibrium setpoint -> optimal
+    from oracle.nominal_exact import solve_nominal_exact
+    from direct_data_driven_mpc_amd.harness import FOUR_TANK, generate_batch
+    spec = orc.spec_from_params(controller_type=0)
+    inst = orc.generate_instance(0)
+    up = inst["u_d"][-4:].reshape(-1); yp = inst["y_d"][-4:].reshape(-1)
+    r = solve_nominal_exact(spec, inst["u_d"], inst["y_d"], up, yp)
+    assert r["status"] == "optimal" and r["rank"] == 136
+    assert np.max(np.abs(r["optimal_u"] - np.tile(spec.u_s, spec.L))) < 1e-9 and abs(r["cost"]) < 1e-12
+    plant = dict(FOUR_TANK); plant["eps_max"] = 0.0
+    d = generate_batch([0], N=400, plant=plant)
+    up = d["u_d"][0, -4:].reshape(-1); yp = d["y_d"][0, -4:].reshape(-1)
+    r = solve_nominal_exact(spec, d["u_d"][0], d["y_d"][0], up, yp)
+    assert r["status"] == "infeasible" and r["rank"] == 72 and 1e-6 < r["residual"] < 1e-3
+    full = orc.solve_fullspace(spec, d["u_d"][0], d["y_d"][0], up, yp)
+    assert np.max(np.abs(r["optimal_u"] - full.optimal_u)) / np.max(np.abs(full.optimal_u)) < 1e-6
+    A, Bm, Cm, D = (FOUR_TANK[k] for k in "ABCD")
+    spec.y_s = (Cm @ np.linalg.inv(np.eye(4) - A) @ Bm + D) @ spec.u_s
+    r = solve_nominal_exact(spec, d["u_d"][0], d["y_d"][0], up, yp)
+    assert r["status"] == "optimal" and r["residual"] < 1e-12 and r["cost"] > 0.1
