@@ -140,7 +140,7 @@ struct ddmpc_handle {
   // warm path: per-instance affine law (ddmpc_prepare)
   DevBuf d_lfac, d_lfacT, d_gain, d_prep_status, d_zero, d_need;
   // host-pointer solves: one packed device buffer and its pinned host mirror (two copies per solve instead of six)
-  DevBuf d_io;
+  DevBuf d_io, d_rr;
   HostBuf h_io;
   bool prepared = false;
   int closed_loop_path = DDMPC_PATH_AUTO;
@@ -459,7 +459,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -560,11 +560,22 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
                                  int32_t* status, int32_t* iters) {
   if (h->prm.controller_type != DDMPC_NOMINAL || h->prm.weight_kind == DDMPC_WEIGHT_DENSE) return DDMPC_OK;
   const size_t r = (size_t)h->kp.r, nR = (size_t)h->n_free;
-  const size_t lds = (r * (r + 1) / 2 + nR * (nR + 1) / 2) * sizeof(double);
-  if (lds + 20 * 1024 > 160 * 1024) return DDMPC_OK;          // does not fit one workgroup: such instances keep their error status
-  HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_nominal_rr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t ndbl = r * (r + 1) / 2 + nR * (nR + 1) / 2;
+  size_t lds = ndbl * sizeof(double);
+  double* scratch = nullptr;
+  if (lds + 20 * 1024 > 160 * 1024) {                         // too big for LDS: per-instance slices of a global workspace
+    int rc = h->d_rr.ensure((size_t)h->batch * ndbl * sizeof(double));
+    if (rc) return rc;
+    scratch = (double*)h->d_rr.p;
+    lds = 0;
+  }
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_nominal_rr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // rank tolerance 1e-8 (relative to the largest diagonal entry of the Gram): with the fixed-first ordering the
+  // pivots of dependent rows come out as rounding residue up to ~3e-10, genuine ones are >= ~5e-7 on exact
+  // four-tank data (L = 10 .. 60)
   hipLaunchKernelGGL(ddmpc_nominal_rr_kernel, dim3((unsigned)h->batch), dim3(256), lds, h->stream, h->kp, 16 * h->kc.NT,
-                     h->ud, h->yd, up, yp, uo, cost, (int*)status, (int*)iters, 1e-10, 1e-7);
+                     h->ud, h->yd, up, yp, uo, cost, (int*)status, (int*)iters, 1e-8, 1e-7, scratch, (long long)ndbl);
   HIP_TRY(hipGetLastError());
   return DDMPC_OK;
 }

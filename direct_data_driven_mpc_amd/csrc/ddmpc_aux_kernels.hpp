@@ -609,8 +609,8 @@ __global__ void ddmpc_pe_guard_kernel(const double* __restrict__ X, int N, int m
 //   z_R = z0 + C v,  z0 = L_RF w,  C = L_RR  (its columns span what is left of range(H))
 //   (C' W C) v = C' W (z_s - z0),  W = diag(weights)                  -> optimal_u = z on the free ubar rows
 //
-// Everything lives in LDS in packed lower storage ((i,j) at i(i+1)/2 + j): G (r rows) and the reduced normal
-// matrix T (nR rows); plain VALU code, one workgroup per instance.  A set-up-time / rescue path, not a
+// Packed lower storage ((i,j) at i(i+1)/2 + j) for G (r rows) and the reduced normal matrix T (nR rows), in LDS
+// when they fit (four-tank size), else in a global workspace; plain VALU code, one workgroup per instance.  A set-up-time / rescue path, not a
 // throughput kernel.  Diagonal weights only.
 // --------------------------------------------------------------------------
 __device__ __forceinline__ int tri_row(int e) {
@@ -650,10 +650,14 @@ __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RP
                                                                const double* __restrict__ y_past,
                                                                double* __restrict__ u_opt, double* __restrict__ cost,
                                                                int* __restrict__ status, int* __restrict__ iters,
-                                                               double rank_tol, double feas_tol) {
-  extern __shared__ __attribute__((aligned(16))) double rsm[];
+                                                               double rank_tol, double feas_tol, double* scratch,
+                                                               long long scratch_stride) {
+  extern __shared__ __attribute__((aligned(16))) double rsm_lds[];
   const long long b = blockIdx.x;
   if (status[b] != 4) return;                           // uniform: only instances the fast path gave up on
+  // the two packed matrices live in LDS when they fit, else in a per-instance slice of a global workspace
+  // (same code, L2 instead of LDS; __syncthreads orders global accesses within the workgroup)
+  double* rsm = scratch ? scratch + b * scratch_stride : rsm_lds;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int r = P.r, m = P.m, p = P.p, nch = P.nch, c = P.c;
   const int n = P.npu / m;
