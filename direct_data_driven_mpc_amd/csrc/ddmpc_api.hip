@@ -884,31 +884,38 @@ int ddmpc_pe_guard(const double* u_d, int64_t batch, int32_t N, int32_t m, int32
     return fail(DDMPC_ERR_INVALID, "mem must be DDMPC_MEM_HOST or DDMPC_MEM_DEVICE");
   if (ddmpc_device_count() <= 0) return fail(DDMPC_ERR_NO_DEVICE, "no HIP device visible (the engine has no CPU fallback)");
   const long long r = (long long)m * order;
-  const size_t lds = (size_t)(r * (r + 1) / 2 + r + 64) * sizeof(double);
-  if (lds > 160 * 1024 - 64)
-    return fail(DDMPC_ERR_UNSUPPORTED, "pe guard: m*order = %lld rows do not fit one workgroup's LDS", r);
+  const size_t ndbl = (size_t)(r * (r + 1) / 2 + r + 64);
+  size_t lds = ndbl * sizeof(double);
   HIP_TRY(hipSetDevice(device));
-  HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_pe_guard_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if (mem == DDMPC_MEM_DEVICE) {
-    hipLaunchKernelGGL(ddmpc_pe_guard_kernel, dim3((unsigned)batch), dim3(256), lds, 0, u_d, N, m, order, ratio_lb);
-    HIP_TRY(hipGetLastError());
-    return DDMPC_OK;
+  double* scratch = nullptr;                                  // packed matrix too large for LDS: global workspace
+  if (lds > 160 * 1024 - 64) {
+    HIP_TRY(hipMalloc((void**)&scratch, (size_t)batch * ndbl * sizeof(double)));
+    lds = 0;
   }
-  const size_t nx = (size_t)batch * N * m * sizeof(double);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_pe_guard_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipError_t e = hipSuccess;
   double *dX = nullptr, *dR = nullptr;
-  HIP_TRY(hipMalloc((void**)&dX, nx));
-  if (hipMalloc((void**)&dR, (size_t)batch * sizeof(double)) != hipSuccess) {
-    (void)hipFree(dX);
-    return fail(DDMPC_ERR_HIP, "hipMalloc failed");
-  }
-  hipError_t e = hipMemcpy(dX, u_d, nx, hipMemcpyHostToDevice);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(ddmpc_pe_guard_kernel, dim3((unsigned)batch), dim3(256), lds, 0, dX, N, m, order, dR);
+  const size_t nx = (size_t)batch * N * m * sizeof(double);
+  if (mem == DDMPC_MEM_DEVICE) {
+    hipLaunchKernelGGL(ddmpc_pe_guard_kernel, dim3((unsigned)batch), dim3(256), lds, 0, u_d, N, m, order, ratio_lb, scratch,
+                       (long long)ndbl);
     e = hipGetLastError();
+    if (e == hipSuccess && scratch) e = hipDeviceSynchronize();          // the workspace is released below
+  } else {
+    e = hipMalloc((void**)&dX, nx);
+    if (e == hipSuccess) e = hipMalloc((void**)&dR, (size_t)batch * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(dX, u_d, nx, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(ddmpc_pe_guard_kernel, dim3((unsigned)batch), dim3(256), lds, 0, dX, N, m, order, dR, scratch,
+                         (long long)ndbl);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(ratio_lb, dR, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost);
   }
-  if (e == hipSuccess) e = hipMemcpy(ratio_lb, dR, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost);
-  (void)hipFree(dX);
-  (void)hipFree(dR);
+  if (dX) (void)hipFree(dX);
+  if (dR) (void)hipFree(dR);
+  if (scratch) (void)hipFree(scratch);
   if (e != hipSuccess) return fail(DDMPC_ERR_HIP, "ddmpc_pe_guard: %s", hipGetErrorString(e));
   return DDMPC_OK;
 }

@@ -512,12 +512,14 @@ __global__ void ddmpc_closed_loop_warm_kernel(KParams P, int RPs, int nf, const 
 // is left to the exact SVD test on the host.  Packed lower storage: (i,j) at i(i+1)/2 + j.
 // --------------------------------------------------------------------------
 __global__ void ddmpc_pe_guard_kernel(const double* __restrict__ X, int N, int m, int order,
-                                      double* __restrict__ ratio_lb) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
+                                      double* __restrict__ ratio_lb, double* scratch, long long scratch_stride) {
+  extern __shared__ __attribute__((aligned(16))) double sm_lds[];
   const long long b = blockIdx.x;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int r = m * order, c = N - order + 1;
   const int npk = r * (r + 1) / 2;
+  // the packed matrix lives in LDS when it fits, else in a per-instance slice of a global workspace
+  double* sm = scratch ? scratch + b * scratch_stride : sm_lds;
   double* G = sm;                 // packed lower, r(r+1)/2
   double* col = sm + npk;         // r
   double* red = col + r;          // 64

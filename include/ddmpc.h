@@ -198,7 +198,8 @@ int ddmpc_hankel(const double* X, int64_t batch, int32_t N, int32_t nch, int32_t
  * Cholesky factorisation of its Gram matrix (0 when the factorisation breaks down).  A bound well
  * above the SVD tolerance max(M,N)*eps certifies full rank on the device; the caller runs the exact
  * SVD test only on the instances it leaves undecided (see BatchedDDMPC.persistent_excitation_guard).
- * Stand-alone (no handle).  DDMPC_ERR_UNSUPPORTED when m*order rows exceed one workgroup's LDS. */
+ * Stand-alone (no handle).  The packed Gram matrix lives in LDS when it fits (m*order <= ~190 rows), else in
+ * a temporary global workspace. */
 int ddmpc_pe_guard(const double* u_d, int64_t batch, int32_t N, int32_t m, int32_t order,
                    double* ratio_lb, int mem, int device);
 
