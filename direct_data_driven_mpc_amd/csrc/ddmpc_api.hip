@@ -145,6 +145,7 @@ struct ddmpc_handle {
   bool prepared = false;
   int closed_loop_path = DDMPC_PATH_AUTO;
   bool closed_loop_graph = false;
+  bool large_nominal = false;              // r beyond the cold kernels: NOMINAL controllers run on the rank-revealing kernel alone
   int n_free = 0;                          // weighted (free) components, nominal scheme: rows of the reduced normal matrix
   bool stamps_on = false;
   const double* last_up = nullptr;
@@ -415,16 +416,40 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
         if (cand.NT == kc->NT && cand.W == want) { kc = &cand; break; }
     }
   }
+  static const KernelChoice kLargeNominal = {0, 4, nullptr, "ddmpc_nominal_rr_kernel", 0};
   if (!kc) {
-    delete h;
-    return fail(DDMPC_ERR_UNSUPPORTED, "problem too large for the single-workgroup kernels: (m+p)(L+n) = %d rows", k.r);
+    // No register-resident kernel holds this many rows.  A NOMINAL controller with diagonal weights can still be
+    // served by the rank-revealing kernel with its matrices in a global workspace (slow, and accurate only to the
+    // extent the Gram route allows at that size: DESIGN.md section 9); everything else is unsupported.
+    if (p.controller_type != DDMPC_NOMINAL || p.weight_kind == DDMPC_WEIGHT_DENSE) {
+      delete h;
+      return fail(DDMPC_ERR_UNSUPPORTED, "problem too large for the single-workgroup kernels: (m+p)(L+n) = %d rows", k.r);
+    }
+    h->large_nominal = true;
+    h->kc = kLargeNominal;
+    h->kc.NT = (rows_needed + 15) / 16;
+  } else {
+    h->kc = *kc;
   }
-  h->kc = *kc;
+  if (h->large_nominal) {
+    k.xs_len = 0;
+    h->lds_bytes = 0;
+    if (hipSetDevice(device) != hipSuccess) { delete h; return fail(DDMPC_ERR_HIP, "hipSetDevice(%d) failed", device); }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete h;
+      return fail(DDMPC_ERR_HIP, "hipStreamCreate failed");
+    }
+    h->own_stream = true;
+    int rcl = upload_params(h);
+    if (rcl) { ddmpc_destroy(h); return rcl; }
+    *out = h;
+    return DDMPC_OK;
+  }
   // dense-Gram operand reads reach (c+2)*nch + 16*NT; the structured walks read up to
   // x[c + 4*NT + 2]; everything past N*nch is zero padding
-  k.xs_len = ((p.N - k.Ln + 4) * k.nch + 16 * kc->NT + 8 + 64 + 1) & ~1;   // + lag groups past Ln in the 4x4x4 base loop
+  k.xs_len = ((p.N - k.Ln + 4) * k.nch + 16 * h->kc.NT + 8 + 64 + 1) & ~1;   // + lag groups past Ln in the 4x4x4 base loop
   if (k.xs_len < (p.N + 2) * k.nch) k.xs_len = ((p.N + 2) * k.nch + 1) & ~1;
-  const size_t lds_doubles = lds_doubles_for(kc->NT, k.xs_len);
+  const size_t lds_doubles = lds_doubles_for(h->kc.NT, k.xs_len);
   h->lds_bytes = lds_doubles * sizeof(double);
   if (const char* pad = getenv("DDMPC_LDS_PAD")) {        // development knob: extra LDS bytes to lower the occupancy
     const long v = atol(pad);
@@ -515,6 +540,10 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
                        int32_t* status, int32_t* iters, double* lfac = nullptr, const int* only = nullptr,
                        const KParams* kp_override = nullptr) {
   int rc;
+  if (h->large_nominal) {          // no cold kernel at this size: every instance goes to the rank-revealing kernel
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)status, 4, (size_t)h->batch, h->stream));
+    return DDMPC_OK;
+  }
   if ((rc = h->d_beta.ensure((size_t)h->batch * h->kp.rE * sizeof(double)))) return rc;
   if ((rc = h->d_act.ensure((size_t)h->batch * h->kp.rE))) return rc;
   dim3 grid((unsigned)h->batch), block(64 * h->kc.W);
@@ -561,13 +590,15 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
   if (h->prm.controller_type != DDMPC_NOMINAL || h->prm.weight_kind == DDMPC_WEIGHT_DENSE) return DDMPC_OK;
   const size_t r = (size_t)h->kp.r, nR = (size_t)h->n_free;
   const size_t ndbl = r * (r + 1) / 2 + nR * (nR + 1) / 2;
-  size_t lds = ndbl * sizeof(double);
+  const size_t rv = (r + 1) & ~(size_t)1;
+  const size_t vec_bytes = 6 * rv * sizeof(double) + 3 * rv * sizeof(int);       // the kernel's r-vectors, always in LDS
+  size_t lds = vec_bytes + ndbl * sizeof(double);
   double* scratch = nullptr;
-  if (lds + 20 * 1024 > 160 * 1024) {                         // too big for LDS: per-instance slices of a global workspace
+  if (lds + 1024 > 160 * 1024) {                              // matrices too big for LDS: per-instance slices of a global workspace
     int rc = h->d_rr.ensure((size_t)h->batch * ndbl * sizeof(double));
     if (rc) return rc;
     scratch = (double*)h->d_rr.p;
-    lds = 0;
+    lds = vec_bytes;
   }
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_nominal_rr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -650,6 +681,10 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
   if (!h || !u_d || !y_d || !u_past || !y_past || !u_opt || !cost || !status)
     return fail(DDMPC_ERR_INVALID, "null argument");
   if (h->batch > 0x7fffffffLL) return fail(DDMPC_ERR_INVALID, "batch too large for one launch");
+  if (h->large_nominal) {                         // no chunked cold launches at this size: plain upload + solve
+    int rcs = ddmpc_set_data(h, u_d, y_d, DDMPC_MEM_HOST);
+    return rcs ? rcs : ddmpc_solve(h, u_past, y_past, u_opt, cost, status, iters, DDMPC_MEM_HOST);
+  }
   HIP_TRY(hipSetDevice(h->device));
   const ddmpc_params& p = h->prm;
   const size_t B = (size_t)h->batch;
@@ -712,6 +747,7 @@ int ddmpc_prepare(ddmpc_handle* h) {
   if (!h->have_data) return fail(DDMPC_ERR_NOT_READY, "ddmpc_set_data must be called before ddmpc_prepare");
   if (h->batch > 0x7fffffffLL) return fail(DDMPC_ERR_INVALID, "batch too large for one launch");
   if (h->prepared) return DDMPC_OK;
+  if (h->large_nominal) return DDMPC_OK;          // no affine law is formed at this size: every step is a full solve
   HIP_TRY(hipSetDevice(h->device));
   const ddmpc_params& p = h->prm;
   const KParams& k = h->kp;
@@ -764,6 +800,7 @@ int ddmpc_step(ddmpc_handle* h, const double* u_past, const double* y_past, doub
                int32_t* status, int32_t* iters, int mem) {
   if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
   if (!h->have_data) return fail(DDMPC_ERR_NOT_READY, "ddmpc_set_data must be called before ddmpc_step");
+  if (h->large_nominal) return solve_impl(h, u_past, y_past, u_opt, cost, status, iters, mem, &launch_cold_plain);
   if (!h->prepared) {
     int rc = ddmpc_prepare(h);
     if (rc) return rc;
@@ -773,6 +810,7 @@ int ddmpc_step(ddmpc_handle* h, const double* u_past, const double* y_past, doub
 
 int ddmpc_get_gain(ddmpc_handle* h, double* out, int mem) {
   if (!h || !out) return fail(DDMPC_ERR_INVALID, "null argument");
+  if (h->large_nominal) return fail(DDMPC_ERR_UNSUPPORTED, "no affine law at this problem size");
   if (!h->prepared) return fail(DDMPC_ERR_NOT_READY, "ddmpc_prepare must be called before ddmpc_get_gain");
   HIP_TRY(hipSetDevice(h->device));
   const size_t bytes = (size_t)h->batch * (h->prm.n * h->kp.nch + 1) * h->kp.r * sizeof(double);
@@ -813,6 +851,7 @@ int ddmpc_set_setpoints(ddmpc_handle* h, const double* u_s, const double* y_s) {
 int ddmpc_get_solution(ddmpc_handle* h, int what, double* out, int mem) {
   if (!h || !out) return fail(DDMPC_ERR_INVALID, "null argument");
   if (!h->solved) return fail(DDMPC_ERR_NOT_READY, "no solve to read a solution from");
+  if (h->large_nominal) return fail(DDMPC_ERR_UNSUPPORTED, "variables are not reconstructed at this problem size");
   HIP_TRY(hipSetDevice(h->device));
   const KParams& k = h->kp;
   size_t per = 0;
@@ -967,7 +1006,7 @@ int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps
   }
   const bool warm_ok = warm_capable(h) && h->closed_loop_path != DDMPC_PATH_COLD &&
                        (size_t)n_mpc_step * m <= (size_t)WARM_MAX_NF && n * h->kp.nch <= WARM_MAX_NF;
-  bool warm = warm_ok && !h->kp.convex;              // no inequality: fused loop, one launch
+  bool warm = warm_ok && !h->kp.convex && !h->large_nominal;   // no inequality: fused loop, one launch
   const bool warm_box = warm_ok && h->kp.convex;     // slack box: per step, affine iterate + cold re-solve where a bound is active
   if (warm_box && (rc = ddmpc_prepare(h))) return rc;
   if (warm && p.controller_type == DDMPC_NOMINAL) {

@@ -657,17 +657,25 @@ __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RP
   extern __shared__ __attribute__((aligned(16))) double rsm_lds[];
   const long long b = blockIdx.x;
   if (status[b] != 4) return;                           // uniform: only instances the fast path gave up on
-  // the two packed matrices live in LDS when they fit, else in a per-instance slice of a global workspace
-  // (same code, L2 instead of LDS; __syncthreads orders global accesses within the workgroup)
-  double* rsm = scratch ? scratch + b * scratch_stride : rsm_lds;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int r = P.r, m = P.m, p = P.p, nch = P.nch, c = P.c;
   const int n = P.npu / m;
-  // LDS carve-up
+  // dynamic LDS: six r-vectors of doubles and three of ints first, then -- when they fit -- the two packed
+  // matrices; otherwise the matrices live in a per-instance slice of a global workspace (same code, L2 instead of
+  // LDS; __syncthreads orders global accesses within the workgroup)
+  const int rv = (r + 1) & ~1;
+  double* fv = rsm_lds;
+  double* wv = fv + rv;
+  double* zs = wv + rv;
+  double* z0 = zs + rv;
+  double* vv = z0 + rv;
+  double* col = vv + rv;
+  int* perm = reinterpret_cast<int*>(col + rv);
+  int* skip = perm + rv;
+  int* skipT = skip + rv;
+  double* rsm = scratch ? scratch + b * scratch_stride : reinterpret_cast<double*>(skipT + rv);
   double* G = rsm;                                      // r(r+1)/2
-  double* T = G + r * (r + 1) / 2;                      // up to r(r+1)/2 would be safe; sized nR(nR+1)/2 by the host
-  __shared__ int perm[WARM_MAX_R], skip[WARM_MAX_R], skipT[WARM_MAX_R];
-  __shared__ double fv[WARM_MAX_R], wv[WARM_MAX_R], zs[WARM_MAX_R], z0[WARM_MAX_R], vv[WARM_MAX_R], col[WARM_MAX_R];
+  double* T = G + r * (r + 1) / 2;                      // nR(nR+1)/2
   __shared__ double red[8];
   __shared__ int cnt[2];
   const double* ud = u_d + b * (long long)P.N * m;

@@ -115,7 +115,11 @@ const char* ddmpc_last_error(void);
 /* Number of visible HIP devices (0 if none); never fails. */
 int ddmpc_device_count(void);
 
-/* Replaces DirectDataDrivenMPCController.__init__ parameter validation
+/* Problem sizes: (m+p)(L+n) <= 271 rows run on the register-resident cold-solve kernels (all schemes).  Beyond
+ * that only NOMINAL controllers with scalar/diagonal weights are accepted: they run on the rank-revealing kernel
+ * alone (correct but slow; no gain, no variable reconstruction); anything else is DDMPC_ERR_UNSUPPORTED.
+ *
+ * Replaces DirectDataDrivenMPCController.__init__ parameter validation
  * (controller.py:165-168,211-222,298-343,664-670) for a batch of instances on
  * HIP device `device`.  Does not solve. */
 int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_handle** out);
