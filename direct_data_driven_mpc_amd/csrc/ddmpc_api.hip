@@ -606,7 +606,9 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
   // pivots of dependent rows come out as rounding residue up to ~3e-10, genuine ones are >= ~5e-7 on exact
   // four-tank data (L = 10 .. 60)
   hipLaunchKernelGGL(ddmpc_nominal_rr_kernel, dim3((unsigned)h->batch), dim3(256), lds, h->stream, h->kp, 16 * h->kc.NT,
-                     h->ud, h->yd, up, yp, uo, cost, (int*)status, (int*)iters, 1e-8, 1e-7, scratch, (long long)ndbl);
+                     h->ud, h->yd, up, yp, uo, cost, (int*)status, (int*)iters, 1e-8, 1e-7, scratch, (long long)ndbl,
+                     (h->stamps_on && h->d_stamps.bytes >= (size_t)h->batch * 8 * sizeof(uint64_t)) ? (unsigned long long*)h->d_stamps.p
+                                                                                                      : (unsigned long long*)nullptr);
   HIP_TRY(hipGetLastError());
   return DDMPC_OK;
 }

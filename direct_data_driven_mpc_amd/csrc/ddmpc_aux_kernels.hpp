@@ -635,15 +635,36 @@ __device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol
     __syncthreads();
     for (int i = k + tid; i < n; i += nthr) A[i * (i + 1) / 2 + k] = col[i];
     if (!sk) {
-      const int nt = n - k - 1, ne = nt * (nt + 1) / 2;
-      for (int e = tid; e < ne; e += nthr) {
-        const int ii = tri_row(e), jj = e - ii * (ii + 1) / 2;
-        const int i = k + 1 + ii, j = k + 1 + jj;
-        A[i * (i + 1) / 2 + j] -= col[i] * col[j];
+      // trailing update, one packed row per thread-iteration (rows dealt cyclically: their lengths differ)
+      // (eight elements are loaded before any is stored: when A is in global memory the loop is otherwise one
+      //  exposed L2 round trip per element)
+      for (int i = k + 1 + tid; i < n; i += nthr) {
+        double* Ai = A + i * (i + 1) / 2;
+        const double ci = col[i];
+        int j = k + 1;
+        for (; j + 8 <= i + 1; j += 8) {
+          double v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = Ai[j + q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) Ai[j + q] = v[q] - ci * col[j + q];
+        }
+        for (; j <= i; ++j) Ai[j] -= ci * col[j];
       }
     }
     __syncthreads();
   }
+}
+
+// Sum of one value per thread over the workgroup (all threads get it); `red` holds >= nthr/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+  return t;
 }
 
 __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RPs, const double* __restrict__ u_d,
@@ -653,7 +674,7 @@ __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RP
                                                                double* __restrict__ u_opt, double* __restrict__ cost,
                                                                int* __restrict__ status, int* __restrict__ iters,
                                                                double rank_tol, double feas_tol, double* scratch,
-                                                               long long scratch_stride) {
+                                                               long long scratch_stride, unsigned long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) double rsm_lds[];
   const long long b = blockIdx.x;
   if (status[b] != 4) return;                           // uniform: only instances the fast path gave up on
@@ -708,22 +729,56 @@ __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RP
   }
   __syncthreads();
   const int nF = cnt[0], nR = cnt[1];
+  if (dbg && tid == 0) dbg[b * 8 + 0] = __builtin_amdgcn_s_memrealtime();
   // ---- Gram in the permuted order: G(i,j) = sum_t x_{perm i}[t] x_{perm j}[t] ----------------
+  // Hankel structure (as in the cold kernel): with components (k, a) = (time offset, channel),
+  //   G((k+d, a), (k, b)) = C_d(a,b) + sum_{j<k} ( x_a[j+c+d] x_b[j+c] - x_a[j+d] x_b[j] ),   C_d(a,b) = sum_{t<c} x_a[t+d] x_b[t],
+  // so only the Ln*nch^2 lag sums need the full length-c dot product (cfg 5: 19 M instead of 363 M multiply-adds).
+  // The lag table borrows the (not yet used) storage of T; if it does not fit there, plain dot products are used.
   const int npk = r * (r + 1) / 2;
-  for (int e = tid; e < npk; e += nthr) {
-    const int i = tri_row(e), j = e - i * (i + 1) / 2;
-    const int ri = perm[i], rj = perm[j];
-    const int ki = ri / nch, ci = ri - ki * nch, kj = rj / nch, cj = rj - kj * nch;
-    const double* xi = (ci < m) ? ud + (long long)ki * m + ci : yd + (long long)ki * p + (ci - m);
-    const double* xj = (cj < m) ? ud + (long long)kj * m + cj : yd + (long long)kj * p + (cj - m);
-    const int si = (ci < m) ? m : p, sj = (cj < m) ? m : p;
-    double s0 = 0.0, s1 = 0.0;
-    int t = 0;
-    for (; t + 1 < c; t += 2) { s0 += xi[t * si] * xj[t * sj]; s1 += xi[(t + 1) * si] * xj[(t + 1) * sj]; }
-    if (t < c) s0 += xi[t * si] * xj[t * sj];
-    G[e] = s0 + s1;
+  auto xat = [&](int a, int t) -> double { return (a < m) ? ud[(long long)t * m + a] : yd[(long long)t * p + (a - m)]; };
+  const int nlag = P.Ln * nch * nch;
+  if (nlag <= nR * (nR + 1) / 2) {
+    double* Ctab = T;
+    for (int e = tid; e < nlag; e += nthr) {
+      const int d = e / (nch * nch), ab = e - d * nch * nch, a = ab / nch, bb = ab - a * nch;
+      const double* xa = (a < m) ? ud + (long long)d * m + a : yd + (long long)d * p + (a - m);
+      const double* xb = (bb < m) ? ud + bb : yd + (bb - m);
+      const int sa = (a < m) ? m : p, sb = (bb < m) ? m : p;
+      double s0 = 0.0, s1 = 0.0;
+      int t = 0;
+      for (; t + 1 < c; t += 2) { s0 += xa[t * sa] * xb[t * sb]; s1 += xa[(t + 1) * sa] * xb[(t + 1) * sb]; }
+      if (t < c) s0 += xa[t * sa] * xb[t * sb];
+      Ctab[e] = s0 + s1;
+    }
+    __syncthreads();
+    for (int e = tid; e < npk; e += nthr) {
+      const int i = tri_row(e), j = e - i * (i + 1) / 2;
+      int ri = perm[i], rj = perm[j];
+      if (ri / nch < rj / nch) { const int tmp = ri; ri = rj; rj = tmp; }       // (k, a) with the larger time offset first
+      const int ki = ri / nch, a = ri - ki * nch, kj = rj / nch, bb = rj - kj * nch;
+      const int d = ki - kj;
+      double s = Ctab[(d * nch + a) * nch + bb];
+      for (int jj = 0; jj < kj; ++jj) s += xat(a, jj + c + d) * xat(bb, jj + c) - xat(a, jj + d) * xat(bb, jj);
+      G[e] = s;
+    }
+  } else {
+    for (int e = tid; e < npk; e += nthr) {
+      const int i = tri_row(e), j = e - i * (i + 1) / 2;
+      const int ri = perm[i], rj = perm[j];
+      const int ki = ri / nch, ci = ri - ki * nch, kj = rj / nch, cj = rj - kj * nch;
+      const double* xi = (ci < m) ? ud + (long long)ki * m + ci : yd + (long long)ki * p + (ci - m);
+      const double* xj = (cj < m) ? ud + (long long)kj * m + cj : yd + (long long)kj * p + (cj - m);
+      const int si = (ci < m) ? m : p, sj = (cj < m) ? m : p;
+      double s0 = 0.0, s1 = 0.0;
+      int t = 0;
+      for (; t + 1 < c; t += 2) { s0 += xi[t * si] * xj[t * sj]; s1 += xi[(t + 1) * si] * xj[(t + 1) * sj]; }
+      if (t < c) s0 += xi[t * si] * xj[t * sj];
+      G[e] = s0 + s1;
+    }
   }
   __syncthreads();
+  if (dbg && tid == 0) dbg[b * 8 + 1] = __builtin_amdgcn_s_memrealtime();
   double dmx = 0.0;
   for (int i = tid; i < r; i += nthr) dmx = fmax(dmx, G[i * (i + 1) / 2 + i]);
 #pragma unroll
@@ -734,17 +789,19 @@ __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RP
   for (int w = 0; w < (nthr >> 6); ++w) dmax = fmax(dmax, red[w]);
   __syncthreads();
   packed_psd_cholesky(G, r, rank_tol * dmax, skip, col);
+  if (dbg && tid == 0) dbg[b * 8 + 2] = __builtin_amdgcn_s_memrealtime();
   // ---- hard constraints: L_FF w = f (skipped pivots carry no unknown); residual of the dependent rows ----
-  if (tid == 0) {
-    for (int k = 0; k < nF; ++k) {
-      double s = fv[k];
-      const double* Lk = G + k * (k + 1) / 2;
-      for (int j = 0; j < k; ++j) s -= Lk[j] * col[j];
+  for (int k = 0; k < nF; ++k) {                      // row by row, the dot product spread over the workgroup
+    const double* Lk = G + k * (k + 1) / 2;
+    double part = 0.0;
+    for (int j = tid; j < k; j += nthr) part += Lk[j] * col[j];
+    const double s = fv[k] - block_sum(part, red);
+    if (tid == 0) {
       col[k] = skip[k] ? 0.0 : s / Lk[k];
       vv[k] = skip[k] ? fabs(s) : 0.0;                  // what a dependent constraint row is off by
     }
+    __syncthreads();
   }
-  __syncthreads();
   double resid = 0.0, fmaxv = 1.0;
   for (int k = 0; k < nF; ++k) { resid = fmax(resid, vv[k]); fmaxv = fmax(fmaxv, fabs(fv[k])); }
   // ---- z0 = L_RF w ------------------------------------------------------------------------------
@@ -755,6 +812,7 @@ __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RP
     z0[i] = s;
   }
   __syncthreads();
+  if (dbg && tid == 0) dbg[b * 8 + 3] = __builtin_amdgcn_s_memrealtime();
   // ---- reduced normal equations T = C' W C, rhs = C' W (zs - z0), C(i,a) = L(nF+i, nF+a), i >= a ----
   const int npt = nR * (nR + 1) / 2;
   for (int e = tid; e < npt; e += nthr) {
@@ -777,24 +835,28 @@ __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RP
     vv[a] = s;
   }
   __syncthreads();
+  if (dbg && tid == 0) dbg[b * 8 + 4] = __builtin_amdgcn_s_memrealtime();
   double tmx = 0.0;
   for (int a = 0; a < nR; ++a) tmx = fmax(tmx, T[a * (a + 1) / 2 + a]);
   packed_psd_cholesky(T, nR, 1e-14 * tmx, skipT, col);
-  // ---- T v = rhs by the factor (thread 0: nR <= 272, a few thousand multiply-adds) ---------------------
-  if (tid == 0) {
-    for (int a = 0; a < nR; ++a) {
-      double s = vv[a];
-      const double* Ta = T + a * (a + 1) / 2;
-      for (int j = 0; j < a; ++j) s -= Ta[j] * vv[j];
-      vv[a] = skipT[a] ? 0.0 : s / Ta[a];
-    }
-    for (int a = nR - 1; a >= 0; --a) {
-      double s = vv[a];
-      for (int i = a + 1; i < nR; ++i) s -= T[i * (i + 1) / 2 + a] * vv[i];
-      vv[a] = skipT[a] ? 0.0 : s / T[a * (a + 1) / 2 + a];
-    }
+  if (dbg && tid == 0) dbg[b * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+  // ---- T v = rhs by the factor, row by row with the dot products spread over the workgroup ----------------
+  for (int a = 0; a < nR; ++a) {
+    const double* Ta = T + a * (a + 1) / 2;
+    double part = 0.0;
+    for (int j = tid; j < a; j += nthr) part += Ta[j] * vv[j];
+    const double s = vv[a] - block_sum(part, red);
+    if (tid == 0) vv[a] = skipT[a] ? 0.0 : s / Ta[a];
+    __syncthreads();
   }
-  __syncthreads();
+  for (int a = nR - 1; a >= 0; --a) {
+    double part = 0.0;
+    for (int i = a + 1 + tid; i < nR; i += nthr) part += T[i * (i + 1) / 2 + a] * vv[i];
+    const double s = vv[a] - block_sum(part, red);
+    if (tid == 0) vv[a] = skipT[a] ? 0.0 : s / T[a * (a + 1) / 2 + a];
+    __syncthreads();
+  }
+  if (dbg && tid == 0) dbg[b * 8 + 6] = __builtin_amdgcn_s_memrealtime();
   // ---- z_R = z0 + C v; outputs -------------------------------------------------------------------
   double part = 0.0;
   double* uo = u_opt + b * (long long)((P.Ln - n) * m);
@@ -822,6 +884,7 @@ __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RP
     const bool feasible = resid <= feas_tol * fmaxv;
     status[b] = !(fabs(tot) < 1e300) ? 4 : (feasible ? 0 : 2);      // 2 = "infeasible"
     if (iters) iters[b] = 1;
+    if (dbg) dbg[b * 8 + 7] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
