@@ -50,3 +50,34 @@ run("cfg4 robust NONE L=60 N=1000", 1024, 60, 1000, 0)
 run("cfg4 robust CONVEX L=60 N=1000", 1024, 60, 1000, 1)
 run("cfg2 PCIe-inclusive (host pointers: upload u_d,y_d + solve + download)", 4096, 30, 400, 0, host=True, steps=5)
 run("cfg2 PCIe-inclusive, pipelined (ddmpc_solve_from_host: chunked upload overlapped with the solves)", 4096, 30, 400, 0, host=True, steps=5, pipelined=True)
+
+
+def run_config5(B=512):
+    """BASELINE configs[4]: nominal scheme, m = p = 8, n = 8, L = 30, N = 2000, exact data of a random stable plant
+    (SURVEY section 8 proposal) -- the rank-revealing kernel with a global workspace."""
+    rng = np.random.default_rng(0)
+    ns = n = 8; m = p = 8; Lh = 30; N = 2000
+    A = rng.normal(size=(ns, ns)); A *= 0.9 / max(abs(np.linalg.eigvals(A)))
+    plant = dict(A=A, B=rng.normal(size=(ns, m)), C=rng.normal(size=(p, ns)), D=np.zeros((p, m)), eps_max=0.0)
+    u_s = 0.1 * np.ones(m); y_s = (plant["C"] @ np.linalg.inv(np.eye(ns) - A) @ plant["B"]) @ u_s
+    d = generate_batch(range(B), N=N, plant=plant)
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    eng = BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=3.0, R=1e-4, u_s=u_s, y_s=y_s, batch=B, controller_type=L.NOMINAL)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ud, yd, upt, ypt = t(d["u_d"]), t(d["y_d"]), t(up), t(yp)
+    eng.set_data(ud, yd)
+    out = eng.solve(upt, ypt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.solve(upt, ypt, *out)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    st = out[2].cpu().numpy()
+    print("%-70s kernel %-30s B=%6d  %.3f ms/step  %.3e solves/s" % (
+        "cfg5 nominal, m=p=8 n=8 L=30 N=2000, exact data status_ok=%d" % int((st == 0).sum()), eng.kernel_name(), B, dt * 1e3, B / dt), flush=True)
+    eng.close()
+
+
+run_config5()
