@@ -17,6 +17,16 @@ import numpy as np
 from .ddmpc_oracle import QPSpec, hankel_matrix
 
 
+def _svd(a, full_matrices):
+    """numpy's divide-and-conquer SVD occasionally fails to converge on these matrices; fall back to the QR-iteration
+    driver then."""
+    try:
+        return np.linalg.svd(a, full_matrices=full_matrices)
+    except np.linalg.LinAlgError:
+        import scipy.linalg
+        return scipy.linalg.svd(a, full_matrices=full_matrices, lapack_driver="gesvd")
+
+
 def solve_nominal_exact(spec: QPSpec, u_d, y_d, u_past, y_past, rank_tol: float = 1e-10, feas_tol: float = 1e-7):
     """Returns dict(status, optimal_u, cost, residual, rank)."""
     n, m, p, L_ = spec.n, spec.m, spec.p, spec.L
@@ -44,10 +54,10 @@ def solve_nominal_exact(spec: QPSpec, u_d, y_d, u_past, y_past, rank_tol: float 
                 weight[i] = spec.Q[kp * p + ch, kp * p + ch]; target[i] = spec.y_s[ch]
     F, R = sorted(fixed), sorted(weight)
     f = np.array([fixed[i] for i in F]); W = np.array([weight[i] for i in R]); zs = np.array([target[i] for i in R])
-    U, S, _ = np.linalg.svd(H, full_matrices=False)
+    U, S, _ = _svd(H, False)
     k = int(np.sum(S > S[0] * rank_tol))
     U = U[:, :k]                                                                    # z = U c spans range(H)
-    Uf, Sf, Vft = np.linalg.svd(U[F], full_matrices=True)
+    Uf, Sf, Vft = _svd(U[F], True)
     kf = int(np.sum(Sf > Sf[0] * 1e-9))
     c_p = Vft[:kf].T @ ((Uf[:, :kf].T @ f) / Sf[:kf])                               # least-squares particular solution
     N = Vft[kf:].T                                                                  # null space of the constraint block

@@ -1,14 +1,18 @@
-"""Dev tool: BASELINE configs[4] (nominal, m=p=8, n=8, L=30, N=2000, B=512, exact data) on the rank-revealing kernel:
-accuracy against the SVD-based CPU solve on a few instances, and time per batch."""
-import sys, time
+"""BASELINE configs[4] (nominal, m=p=8, n=8, L=30, N=2000, B=512, exact data of a random stable plant) on the
+rank-revealing kernel: accuracy against the SVD-based CPU solve on the first `--check` instances (oracle solves in
+forked workers, before the GPU runtime starts), and time per batch.
+
+    python tools/config5_check.py [--check 64]
+"""
+import argparse, sys, time
+import multiprocessing as mp
 import numpy as np
 sys.path.insert(0, ".")
-from direct_data_driven_mpc_amd import _lib as L
-from direct_data_driven_mpc_amd.engine import BatchedDDMPC
 from direct_data_driven_mpc_amd.harness import generate_batch
 from oracle import ddmpc_oracle as orc
 from oracle.nominal_exact import solve_nominal_exact
 
+ap = argparse.ArgumentParser(); ap.add_argument("--check", type=int, default=64); a = ap.parse_args()
 rng = np.random.default_rng(0)
 ns = n = 8; m = p = 8; Lh = 30; N = 2000; B = 512
 A = rng.normal(size=(ns, ns)); A *= 0.9 / max(abs(np.linalg.eigvals(A)))
@@ -18,13 +22,33 @@ spec = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=3.0 * np.eye(p * Lh), R=1e-4 * np.eye(m
                   eps_max=0.0, lamb_alpha=0.0, lamb_sigma=0.0, c=0.0, slack="none", tec=True)
 d = generate_batch(range(B), N=N, plant=plant)
 up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+
+
+def _ref(b):
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=1)
+    except Exception:
+        pass
+    r = solve_nominal_exact(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
+    return r["status"], r["optimal_u"], r["cost"], r["rank"]
+
+
+K = min(a.check, B)
+t0 = time.perf_counter()
+with mp.get_context("fork").Pool(16) as pool:
+    refs = pool.map(_ref, range(K))
+print("oracle (SVD route): %d instances in %.1f s on 16 worker processes" % (K, time.perf_counter() - t0), flush=True)
+
+from direct_data_driven_mpc_amd import _lib as L
+from direct_data_driven_mpc_amd.engine import BatchedDDMPC
 eng = BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=3.0, R=1e-4, u_s=u_s, y_s=y_s, batch=B, controller_type=L.NOMINAL)
 eng.set_data(d["u_d"], d["y_d"])
 u, cost, status, _ = eng.solve(up, yp)
 t = time.perf_counter(); u, cost, status, _ = eng.solve(up, yp); dt = time.perf_counter() - t
-print("cfg5 nominal exact, B=%d: %.1f ms per batch -> %.3e solves/s; status %s" % (B, dt * 1e3, B / dt, sorted(set(status.tolist()))))
-for b in range(4):
-    ref = solve_nominal_exact(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
-    print("  instance %d: rel err u %.2e cost %.2e (oracle %s, rank %d, cost %.6g)" % (
-        b, np.max(np.abs(u[b] - ref["optimal_u"])) / np.max(np.abs(ref["optimal_u"])), abs(cost[b] - ref["cost"]) / abs(ref["cost"]),
-        ref["status"], ref["rank"], ref["cost"]))
+print("cfg5 nominal exact, kernel %s, B=%d: %.1f ms per batch -> %.3e solves/s; status values %s" % (
+    eng.kernel_name(), B, dt * 1e3, B / dt, sorted(set(status.tolist()))))
+eu = max(np.max(np.abs(u[b] - refs[b][1])) / np.max(np.abs(refs[b][1])) for b in range(K))
+ec = max(abs(cost[b] - refs[b][2]) / abs(refs[b][2]) for b in range(K))
+print("first %d instances vs the SVD-based oracle (all '%s', rank %d of 608): max rel err u %.3e, cost %.3e" % (
+    K, ",".join(sorted(set(r[0] for r in refs))), refs[0][3], eu, ec))
