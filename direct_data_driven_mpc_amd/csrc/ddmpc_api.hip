@@ -591,7 +591,8 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
   const size_t r = (size_t)h->kp.r, nR = (size_t)h->n_free;
   const size_t ndbl = r * (r + 1) / 2 + nR * (nR + 1) / 2;
   const size_t rv = (r + 1) & ~(size_t)1;
-  const size_t vec_bytes = 6 * rv * sizeof(double) + 3 * rv * sizeof(int);       // the kernel's r-vectors, always in LDS
+  const size_t vec_bytes = 6 * rv * sizeof(double) + 4 * rv * sizeof(int) +     // the kernel's r-vectors, always in LDS,
+                           (r * PSD_NB + PSD_NB * PSD_CH) * sizeof(double);        // and the panel scratch of its Cholesky
   size_t lds = vec_bytes + ndbl * sizeof(double);
   double* scratch = nullptr;
   if (lds + 1024 > 160 * 1024) {                              // matrices too big for LDS: per-instance slices of a global workspace

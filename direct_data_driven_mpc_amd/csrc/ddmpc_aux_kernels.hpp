@@ -622,35 +622,76 @@ __device__ __forceinline__ int tri_row(int e) {
   return i;
 }
 
-// in-place Cholesky of a packed lower matrix with `n` rows; pivots <= tol * dmax are skipped (column zeroed,
-// skip[k] = 1).  All threads of the workgroup must call it.
-__device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol_abs, int* skip, double* col) {
+// In-place Cholesky of a packed lower matrix with `n` rows; pivots <= tol_abs are skipped (column zeroed,
+// skip[k] = 1).  Panel-blocked, left-looking: a panel of PSD_NB columns is pulled into LDS, updated with ALL the
+// columns factored so far in one sweep (each thread streams its own rows of the factor once per panel; the PSD_NB
+// factor rows the whole workgroup needs are staged through LDS in chunks), factored there and written back --
+// the matrix, which may live in global memory, is read ~n^3/(6 PSD_NB) times instead of being read and written
+// n^3/3 times by a column-at-a-time right-looking update.  `pan` = LDS scratch of n*PSD_NB + PSD_NB*PSD_CH doubles.
+// All threads of the workgroup must call it.
+constexpr int PSD_NB = 16;      // panel width
+constexpr int PSD_CH = 64;      // columns of the factor staged per chunk
+__device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol_abs, int* skip, double* pan) {
   const int tid = threadIdx.x, nthr = blockDim.x;
-  for (int k = 0; k < n; ++k) {
-    const double dk = A[k * (k + 1) / 2 + k];
-    const bool sk = !(dk > tol_abs);                    // uniform: every thread reads the same value
-    if (tid == 0) skip[k] = sk ? 1 : 0;
-    const double inv = sk ? 0.0 : 1.0 / sqrt(dk);
-    for (int i = k + tid; i < n; i += nthr) col[i] = A[i * (i + 1) / 2 + k] * inv;
-    __syncthreads();
-    for (int i = k + tid; i < n; i += nthr) A[i * (i + 1) / 2 + k] = col[i];
-    if (!sk) {
-      // trailing update, one packed row per thread-iteration (rows dealt cyclically: their lengths differ)
-      // (eight elements are loaded before any is stored: when A is in global memory the loop is otherwise one
-      //  exposed L2 round trip per element)
-      for (int i = k + 1 + tid; i < n; i += nthr) {
-        double* Ai = A + i * (i + 1) / 2;
-        const double ci = col[i];
-        int j = k + 1;
-        for (; j + 8 <= i + 1; j += 8) {
-          double v[8];
+  double* Pn = pan;                           // Pn[(i - k0) * PSD_NB + c] = A(i, k0 + c)
+  double* Lp = pan + (size_t)n * PSD_NB;      // Lp[c * PSD_CH + jj]      = A(k0 + c, j0 + jj)
+  for (int k0 = 0; k0 < n; k0 += PSD_NB) {
+    const int nb = (n - k0) < PSD_NB ? (n - k0) : PSD_NB;
+    // (1) + (2): panel rows, minus the contribution of the columns factored so far
+    for (int i0 = k0; i0 < n; i0 += nthr) {
+      const int i = i0 + tid;
+      double acc[PSD_NB];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = Ai[j + q];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) Ai[j + q] = v[q] - ci * col[j + q];
+      for (int c = 0; c < PSD_NB; ++c) acc[c] = 0.0;
+      const double* Ai = A + (size_t)(i < n ? i : k0) * ((i < n ? i : k0) + 1) / 2;
+      for (int j0 = 0; j0 < k0; j0 += PSD_CH) {
+        const int nj = (k0 - j0) < PSD_CH ? (k0 - j0) : PSD_CH;
+        __syncthreads();                       // previous chunk consumed
+        for (int e = tid; e < nb * nj; e += nthr) {
+          const int c = e / nj, jj = e - c * nj;
+          Lp[c * PSD_CH + jj] = A[(size_t)(k0 + c) * (k0 + c + 1) / 2 + j0 + jj];
         }
-        for (; j <= i; ++j) Ai[j] -= ci * col[j];
+        __syncthreads();
+        if (i < n) {
+          for (int jj = 0; jj < nj; ++jj) {
+            const double li = Ai[j0 + jj];
+#pragma unroll
+            for (int c = 0; c < PSD_NB; ++c) acc[c] += li * Lp[c * PSD_CH + jj];
+          }
+        }
       }
+      if (i < n) {
+#pragma unroll
+        for (int c = 0; c < PSD_NB; ++c)
+          Pn[(i - k0) * PSD_NB + c] = (c < nb && k0 + c <= i) ? Ai[k0 + c] - acc[c] : 0.0;
+      }
+    }
+    __syncthreads();
+    // (3) factor the panel in LDS, column by column
+    for (int c = 0; c < nb; ++c) {
+      const int k = k0 + c;
+      const double dk = Pn[c * PSD_NB + c];
+      const bool sk = !(dk > tol_abs);          // uniform: every thread reads the same value
+      if (tid == 0) skip[k] = sk ? 1 : 0;
+      const double inv = sk ? 0.0 : 1.0 / sqrt(dk);
+      __syncthreads();                          // everyone has read the pivot
+      for (int i = k + tid; i < n; i += nthr) Pn[(i - k0) * PSD_NB + c] *= inv;
+      __syncthreads();
+      if (!sk) {
+        for (int i = k + 1 + tid; i < n; i += nthr) {
+          double* Pi = Pn + (i - k0) * PSD_NB;
+          const double ci = Pi[c];
+          for (int c2 = c + 1; c2 < nb; ++c2)
+            if (k0 + c2 <= i) Pi[c2] -= ci * Pn[c2 * PSD_NB + c];        // A(k0+c2, k) sits in row c2 of the panel
+        }
+      }
+      __syncthreads();
+    }
+    // (4) panel -> matrix
+    for (int i = k0 + tid; i < n; i += nthr) {
+      double* Ai = A + (size_t)i * (i + 1) / 2;
+      for (int c = 0; c < nb; ++c)
+        if (k0 + c <= i) Ai[k0 + c] = Pn[(i - k0) * PSD_NB + c];
     }
     __syncthreads();
   }
@@ -681,7 +722,7 @@ __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RP
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int r = P.r, m = P.m, p = P.p, nch = P.nch, c = P.c;
   const int n = P.npu / m;
-  // dynamic LDS: six r-vectors of doubles and three of ints first, then -- when they fit -- the two packed
+  // dynamic LDS: six r-vectors of doubles and four of ints first, then -- when they fit -- the two packed
   // matrices; otherwise the matrices live in a per-instance slice of a global workspace (same code, L2 instead of
   // LDS; __syncthreads orders global accesses within the workgroup)
   const int rv = (r + 1) & ~1;
@@ -694,7 +735,9 @@ __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RP
   int* perm = reinterpret_cast<int*>(col + rv);
   int* skip = perm + rv;
   int* skipT = skip + rv;
-  double* rsm = scratch ? scratch + b * scratch_stride : reinterpret_cast<double*>(skipT + rv);
+  int* iperm = skipT + rv;                              // component -> position in the fixed-first order
+  double* pan = reinterpret_cast<double*>(iperm + rv);                 // panel + chunk scratch of the Cholesky (always LDS)
+  double* rsm = scratch ? scratch + b * scratch_stride : pan + (size_t)r * PSD_NB + PSD_NB * PSD_CH;
   double* G = rsm;                                      // r(r+1)/2
   double* T = G + r * (r + 1) / 2;                      // nR(nR+1)/2
   __shared__ double red[8];
@@ -740,27 +783,47 @@ __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RP
   const int nlag = P.Ln * nch * nch;
   if (nlag <= nR * (nR + 1) / 2) {
     double* Ctab = T;
+    // lag sums C_d(a,b) = sum_{t<c} x_a[t+d] x_b[t]: the trajectory is streamed through LDS in chunks of time steps
+    // (the panel scratch of the Cholesky is free now), every thread accumulating its own (d,a,b) entries
+    {
+      const int TCH = ((r * PSD_NB + PSD_NB * PSD_CH) / nch) - P.Ln;          // time steps per chunk that fit with the lag overlap
+      double* xc = pan;                                                       // xc[(t - t0) * nch + ch], t0 <= t < t0 + TCH + Ln
+      for (int e = tid; e < nlag; e += nthr) Ctab[e] = 0.0;
+      for (int t0 = 0; t0 < c; t0 += TCH) {
+        const int nt = (c - t0) < TCH ? (c - t0) : TCH;                        // terms of this chunk
+        const int nload = nt + P.Ln - 1;                                      // time steps needed (x_a[t+d], d < Ln)
+        __syncthreads();
+        for (int i = tid; i < nload * nch; i += nthr) {
+          const int tt = i / nch, ch = i - tt * nch;
+          xc[i] = xat(ch, t0 + tt);
+        }
+        __syncthreads();
+        for (int e = tid; e < nlag; e += nthr) {
+          const int d = e / (nch * nch), ab = e - d * nch * nch, a = ab / nch, bb = ab - a * nch;
+          const double* xa = xc + d * nch + a;
+          const double* xb = xc + bb;
+          double s0 = 0.0, s1 = 0.0;
+          int t = 0;
+          for (; t + 1 < nt; t += 2) { s0 += xa[t * nch] * xb[t * nch]; s1 += xa[(t + 1) * nch] * xb[(t + 1) * nch]; }
+          if (t < nt) s0 += xa[t * nch] * xb[t * nch];
+          Ctab[e] += s0 + s1;
+        }
+      }
+    }
+    for (int i = tid; i < r; i += nthr) iperm[perm[i]] = i;
+    __syncthreads();
+    // one (lag, channel pair) diagonal per thread-iteration, walked with the O(1) window update; every unordered
+    // pair of components is met exactly once (lag 0: channel pairs a >= b only)
     for (int e = tid; e < nlag; e += nthr) {
       const int d = e / (nch * nch), ab = e - d * nch * nch, a = ab / nch, bb = ab - a * nch;
-      const double* xa = (a < m) ? ud + (long long)d * m + a : yd + (long long)d * p + (a - m);
-      const double* xb = (bb < m) ? ud + bb : yd + (bb - m);
-      const int sa = (a < m) ? m : p, sb = (bb < m) ? m : p;
-      double s0 = 0.0, s1 = 0.0;
-      int t = 0;
-      for (; t + 1 < c; t += 2) { s0 += xa[t * sa] * xb[t * sb]; s1 += xa[(t + 1) * sa] * xb[(t + 1) * sb]; }
-      if (t < c) s0 += xa[t * sa] * xb[t * sb];
-      Ctab[e] = s0 + s1;
-    }
-    __syncthreads();
-    for (int e = tid; e < npk; e += nthr) {
-      const int i = tri_row(e), j = e - i * (i + 1) / 2;
-      int ri = perm[i], rj = perm[j];
-      if (ri / nch < rj / nch) { const int tmp = ri; ri = rj; rj = tmp; }       // (k, a) with the larger time offset first
-      const int ki = ri / nch, a = ri - ki * nch, kj = rj / nch, bb = rj - kj * nch;
-      const int d = ki - kj;
-      double s = Ctab[(d * nch + a) * nch + bb];
-      for (int jj = 0; jj < kj; ++jj) s += xat(a, jj + c + d) * xat(bb, jj + c) - xat(a, jj + d) * xat(bb, jj);
-      G[e] = s;
+      if (d == 0 && a < bb) continue;
+      double s = Ctab[e];
+      for (int k = 0; k + d < P.Ln; ++k) {
+        if (k > 0) s += xat(a, k - 1 + c + d) * xat(bb, k - 1 + c) - xat(a, k - 1 + d) * xat(bb, k - 1);
+        const int pi = iperm[(k + d) * nch + a], pj = iperm[k * nch + bb];
+        const int hi = pi > pj ? pi : pj, lo = pi > pj ? pj : pi;
+        G[hi * (hi + 1) / 2 + lo] = s;
+      }
     }
   } else {
     for (int e = tid; e < npk; e += nthr) {
@@ -788,7 +851,7 @@ __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RP
   double dmax = 0.0;
   for (int w = 0; w < (nthr >> 6); ++w) dmax = fmax(dmax, red[w]);
   __syncthreads();
-  packed_psd_cholesky(G, r, rank_tol * dmax, skip, col);
+  packed_psd_cholesky(G, r, rank_tol * dmax, skip, pan);
   if (dbg && tid == 0) dbg[b * 8 + 2] = __builtin_amdgcn_s_memrealtime();
   // ---- hard constraints: L_FF w = f (skipped pivots carry no unknown); residual of the dependent rows ----
   for (int k = 0; k < nF; ++k) {                      // row by row, the dot product spread over the workgroup
@@ -838,7 +901,7 @@ __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RP
   if (dbg && tid == 0) dbg[b * 8 + 4] = __builtin_amdgcn_s_memrealtime();
   double tmx = 0.0;
   for (int a = 0; a < nR; ++a) tmx = fmax(tmx, T[a * (a + 1) / 2 + a]);
-  packed_psd_cholesky(T, nR, 1e-14 * tmx, skipT, col);
+  packed_psd_cholesky(T, nR, 1e-14 * tmx, skipT, pan);
   if (dbg && tid == 0) dbg[b * 8 + 5] = __builtin_amdgcn_s_memrealtime();
   // ---- T v = rhs by the factor, row by row with the dot products spread over the workgroup ----------------
   for (int a = 0; a < nR; ++a) {
