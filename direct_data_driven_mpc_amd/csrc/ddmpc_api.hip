@@ -145,7 +145,8 @@ struct ddmpc_handle {
   bool prepared = false;
   int closed_loop_path = DDMPC_PATH_AUTO;
   bool closed_loop_graph = false;
-  bool large_nominal = false;              // r beyond the cold kernels: NOMINAL controllers run on the rank-revealing kernel alone
+  bool large = false;                      // r beyond the register-resident cold kernels: global-workspace kernels only
+  bool large_nominal = false;              // ... NOMINAL: every solve is the rank-revealing kernel; else ddmpc_large_solve_kernel
   int n_free = 0;                          // weighted (free) components, nominal scheme: rows of the reduced normal matrix
   bool stamps_on = false;
   const double* last_up = nullptr;
@@ -417,21 +418,25 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
     }
   }
   static const KernelChoice kLargeNominal = {0, 4, nullptr, "ddmpc_nominal_rr_kernel", 0};
+  static const KernelChoice kLargeSolve = {0, 4, nullptr, "ddmpc_large_solve_kernel", 0};
   if (!kc) {
-    // No register-resident kernel holds this many rows.  A NOMINAL controller with diagonal weights can still be
-    // served by the rank-revealing kernel with its matrices in a global workspace (slow, and accurate only to the
-    // extent the Gram route allows at that size: DESIGN.md section 9); everything else is unsupported.
-    if (p.controller_type != DDMPC_NOMINAL || p.weight_kind == DDMPC_WEIGHT_DENSE) {
+    // No register-resident kernel holds this many rows.  With scalar/diagonal weights the problem is served by the
+    // global-workspace kernels (plain VALU code): ROBUST controllers by
+    // ddmpc_large_solve_kernel, NOMINAL ones by the rank-revealing kernel (accurate only to the extent the Gram
+    // route allows at that size).  Dense weights are unsupported here.
+    if (p.weight_kind == DDMPC_WEIGHT_DENSE) {
       delete h;
-      return fail(DDMPC_ERR_UNSUPPORTED, "problem too large for the single-workgroup kernels: (m+p)(L+n) = %d rows", k.r);
+      return fail(DDMPC_ERR_UNSUPPORTED, "problem too large for the single-workgroup kernels: (m+p)(L+n) = %d rows "
+                  "(dense weighting matrices are limited to 271 rows)", k.r);
     }
-    h->large_nominal = true;
-    h->kc = kLargeNominal;
+    h->large = true;
+    h->large_nominal = (p.controller_type == DDMPC_NOMINAL);
+    h->kc = h->large_nominal ? kLargeNominal : kLargeSolve;
     h->kc.NT = (rows_needed + 15) / 16;
   } else {
     h->kc = *kc;
   }
-  if (h->large_nominal) {
+  if (h->large) {
     k.xs_len = 0;
     h->lds_bytes = 0;
     if (hipSetDevice(device) != hipSuccess) { delete h; return fail(DDMPC_ERR_HIP, "hipSetDevice(%d) failed", device); }
@@ -542,6 +547,21 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
   int rc;
   if (h->large_nominal) {          // no cold kernel at this size: every instance goes to the rank-revealing kernel
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)status, 4, (size_t)h->batch, h->stream));
+    return DDMPC_OK;
+  }
+  if (h->large) {                  // robust scheme beyond the register-resident kernels: matrices in a global workspace
+    const size_t r = (size_t)h->kp.r, npk = r * (r + 1) / 2, rv = (r + 1) & ~(size_t)1;
+    if ((rc = h->d_rr.ensure((size_t)h->batch * 2 * npk * sizeof(double)))) return rc;
+    if ((rc = h->d_beta.ensure((size_t)h->batch * h->kp.rE * sizeof(double)))) return rc;
+    if ((rc = h->d_act.ensure((size_t)h->batch * h->kp.rE))) return rc;
+    const size_t lds = 4 * rv * sizeof(double) + 2 * rv * sizeof(int) + (r * PSD_NB + PSD_NB * PSD_CH) * sizeof(double);
+    if (lds + 1024 > 160 * 1024) return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: %zu rows", r);
+    if (lds > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_large_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ddmpc_large_solve_kernel, dim3((unsigned)h->batch), dim3(256), lds, h->stream,
+                       kp_override ? *kp_override : h->kp, 16 * h->kc.NT, h->ud, h->yd, up, yp, uo, cost, (int*)status,
+                       (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, (double*)h->d_rr.p, (long long)(2 * npk));
+    HIP_TRY(hipGetLastError());
     return DDMPC_OK;
   }
   if ((rc = h->d_beta.ensure((size_t)h->batch * h->kp.rE * sizeof(double)))) return rc;
@@ -684,7 +704,7 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
   if (!h || !u_d || !y_d || !u_past || !y_past || !u_opt || !cost || !status)
     return fail(DDMPC_ERR_INVALID, "null argument");
   if (h->batch > 0x7fffffffLL) return fail(DDMPC_ERR_INVALID, "batch too large for one launch");
-  if (h->large_nominal) {                         // no chunked cold launches at this size: plain upload + solve
+  if (h->large) {                         // no chunked cold launches at this size: plain upload + solve
     int rcs = ddmpc_set_data(h, u_d, y_d, DDMPC_MEM_HOST);
     return rcs ? rcs : ddmpc_solve(h, u_past, y_past, u_opt, cost, status, iters, DDMPC_MEM_HOST);
   }
@@ -750,7 +770,7 @@ int ddmpc_prepare(ddmpc_handle* h) {
   if (!h->have_data) return fail(DDMPC_ERR_NOT_READY, "ddmpc_set_data must be called before ddmpc_prepare");
   if (h->batch > 0x7fffffffLL) return fail(DDMPC_ERR_INVALID, "batch too large for one launch");
   if (h->prepared) return DDMPC_OK;
-  if (h->large_nominal) return DDMPC_OK;          // no affine law is formed at this size: every step is a full solve
+  if (h->large) return DDMPC_OK;          // no affine law is formed at this size: every step is a full solve
   HIP_TRY(hipSetDevice(h->device));
   const ddmpc_params& p = h->prm;
   const KParams& k = h->kp;
@@ -803,7 +823,7 @@ int ddmpc_step(ddmpc_handle* h, const double* u_past, const double* y_past, doub
                int32_t* status, int32_t* iters, int mem) {
   if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
   if (!h->have_data) return fail(DDMPC_ERR_NOT_READY, "ddmpc_set_data must be called before ddmpc_step");
-  if (h->large_nominal) return solve_impl(h, u_past, y_past, u_opt, cost, status, iters, mem, &launch_cold_plain);
+  if (h->large) return solve_impl(h, u_past, y_past, u_opt, cost, status, iters, mem, &launch_cold_plain);
   if (!h->prepared) {
     int rc = ddmpc_prepare(h);
     if (rc) return rc;
@@ -813,7 +833,7 @@ int ddmpc_step(ddmpc_handle* h, const double* u_past, const double* y_past, doub
 
 int ddmpc_get_gain(ddmpc_handle* h, double* out, int mem) {
   if (!h || !out) return fail(DDMPC_ERR_INVALID, "null argument");
-  if (h->large_nominal) return fail(DDMPC_ERR_UNSUPPORTED, "no affine law at this problem size");
+  if (h->large) return fail(DDMPC_ERR_UNSUPPORTED, "no affine law at this problem size");
   if (!h->prepared) return fail(DDMPC_ERR_NOT_READY, "ddmpc_prepare must be called before ddmpc_get_gain");
   HIP_TRY(hipSetDevice(h->device));
   const size_t bytes = (size_t)h->batch * (h->prm.n * h->kp.nch + 1) * h->kp.r * sizeof(double);
@@ -1009,8 +1029,8 @@ int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps
   }
   const bool warm_ok = warm_capable(h) && h->closed_loop_path != DDMPC_PATH_COLD &&
                        (size_t)n_mpc_step * m <= (size_t)WARM_MAX_NF && n * h->kp.nch <= WARM_MAX_NF;
-  bool warm = warm_ok && !h->kp.convex && !h->large_nominal;   // no inequality: fused loop, one launch
-  const bool warm_box = warm_ok && h->kp.convex;     // slack box: per step, affine iterate + cold re-solve where a bound is active
+  bool warm = warm_ok && !h->kp.convex && !h->large;   // no inequality: fused loop, one launch
+  const bool warm_box = warm_ok && h->kp.convex && !h->large;     // slack box: per step, affine iterate + cold re-solve where a bound is active
   if (warm_box && (rc = ddmpc_prepare(h))) return rc;
   if (warm && p.controller_type == DDMPC_NOMINAL) {
     // nominal scheme: an instance with a singular Gram matrix (exact data) has no affine law; if there is one,

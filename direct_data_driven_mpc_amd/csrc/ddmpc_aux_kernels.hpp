@@ -697,6 +697,61 @@ __device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol
   }
 }
 
+// Packed lower triangle of G = H H' for the block-Hankel H of one instance, through the Hankel structure (as in the
+// cold kernel): with components (k, a) = (time offset, channel),
+//   G((k+d, a), (k, b)) = C_d(a,b) + sum_{j<k} ( x_a[j+c+d] x_b[j+c] - x_a[j+d] x_b[j] ),   C_d(a,b) = sum_{t<c} x_a[t+d] x_b[t],
+// so only the Ln*nch^2 lag sums need the full length-c dot product (cfg 5: 19 M instead of 363 M multiply-adds).
+// `Ctab` holds the Ln*nch^2 lag sums (any scratch of that size), `pan` >= r*PSD_NB + PSD_NB*PSD_CH doubles of LDS;
+// `iperm` maps component rho = k*nch + ch to its row in G (nullptr: identity; written by the caller BEFORE the call).
+__device__ __forceinline__ void hankel_gram_packed(const KParams& P, const double* __restrict__ ud,
+                                                   const double* __restrict__ yd, double* G, double* Ctab,
+                                                   const int* iperm, double* pan) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int r = P.r, m = P.m, p = P.p, nch = P.nch, c = P.c;
+  const int nlag = P.Ln * nch * nch;
+  auto xat = [&](int a, int t) -> double { return (a < m) ? ud[(long long)t * m + a] : yd[(long long)t * p + (a - m)]; };
+  // lag sums: the trajectory is streamed through LDS in chunks of time steps (the panel scratch of the Cholesky is
+  // free at this point), every thread accumulating its own (d,a,b) entries
+  const int TCH = ((r * PSD_NB + PSD_NB * PSD_CH) / nch) - P.Ln;            // time steps per chunk that fit with the lag overlap
+  double* xc = pan;                                                         // xc[(t - t0) * nch + ch], t0 <= t < t0 + TCH + Ln
+  for (int e = tid; e < nlag; e += nthr) Ctab[e] = 0.0;
+  for (int t0 = 0; t0 < c; t0 += TCH) {
+    const int nt = (c - t0) < TCH ? (c - t0) : TCH;                          // terms of this chunk
+    const int nload = nt + P.Ln - 1;                                        // time steps needed (x_a[t+d], d < Ln)
+    __syncthreads();
+    for (int i = tid; i < nload * nch; i += nthr) {
+      const int tt = i / nch, ch = i - tt * nch;
+      xc[i] = xat(ch, t0 + tt);
+    }
+    __syncthreads();
+    for (int e = tid; e < nlag; e += nthr) {
+      const int d = e / (nch * nch), ab = e - d * nch * nch, a = ab / nch, bb = ab - a * nch;
+      const double* xa = xc + d * nch + a;
+      const double* xb = xc + bb;
+      double s0 = 0.0, s1 = 0.0;
+      int t = 0;
+      for (; t + 1 < nt; t += 2) { s0 += xa[t * nch] * xb[t * nch]; s1 += xa[(t + 1) * nch] * xb[(t + 1) * nch]; }
+      if (t < nt) s0 += xa[t * nch] * xb[t * nch];
+      Ctab[e] += s0 + s1;
+    }
+  }
+  __syncthreads();
+  // one (lag, channel pair) diagonal per thread-iteration, walked with the O(1) window update; every unordered
+  // pair of components is met exactly once (lag 0: channel pairs a >= b only)
+  for (int e = tid; e < nlag; e += nthr) {
+    const int d = e / (nch * nch), ab = e - d * nch * nch, a = ab / nch, bb = ab - a * nch;
+    if (d == 0 && a < bb) continue;
+    double s = Ctab[e];
+    for (int k = 0; k + d < P.Ln; ++k) {
+      if (k > 0) s += xat(a, k - 1 + c + d) * xat(bb, k - 1 + c) - xat(a, k - 1 + d) * xat(bb, k - 1);
+      const int ci = (k + d) * nch + a, cj = k * nch + bb;
+      const int pi = iperm ? iperm[ci] : ci, pj = iperm ? iperm[cj] : cj;
+      const int hi = pi > pj ? pi : pj, lo = pi > pj ? pj : pi;
+      G[hi * (hi + 1) / 2 + lo] = s;
+    }
+  }
+}
+
 // Sum of one value per thread over the workgroup (all threads get it); `red` holds >= nthr/64 doubles.
 __device__ __forceinline__ double block_sum(double v, double* red) {
   v = wave_sum(v);
@@ -779,52 +834,10 @@ __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RP
   // so only the Ln*nch^2 lag sums need the full length-c dot product (cfg 5: 19 M instead of 363 M multiply-adds).
   // The lag table borrows the (not yet used) storage of T; if it does not fit there, plain dot products are used.
   const int npk = r * (r + 1) / 2;
-  auto xat = [&](int a, int t) -> double { return (a < m) ? ud[(long long)t * m + a] : yd[(long long)t * p + (a - m)]; };
   const int nlag = P.Ln * nch * nch;
   if (nlag <= nR * (nR + 1) / 2) {
-    double* Ctab = T;
-    // lag sums C_d(a,b) = sum_{t<c} x_a[t+d] x_b[t]: the trajectory is streamed through LDS in chunks of time steps
-    // (the panel scratch of the Cholesky is free now), every thread accumulating its own (d,a,b) entries
-    {
-      const int TCH = ((r * PSD_NB + PSD_NB * PSD_CH) / nch) - P.Ln;          // time steps per chunk that fit with the lag overlap
-      double* xc = pan;                                                       // xc[(t - t0) * nch + ch], t0 <= t < t0 + TCH + Ln
-      for (int e = tid; e < nlag; e += nthr) Ctab[e] = 0.0;
-      for (int t0 = 0; t0 < c; t0 += TCH) {
-        const int nt = (c - t0) < TCH ? (c - t0) : TCH;                        // terms of this chunk
-        const int nload = nt + P.Ln - 1;                                      // time steps needed (x_a[t+d], d < Ln)
-        __syncthreads();
-        for (int i = tid; i < nload * nch; i += nthr) {
-          const int tt = i / nch, ch = i - tt * nch;
-          xc[i] = xat(ch, t0 + tt);
-        }
-        __syncthreads();
-        for (int e = tid; e < nlag; e += nthr) {
-          const int d = e / (nch * nch), ab = e - d * nch * nch, a = ab / nch, bb = ab - a * nch;
-          const double* xa = xc + d * nch + a;
-          const double* xb = xc + bb;
-          double s0 = 0.0, s1 = 0.0;
-          int t = 0;
-          for (; t + 1 < nt; t += 2) { s0 += xa[t * nch] * xb[t * nch]; s1 += xa[(t + 1) * nch] * xb[(t + 1) * nch]; }
-          if (t < nt) s0 += xa[t * nch] * xb[t * nch];
-          Ctab[e] += s0 + s1;
-        }
-      }
-    }
     for (int i = tid; i < r; i += nthr) iperm[perm[i]] = i;
-    __syncthreads();
-    // one (lag, channel pair) diagonal per thread-iteration, walked with the O(1) window update; every unordered
-    // pair of components is met exactly once (lag 0: channel pairs a >= b only)
-    for (int e = tid; e < nlag; e += nthr) {
-      const int d = e / (nch * nch), ab = e - d * nch * nch, a = ab / nch, bb = ab - a * nch;
-      if (d == 0 && a < bb) continue;
-      double s = Ctab[e];
-      for (int k = 0; k + d < P.Ln; ++k) {
-        if (k > 0) s += xat(a, k - 1 + c + d) * xat(bb, k - 1 + c) - xat(a, k - 1 + d) * xat(bb, k - 1);
-        const int pi = iperm[(k + d) * nch + a], pj = iperm[k * nch + bb];
-        const int hi = pi > pj ? pi : pj, lo = pi > pj ? pj : pi;
-        G[hi * (hi + 1) / 2 + lo] = s;
-      }
-    }
+    hankel_gram_packed(P, ud, yd, G, T, iperm, pan);
   } else {
     for (int e = tid; e < npk; e += nthr) {
       const int i = tri_row(e), j = e - i * (i + 1) / 2;
@@ -948,6 +961,143 @@ __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RP
     status[b] = !(fabs(tot) < 1e300) ? 4 : (feasible ? 0 : 2);      // 2 = "infeasible"
     if (iters) iters[b] = 1;
     if (dbg) dbg[b * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Problems with more rows than the register-resident cold kernels hold ((m+p)(L+n) > 271): the same reduced system
+//   (G + lam*D) beta = t,  z = t - lam*D*beta,  primal-dual active set on the slack box (CONVEX)
+// with the matrices in a per-instance slice of a global workspace (packed lower triangles of G and of the factor),
+// plain VALU code: Hankel-structured Gram, panel-blocked Cholesky (panel in LDS), row-wise substitutions.  Same
+// component tables, outputs, status and iteration count as ddmpc_cold_solve_kernel (ddmpc_kernels.hpp), diagonal
+// weights only.  One workgroup of 256 threads per instance.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ddmpc_large_solve_kernel(KParams P, int RPs, const double* __restrict__ u_d,
+                                                                const double* __restrict__ y_d,
+                                                                const double* __restrict__ u_past,
+                                                                const double* __restrict__ y_past,
+                                                                double* __restrict__ u_opt, double* __restrict__ cost,
+                                                                int* __restrict__ status, int* __restrict__ iters,
+                                                                double* __restrict__ beta_ws,
+                                                                signed char* __restrict__ act_ws, double* scratch,
+                                                                long long scratch_stride) {
+  extern __shared__ __attribute__((aligned(16))) double lsm_lds[];
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int r = P.r, m = P.m, p = P.p;
+  const int n = P.npu / m;
+  const int rv = (r + 1) & ~1;
+  double* ct = lsm_lds;                                 // target of the component without the bound shift
+  double* tv = ct + rv;                                 // right-hand side of the current active set
+  double* dv = tv + rv;                                 // D of the current active set
+  double* bv = dv + rv;                                 // y, then beta
+  int* act = reinterpret_cast<int*>(bv + rv);
+  int* skip = act + rv;
+  double* pan = reinterpret_cast<double*>(skip + rv);
+  const int npk = r * (r + 1) / 2;
+  double* G = scratch + b * scratch_stride;             // Gram, kept across active-set iterations
+  double* K = G + npk;                                  // G + lam*D -> its Cholesky factor
+  __shared__ double red[8];
+  __shared__ int flag[1];
+  const double* ud = u_d + b * (long long)P.N * m;
+  const double* yd = y_d + b * (long long)P.N * p;
+  const double* up = u_past + b * (long long)P.npu;
+  const double* yp = y_past + b * (long long)(n * p);
+  for (int rho = tid; rho < r; rho += nthr) {
+    const int pidx = P.tabi[1 * RPs + rho];
+    ct[rho] = (pidx >= 0) ? ((pidx < P.npu) ? up[pidx] : yp[pidx - P.npu]) : P.tabd[2 * RPs + rho];
+    act[rho] = 0;
+  }
+  hankel_gram_packed(P, ud, yd, G, K, nullptr, pan);    // lag table in the (not yet used) factor storage
+  __syncthreads();
+  int iter = 0, st = 0;
+  while (true) {
+    ++iter;
+    for (int e = tid; e < npk; e += nthr) K[e] = G[e];
+    __syncthreads();
+    for (int rho = tid; rho < r; rho += nthr) {
+      const int a = act[rho];
+      const double D = a ? P.tabd[1 * RPs + rho] : P.tabd[0 * RPs + rho];
+      dv[rho] = D;
+      tv[rho] = ct[rho] + a * P.bound;
+      K[rho * (rho + 1) / 2 + rho] += P.lam * D;
+    }
+    __syncthreads();
+    packed_psd_cholesky(K, r, 0.0, skip, pan);          // a pivot that is not positive is skipped and counted below
+    double nbad = 0.0;
+    for (int rho = tid; rho < r; rho += nthr) nbad += skip[rho] ? 1.0 : 0.0;
+    if (block_sum(nbad, red) != 0.0) { st = 4; break; } // uniform
+    __syncthreads();
+    for (int k = 0; k < r; ++k) {                       // L y = t, row by row, the dot product spread over the workgroup
+      const double* Lk = K + k * (k + 1) / 2;
+      double part = 0.0;
+      for (int j = tid; j < k; j += nthr) part += Lk[j] * bv[j];
+      const double s = tv[k] - block_sum(part, red);
+      if (tid == 0) bv[k] = s / Lk[k];
+      __syncthreads();
+    }
+    for (int a = r - 1; a >= 0; --a) {                  // L' beta = y
+      double part = 0.0;
+      for (int i = a + 1 + tid; i < r; i += nthr) part += K[i * (i + 1) / 2 + a] * bv[i];
+      const double s = bv[a] - block_sum(part, red);
+      if (tid == 0) bv[a] = s / K[a * (a + 1) / 2 + a];
+      __syncthreads();
+    }
+    if (!P.convex) break;
+    // slack box: primal-dual active-set update (sigma[n*p:], controller.py:659)
+    if (tid == 0) flag[0] = 0;
+    __syncthreads();
+    const double scale = -P.lam / P.lamb_sigma;
+    for (int rho = tid; rho < r; rho += nthr) {
+      const int kind = P.tabi[0 * RPs + rho];
+      if (kind == K_WPRED || kind == K_WTERM) {
+        const double sh = scale * bv[rho];
+        const int ns = (sh > P.bound) ? 1 : (sh < -P.bound) ? -1 : 0;
+        if (ns != act[rho]) { act[rho] = ns; flag[0] = 1; }
+      }
+    }
+    __syncthreads();
+    const int changed = flag[0];
+    __syncthreads();
+    if (!changed) break;
+    if (iter >= P.max_iter) { st = 4; break; }
+  }
+  // ---- outputs: z = t - lam*D*beta; cost = control cost + lam*beta'z + lamb_sigma*|sigma|^2 --------------------
+  double part = 0.0, bad = 0.0;
+  double* uo = u_opt + b * (long long)((P.Ln - n) * m);
+  if (st == 0) {
+    for (int rho = tid; rho < r; rho += nthr) {
+      const int s_act = act[rho];
+      const double bb = bv[rho];
+      const double t = tv[rho];
+      const double z = t - P.lam * dv[rho] * bb;
+      const double wq = P.tabd[3 * RPs + rho];
+      const double tb = P.tabd[2 * RPs + rho];          // setpoint of the component (u_s / y_s)
+      const int oidx = P.tabi[2 * RPs + rho];
+      const int kind = P.tabi[0 * RPs + rho];
+      if (!(fabs(bb) < 1e300)) bad = 1.0;
+      double contrib = P.lam * bb * z;
+      if (kind == K_UFREE || kind == K_YFREE) { const double dlt = z - tb; contrib += wq * dlt * dlt; }
+      else if (kind == K_WINT) { const double sg = z - ct[rho]; contrib += P.lamb_sigma * sg * sg; }
+      else if (kind == K_WTERM) { const double sg = z - tb; contrib += P.lamb_sigma * sg * sg; }
+      else if (kind == K_WPRED) {
+        const double sg = (s_act != 0) ? s_act * P.bound : -P.lam * bb / P.lamb_sigma;
+        const double dlt = z - sg - tb;
+        contrib += wq * dlt * dlt + P.lamb_sigma * sg * sg;
+      }
+      part += contrib;
+      if (oidx >= 0) uo[oidx] = z;                      // ubar[n*m:], controller.py:799-805
+      if (beta_ws) beta_ws[b * (long long)P.rE + rho] = bb;
+      if (act_ws) act_ws[b * (long long)P.rE + rho] = (signed char)s_act;
+    }
+  }
+  const double tot = block_sum(part, red);
+  const double nbad = block_sum(bad, red);
+  if (tid == 0) {
+    if (nbad != 0.0 || !(fabs(tot) < 1e300)) st = 4;
+    cost[b] = tot;
+    status[b] = st;
+    if (iters) iters[b] = iter;
   }
 }
 

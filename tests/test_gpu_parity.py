@@ -372,6 +372,30 @@ def test_long_horizon_config4(gpu, slack):
     assert al.shape == (B, 937)
 
 
+@pytest.mark.parametrize("slack", [0, 1], ids=["none", "convex"])
+def test_robust_scheme_beyond_the_register_resident_kernels(gpu, slack):
+    # (m+p)(L+n) = 296 rows > 271: ddmpc_large_solve_kernel (matrices in a global workspace), same outputs,
+    # status, iteration count and reconstructed variables as the register-resident kernels
+    spec = orc.spec_from_params(L=70, N=1200, slack_var_constraint_type=slack)
+    B = 3
+    u_d, y_d, up, yp = _instances(B, N=1200, seed0=21)
+    with _engine(spec, 1200, B) as eng:
+        assert "large_solve" in eng.kernel_name()
+        eng.set_data(u_d, y_d)
+        u, cost, status, iters = eng.solve(up, yp)
+        u2, cost2, status2, _ = eng.step(up, yp)                    # no affine law at this size: a step is a solve
+        al = eng.get_solution("alpha"); sg = eng.get_solution("sigma"); yb = eng.get_solution("ybar")
+    _check(spec, u_d, y_d, up, yp, u, cost, status, range(B))
+    assert np.array_equal(u, u2) and np.array_equal(cost, cost2) and np.array_equal(status, status2)
+    for b in range(B):
+        ref = orc.solve_fullspace(spec, u_d[b], y_d[b], up[b], yp[b])
+        if slack == 1:
+            assert int(iters[b]) == ref.iters
+        assert np.max(np.abs(sg[b] - ref.sigma.ravel())) <= 1e-9 * max(1.0, np.max(np.abs(ref.sigma)))
+        assert np.max(np.abs(yb[b] - ref.ybar.ravel())) <= 1e-9
+        assert np.max(np.abs(al[b] - ref.alpha.ravel())) <= 1e-8 * max(1e-3, np.max(np.abs(ref.alpha)))
+
+
 def test_convex_active_set_converges_on_full_batch(gpu):
     # slack CONVEX on 4096 seeds: every instance must reach a stable active set ("optimal"),
     # a sample is compared with the full-space oracle, and the bound must hold everywhere
@@ -1149,8 +1173,25 @@ def test_config5_size_nominal_runs_on_the_rank_revealing_kernel(gpu):
         assert ref["status"] == "optimal" and ref["rank"] == m * (Lh + n) + ns and int(status[b]) == 0
         assert np.max(np.abs(u[b] - ref["optimal_u"])) / np.max(np.abs(ref["optimal_u"])) < 1e-7, b
         assert abs(cost[b] - ref["cost"]) <= 1e-9 * abs(ref["cost"])
-    # the robust scheme at this size has no kernel: reported at create time
+    # the robust scheme at this size runs on ddmpc_large_solve_kernel (noisy data of the same plant)
     specr = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=3.0 * np.eye(p * Lh), R=1e-4 * np.eye(m * Lh), u_s=u_s, y_s=y_s, robust=True,
-                       eps_max=0.002, lamb_alpha=50.0, lamb_sigma=1000.0, c=1.0, slack="none", tec=True)
+                       eps_max=0.002, lamb_alpha=50.0, lamb_sigma=1000.0, c=1.0, slack="convex", tec=True)
+    dn = generate_batch(range(B), N=N, plant=dict(plant, eps_max=0.002))
+    upn = dn["u_d"][:, -n:, :].reshape(B, -1).copy(); ypn = dn["y_d"][:, -n:, :].reshape(B, -1).copy()
+    with _engine(specr, N, B) as eng:
+        assert eng.kernel_name() == "ddmpc_large_solve_kernel"
+        eng.set_data(dn["u_d"], dn["y_d"])
+        ur, costr, statusr, itr = eng.solve(upn, ypn)
+    # cond(G + lam*D) is ~8e11 at this size (G grows with N and r, lam*D does not): the reduced route in fp64 is good to
+    # ~1e-7 here (the full-space oracle agrees with an 80-bit solve of the reduced system to 1e-9) -- partial parity,
+    # like the nominal scheme above; well-conditioned large problems meet the 1e-8 bar
+    # (test_robust_scheme_beyond_the_register_resident_kernels)
+    for b in range(B):
+        sol = orc.solve_fullspace(specr, dn["u_d"][b], dn["y_d"][b], upn[b], ypn[b])
+        assert L.STATUS_STRINGS[int(statusr[b])] == sol.status == "optimal" and int(itr[b]) == sol.iters
+        assert np.max(np.abs(ur[b] - sol.optimal_u)) / np.max(np.abs(sol.optimal_u)) < 1e-6
+        assert abs(costr[b] - sol.cost) / abs(sol.cost) < 1e-7
+    # dense weighting matrices stay limited to the register-resident kernels
     with pytest.raises(L.DDMPCError, match="too large"):
-        _engine(specr, N, 1)
+        BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=3.0 * np.eye(p * Lh) + 0.01, R=1e-4 * np.eye(m * Lh), u_s=u_s, y_s=y_s,
+                     batch=1, controller_type=L.ROBUST, eps_max=0.002, lamb_alpha=50.0, lamb_sigma=1000.0, c=1.0)
