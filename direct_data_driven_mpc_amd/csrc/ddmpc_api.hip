@@ -541,6 +541,12 @@ int ddmpc_set_data(ddmpc_handle* h, const double* u_d, const double* y_d, int me
   return DDMPC_OK;
 }
 
+static unsigned large_threads() {          // workgroup size of the global-workspace kernels (development knob)
+  const char* e = getenv("DDMPC_LARGE_THREADS");
+  const int v = e ? atoi(e) : 512;
+  return (v == 256 || v == 128) ? (unsigned)v : 512u;
+}
+
 static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
                        int32_t* status, int32_t* iters, double* lfac = nullptr, const int* only = nullptr,
                        const KParams* kp_override = nullptr) {
@@ -558,7 +564,7 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
     if (lds + 1024 > 160 * 1024) return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: %zu rows", r);
     if (lds > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_large_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ddmpc_large_solve_kernel, dim3((unsigned)h->batch), dim3(256), lds, h->stream,
+    hipLaunchKernelGGL(ddmpc_large_solve_kernel, dim3((unsigned)h->batch), dim3(large_threads()), lds, h->stream,
                        kp_override ? *kp_override : h->kp, 16 * h->kc.NT, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                        (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, (double*)h->d_rr.p, (long long)(2 * npk));
     HIP_TRY(hipGetLastError());
@@ -626,7 +632,7 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
   // rank tolerance 1e-8 (relative to the largest diagonal entry of the Gram): with the fixed-first ordering the
   // pivots of dependent rows come out as rounding residue up to ~3e-10, genuine ones are >= ~5e-7 on exact
   // four-tank data (L = 10 .. 60)
-  hipLaunchKernelGGL(ddmpc_nominal_rr_kernel, dim3((unsigned)h->batch), dim3(256), lds, h->stream, h->kp, 16 * h->kc.NT,
+  hipLaunchKernelGGL(ddmpc_nominal_rr_kernel, dim3((unsigned)h->batch), dim3(large_threads()), lds, h->stream, h->kp, 16 * h->kc.NT,
                      h->ud, h->yd, up, yp, uo, cost, (int*)status, (int*)iters, 1e-8, 1e-7, scratch, (long long)ndbl,
                      (h->stamps_on && h->d_stamps.bytes >= (size_t)h->batch * 8 * sizeof(uint64_t)) ? (unsigned long long*)h->d_stamps.p
                                                                                                       : (unsigned long long*)nullptr);

@@ -763,7 +763,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return t;
 }
 
-__global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RPs, const double* __restrict__ u_d,
+__global__ __launch_bounds__(512) void ddmpc_nominal_rr_kernel(KParams P, int RPs, const double* __restrict__ u_d,
                                                                const double* __restrict__ y_d,
                                                                const double* __restrict__ u_past,
                                                                const double* __restrict__ y_past,
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RP
   double* rsm = scratch ? scratch + b * scratch_stride : pan + (size_t)r * PSD_NB + PSD_NB * PSD_CH;
   double* G = rsm;                                      // r(r+1)/2
   double* T = G + r * (r + 1) / 2;                      // nR(nR+1)/2
-  __shared__ double red[8];
+  __shared__ double red[16];
   __shared__ int cnt[2];
   const double* ud = u_d + b * (long long)P.N * m;
   const double* yd = y_d + b * (long long)P.N * p;
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256) void ddmpc_nominal_rr_kernel(KParams P, int RP
 // component tables, outputs, status and iteration count as ddmpc_cold_solve_kernel (ddmpc_kernels.hpp), diagonal
 // weights only.  One workgroup of 256 threads per instance.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ddmpc_large_solve_kernel(KParams P, int RPs, const double* __restrict__ u_d,
+__global__ __launch_bounds__(512) void ddmpc_large_solve_kernel(KParams P, int RPs, const double* __restrict__ u_d,
                                                                 const double* __restrict__ y_d,
                                                                 const double* __restrict__ u_past,
                                                                 const double* __restrict__ y_past,
@@ -997,7 +997,7 @@ __global__ __launch_bounds__(256) void ddmpc_large_solve_kernel(KParams P, int R
   const int npk = r * (r + 1) / 2;
   double* G = scratch + b * scratch_stride;             // Gram, kept across active-set iterations
   double* K = G + npk;                                  // G + lam*D -> its Cholesky factor
-  __shared__ double red[8];
+  __shared__ double red[16];
   __shared__ int flag[1];
   const double* ud = u_d + b * (long long)P.N * m;
   const double* yd = y_d + b * (long long)P.N * p;
