@@ -224,7 +224,7 @@ def main():
     # ---- secondary metric (SURVEY 8d "warm" step), outside the timed region: rank 0, one GPU's share.
     # After ddmpc_prepare a control step only evaluates the per-instance affine law (slack NONE).
     warm = None
-    if rank == 0 and a.slack == "none" and not a.no_warm:
+    if rank == 0 and world == 1 and a.slack == "none" and not a.no_warm:      # N=1 only: the other ranks must not wait on it
         u_cold = u_opt.clone(); c_cold = cost.clone()
         torch.cuda.synchronize(); tp = time.perf_counter()
         eng.prepare()
