@@ -194,6 +194,11 @@ def main():
 
     for _ in range(a.warmup):
         eng.solve(up, yp, u_opt, cost, status, iters)
+    if world > 1 and a.warmup > 0:              # the gather's first call sets up RCCL channels: part of the warm-up
+        if a.rehearse_on_one_gpu:
+            gather_results(u_opt.cpu(), cost.cpu(), status.cpu(), total)
+        else:
+            gather_results(u_opt, cost, status, total)
     torch.cuda.synchronize()
     # ---- timed region: exactly K steps + the final gather ------------------------
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]

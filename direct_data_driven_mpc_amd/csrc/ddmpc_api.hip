@@ -557,16 +557,19 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
   }
   if (h->large) {                  // robust scheme beyond the register-resident kernels: matrices in a global workspace
     const size_t r = (size_t)h->kp.r, npk = r * (r + 1) / 2, rv = (r + 1) & ~(size_t)1;
-    if ((rc = h->d_rr.ensure((size_t)h->batch * 2 * npk * sizeof(double)))) return rc;
+    const size_t nB = h->kp.convex ? (size_t)h->prm.p * h->prm.L : 0;      // components the slack box acts on
+    const size_t nlag = (size_t)h->kp.Ln * h->kp.nch * h->kp.nch, sb = nB * (nB + 1);
+    const size_t stride = npk + (nlag > sb ? nlag : sb);
+    if ((rc = h->d_rr.ensure((size_t)h->batch * stride * sizeof(double)))) return rc;
     if ((rc = h->d_beta.ensure((size_t)h->batch * h->kp.rE * sizeof(double)))) return rc;
     if ((rc = h->d_act.ensure((size_t)h->batch * h->kp.rE))) return rc;
-    const size_t lds = 4 * rv * sizeof(double) + 2 * rv * sizeof(int) + (r * PSD_NB + PSD_NB * PSD_CH) * sizeof(double);
+    const size_t lds = 4 * rv * sizeof(double) + 4 * rv * sizeof(int) + (r * PSD_NB + PSD_NB * PSD_CH) * sizeof(double);
     if (lds + 1024 > 160 * 1024) return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: %zu rows", r);
     if (lds > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_large_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(ddmpc_large_solve_kernel, dim3((unsigned)h->batch), dim3(large_threads()), lds, h->stream,
                        kp_override ? *kp_override : h->kp, 16 * h->kc.NT, h->ud, h->yd, up, yp, uo, cost, (int*)status,
-                       (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, (double*)h->d_rr.p, (long long)(2 * npk));
+                       (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, (double*)h->d_rr.p, (long long)stride);
     HIP_TRY(hipGetLastError());
     return DDMPC_OK;
   }

@@ -631,12 +631,15 @@ __device__ __forceinline__ int tri_row(int e) {
 // All threads of the workgroup must call it.
 constexpr int PSD_NB = 16;      // panel width
 constexpr int PSD_CH = 64;      // columns of the factor staged per chunk
-__device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol_abs, int* skip, double* pan) {
+// `ncols` < n stops after the first ncols columns (rows >= ncols of those columns hold the factor's off-diagonal
+// block, the trailing block is left untouched).
+__device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol_abs, int* skip, double* pan, int ncols = -1) {
   const int tid = threadIdx.x, nthr = blockDim.x;
   double* Pn = pan;                           // Pn[(i - k0) * PSD_NB + c] = A(i, k0 + c)
   double* Lp = pan + (size_t)n * PSD_NB;      // Lp[c * PSD_CH + jj]      = A(k0 + c, j0 + jj)
-  for (int k0 = 0; k0 < n; k0 += PSD_NB) {
-    const int nb = (n - k0) < PSD_NB ? (n - k0) : PSD_NB;
+  if (ncols < 0) ncols = n;
+  for (int k0 = 0; k0 < ncols; k0 += PSD_NB) {
+    const int nb = (ncols - k0) < PSD_NB ? (ncols - k0) : PSD_NB;
     // (1) + (2): panel rows, minus the contribution of the columns factored so far
     for (int i0 = k0; i0 < n; i0 += nthr) {
       const int i = i0 + tid;
@@ -967,10 +970,13 @@ __global__ __launch_bounds__(512) void ddmpc_nominal_rr_kernel(KParams P, int RP
 // ---------------------------------------------------------------------------------------------------------------
 // Problems with more rows than the register-resident cold kernels hold ((m+p)(L+n) > 271): the same reduced system
 //   (G + lam*D) beta = t,  z = t - lam*D*beta,  primal-dual active set on the slack box (CONVEX)
-// with the matrices in a per-instance slice of a global workspace (packed lower triangles of G and of the factor),
-// plain VALU code: Hankel-structured Gram, panel-blocked Cholesky (panel in LDS), row-wise substitutions.  Same
-// component tables, outputs, status and iteration count as ddmpc_cold_solve_kernel (ddmpc_kernels.hpp), diagonal
-// weights only.  One workgroup of 256 threads per instance.
+// with the matrices in a per-instance slice of a global workspace (packed lower triangles), plain VALU code:
+// Hankel-structured Gram, panel-blocked Cholesky (panel in LDS), row-wise substitutions.  The components the slack
+// box acts on (set B, the sigma rows of the prediction window) are ordered LAST: the factor of the other columns
+// (set A) and the Schur complement S = K_BB - L_BA L_BA' are formed once, and an active-set iteration only
+// re-factors S + lam*D_B(active set) (|B| = p*L rows) and substitutes through it.  Same component tables, outputs,
+// status and iteration count as ddmpc_cold_solve_kernel (ddmpc_kernels.hpp), diagonal weights only.  One workgroup
+// per instance.  Workspace per instance: r(r+1)/2 + max(Ln*nch^2, 2*|B|(|B|+1)/2) doubles.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void ddmpc_large_solve_kernel(KParams P, int RPs, const double* __restrict__ u_d,
                                                                 const double* __restrict__ y_d,
@@ -987,90 +993,158 @@ __global__ __launch_bounds__(512) void ddmpc_large_solve_kernel(KParams P, int R
   const int r = P.r, m = P.m, p = P.p;
   const int n = P.npu / m;
   const int rv = (r + 1) & ~1;
+  // r-vectors, indexed by POSITION in the elimination order (A first, B last)
   double* ct = lsm_lds;                                 // target of the component without the bound shift
-  double* tv = ct + rv;                                 // right-hand side of the current active set
-  double* dv = tv + rv;                                 // D of the current active set
-  double* bv = dv + rv;                                 // y, then beta
-  int* act = reinterpret_cast<int*>(bv + rv);
+  double* yv = ct + rv;                                 // y = L^-1 t  (A part fixed, B part per iteration)
+  double* bv = yv + rv;                                 // beta
+  double* zb = bv + rv;                                 // L_BA y_A (B part only)
+  int* act = reinterpret_cast<int*>(zb + rv);
   int* skip = act + rv;
-  double* pan = reinterpret_cast<double*>(skip + rv);
+  int* perm = skip + rv;                                // position -> component
+  int* iperm = perm + rv;                               // component -> position
+  double* pan = reinterpret_cast<double*>(iperm + rv);
   const int npk = r * (r + 1) / 2;
-  double* G = scratch + b * scratch_stride;             // Gram, kept across active-set iterations
-  double* K = G + npk;                                  // G + lam*D -> its Cholesky factor
+  double* G = scratch + b * scratch_stride;             // Gram -> [L_AA; L_BA] in its first nA columns
   __shared__ double red[16];
   __shared__ int flag[1];
+  __shared__ int cnt[1];
   const double* ud = u_d + b * (long long)P.N * m;
   const double* yd = y_d + b * (long long)P.N * p;
   const double* up = u_past + b * (long long)P.npu;
   const double* yp = y_past + b * (long long)(n * p);
-  for (int rho = tid; rho < r; rho += nthr) {
-    const int pidx = P.tabi[1 * RPs + rho];
-    ct[rho] = (pidx >= 0) ? ((pidx < P.npu) ? up[pidx] : yp[pidx - P.npu]) : P.tabd[2 * RPs + rho];
-    act[rho] = 0;
-  }
-  hankel_gram_packed(P, ud, yd, G, K, nullptr, pan);    // lag table in the (not yet used) factor storage
-  __syncthreads();
-  int iter = 0, st = 0;
-  while (true) {
-    ++iter;
-    for (int e = tid; e < npk; e += nthr) K[e] = G[e];
-    __syncthreads();
-    for (int rho = tid; rho < r; rho += nthr) {
-      const int a = act[rho];
-      const double D = a ? P.tabd[1 * RPs + rho] : P.tabd[0 * RPs + rho];
-      dv[rho] = D;
-      tv[rho] = ct[rho] + a * P.bound;
-      K[rho * (rho + 1) / 2 + rho] += P.lam * D;
-    }
-    __syncthreads();
-    packed_psd_cholesky(K, r, 0.0, skip, pan);          // a pivot that is not positive is skipped and counted below
-    double nbad = 0.0;
-    for (int rho = tid; rho < r; rho += nthr) nbad += skip[rho] ? 1.0 : 0.0;
-    if (block_sum(nbad, red) != 0.0) { st = 4; break; } // uniform
-    __syncthreads();
-    for (int k = 0; k < r; ++k) {                       // L y = t, row by row, the dot product spread over the workgroup
-      const double* Lk = K + k * (k + 1) / 2;
-      double part = 0.0;
-      for (int j = tid; j < k; j += nthr) part += Lk[j] * bv[j];
-      const double s = tv[k] - block_sum(part, red);
-      if (tid == 0) bv[k] = s / Lk[k];
-      __syncthreads();
-    }
-    for (int a = r - 1; a >= 0; --a) {                  // L' beta = y
-      double part = 0.0;
-      for (int i = a + 1 + tid; i < r; i += nthr) part += K[i * (i + 1) / 2 + a] * bv[i];
-      const double s = bv[a] - block_sum(part, red);
-      if (tid == 0) bv[a] = s / K[a * (a + 1) / 2 + a];
-      __syncthreads();
-    }
-    if (!P.convex) break;
-    // slack box: primal-dual active-set update (sigma[n*p:], controller.py:659)
-    if (tid == 0) flag[0] = 0;
-    __syncthreads();
-    const double scale = -P.lam / P.lamb_sigma;
-    for (int rho = tid; rho < r; rho += nthr) {
+  if (tid == 0) {                                       // elimination order: boxed components last
+    int na = 0;
+    for (int rho = 0; rho < r; ++rho) {
       const int kind = P.tabi[0 * RPs + rho];
-      if (kind == K_WPRED || kind == K_WTERM) {
-        const double sh = scale * bv[rho];
-        const int ns = (sh > P.bound) ? 1 : (sh < -P.bound) ? -1 : 0;
-        if (ns != act[rho]) { act[rho] = ns; flag[0] = 1; }
-      }
+      if (!(P.convex && (kind == K_WPRED || kind == K_WTERM))) perm[na++] = rho;
+    }
+    cnt[0] = na;
+    for (int rho = 0; rho < r; ++rho) {
+      const int kind = P.tabi[0 * RPs + rho];
+      if (P.convex && (kind == K_WPRED || kind == K_WTERM)) perm[na++] = rho;
+    }
+  }
+  __syncthreads();
+  const int nA = cnt[0], nB = r - nA;
+  const int npB = nB * (nB + 1) / 2;
+  double* S = G + npk;                                  // Schur complement of the B block (without lam*D_B)
+  double* T = S + npB;                                  // S + lam*D_B -> its factor
+  for (int i = tid; i < r; i += nthr) {
+    const int rho = perm[i];
+    iperm[rho] = i;
+    const int pidx = P.tabi[1 * RPs + rho];
+    ct[i] = (pidx >= 0) ? ((pidx < P.npu) ? up[pidx] : yp[pidx - P.npu]) : P.tabd[2 * RPs + rho];
+    act[i] = 0;
+  }
+  __syncthreads();
+  hankel_gram_packed(P, ud, yd, G, G + npk, iperm, pan);   // lag table in the (not yet used) storage behind G
+  __syncthreads();
+  for (int i = tid; i < nA; i += nthr) G[i * (i + 1) / 2 + i] += P.lam * P.tabd[0 * RPs + perm[i]];
+  __syncthreads();
+  packed_psd_cholesky(G, r, 0.0, skip, pan, nA);        // columns of A only; a pivot that is not positive is skipped
+  int st = 0, iter = 0;
+  {
+    double nbad = 0.0;
+    for (int i = tid; i < nA; i += nthr) nbad += skip[i] ? 1.0 : 0.0;
+    if (block_sum(nbad, red) != 0.0) st = 4;            // uniform
+  }
+  __syncthreads();
+  if (st == 0) {
+    // S = K_BB - L_BA L_BA'  (the diagonal shift of B is added per active set)
+    for (int e = tid; e < npB; e += nthr) {
+      const int i = tri_row(e), j = e - i * (i + 1) / 2;
+      const double* Li = G + (size_t)(nA + i) * (nA + i + 1) / 2;
+      const double* Lj = G + (size_t)(nA + j) * (nA + j + 1) / 2;
+      double s0 = 0.0, s1 = 0.0;
+      int k = 0;
+      for (; k + 1 < nA; k += 2) { s0 += Li[k] * Lj[k]; s1 += Li[k + 1] * Lj[k + 1]; }
+      if (k < nA) s0 += Li[k] * Lj[k];
+      S[e] = Li[nA + j] - (s0 + s1);
+    }
+    // L_AA y_A = t_A, row by row, the dot product spread over the workgroup (t_A does not depend on the active set)
+    for (int k = 0; k < nA; ++k) {
+      const double* Lk = G + (size_t)k * (k + 1) / 2;
+      double part = 0.0;
+      for (int j = tid; j < k; j += nthr) part += Lk[j] * yv[j];
+      const double s = ct[k] - block_sum(part, red);
+      if (tid == 0) yv[k] = s / Lk[k];
+      __syncthreads();
+    }
+    for (int i = tid; i < nB; i += nthr) {               // zb = L_BA y_A
+      const double* Li = G + (size_t)(nA + i) * (nA + i + 1) / 2;
+      double s = 0.0;
+      for (int k = 0; k < nA; ++k) s += Li[k] * yv[k];
+      zb[i] = s;
     }
     __syncthreads();
-    const int changed = flag[0];
-    __syncthreads();
-    if (!changed) break;
-    if (iter >= P.max_iter) { st = 4; break; }
+    // ---- active-set iterations on the B block --------------------------------------------------------------
+    while (true) {
+      ++iter;
+      if (nB == 0) break;
+      for (int e = tid; e < npB; e += nthr) T[e] = S[e];
+      __syncthreads();
+      for (int i = tid; i < nB; i += nthr) {
+        const int rho = perm[nA + i];
+        const double D = act[nA + i] ? P.tabd[1 * RPs + rho] : P.tabd[0 * RPs + rho];
+        T[i * (i + 1) / 2 + i] += P.lam * D;
+      }
+      __syncthreads();
+      packed_psd_cholesky(T, nB, 0.0, skip + nA, pan);
+      double nbad = 0.0;
+      for (int i = tid; i < nB; i += nthr) nbad += skip[nA + i] ? 1.0 : 0.0;
+      if (block_sum(nbad, red) != 0.0) { st = 4; break; }
+      __syncthreads();
+      for (int k = 0; k < nB; ++k) {                     // L_BB y_B = t_B - L_BA y_A
+        const double* Tk = T + (size_t)k * (k + 1) / 2;
+        double part = 0.0;
+        for (int j = tid; j < k; j += nthr) part += Tk[j] * yv[nA + j];
+        const double s = (ct[nA + k] + act[nA + k] * P.bound) - zb[k] - block_sum(part, red);
+        if (tid == 0) yv[nA + k] = s / Tk[k];
+        __syncthreads();
+      }
+      for (int a = nB - 1; a >= 0; --a) {                // L_BB' beta_B = y_B
+        double part = 0.0;
+        for (int i = a + 1 + tid; i < nB; i += nthr) part += T[(size_t)i * (i + 1) / 2 + a] * bv[nA + i];
+        const double s = yv[nA + a] - block_sum(part, red);
+        if (tid == 0) bv[nA + a] = s / T[(size_t)a * (a + 1) / 2 + a];
+        __syncthreads();
+      }
+      // slack box: primal-dual active-set update (sigma[n*p:], controller.py:659); B holds exactly those components
+      if (tid == 0) flag[0] = 0;
+      __syncthreads();
+      const double scale = -P.lam / P.lamb_sigma;
+      for (int i = tid; i < nB; i += nthr) {
+        const double sh = scale * bv[nA + i];
+        const int ns = (sh > P.bound) ? 1 : (sh < -P.bound) ? -1 : 0;
+        if (ns != act[nA + i]) { act[nA + i] = ns; flag[0] = 1; }
+      }
+      __syncthreads();
+      const int changed = flag[0];
+      __syncthreads();
+      if (!changed) break;
+      if (iter >= P.max_iter) { st = 4; break; }
+    }
+  }
+  if (st == 0) {
+    for (int a = nA - 1; a >= 0; --a) {                  // L_AA' beta_A = y_A - L_BA' beta_B
+      double part = 0.0;
+      for (int i = a + 1 + tid; i < r; i += nthr) part += G[(size_t)i * (i + 1) / 2 + a] * bv[i];
+      const double s = yv[a] - block_sum(part, red);
+      if (tid == 0) bv[a] = s / G[(size_t)a * (a + 1) / 2 + a];
+      __syncthreads();
+    }
   }
   // ---- outputs: z = t - lam*D*beta; cost = control cost + lam*beta'z + lamb_sigma*|sigma|^2 --------------------
   double part = 0.0, bad = 0.0;
   double* uo = u_opt + b * (long long)((P.Ln - n) * m);
   if (st == 0) {
-    for (int rho = tid; rho < r; rho += nthr) {
-      const int s_act = act[rho];
-      const double bb = bv[rho];
-      const double t = tv[rho];
-      const double z = t - P.lam * dv[rho] * bb;
+    for (int i = tid; i < r; i += nthr) {
+      const int rho = perm[i];
+      const int s_act = act[i];
+      const double bb = bv[i];
+      const double D = s_act ? P.tabd[1 * RPs + rho] : P.tabd[0 * RPs + rho];
+      const double t = ct[i] + s_act * P.bound;
+      const double z = t - P.lam * D * bb;
       const double wq = P.tabd[3 * RPs + rho];
       const double tb = P.tabd[2 * RPs + rho];          // setpoint of the component (u_s / y_s)
       const int oidx = P.tabi[2 * RPs + rho];
@@ -1078,7 +1152,7 @@ __global__ __launch_bounds__(512) void ddmpc_large_solve_kernel(KParams P, int R
       if (!(fabs(bb) < 1e300)) bad = 1.0;
       double contrib = P.lam * bb * z;
       if (kind == K_UFREE || kind == K_YFREE) { const double dlt = z - tb; contrib += wq * dlt * dlt; }
-      else if (kind == K_WINT) { const double sg = z - ct[rho]; contrib += P.lamb_sigma * sg * sg; }
+      else if (kind == K_WINT) { const double sg = z - ct[i]; contrib += P.lamb_sigma * sg * sg; }
       else if (kind == K_WTERM) { const double sg = z - tb; contrib += P.lamb_sigma * sg * sg; }
       else if (kind == K_WPRED) {
         const double sg = (s_act != 0) ? s_act * P.bound : -P.lam * bb / P.lamb_sigma;
@@ -1097,7 +1171,7 @@ __global__ __launch_bounds__(512) void ddmpc_large_solve_kernel(KParams P, int R
     if (nbad != 0.0 || !(fabs(tot) < 1e300)) st = 4;
     cost[b] = tot;
     status[b] = st;
-    if (iters) iters[b] = iter;
+    if (iters) iters[b] = iter > 0 ? iter : 1;
   }
 }
 

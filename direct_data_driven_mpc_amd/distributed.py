@@ -35,15 +35,21 @@ def gather_results(u_opt, cost, status, total: int):
     lo, hi = shard_bounds(total, rank, world)
     assert u_opt.shape[0] == hi - lo
 
-    def _gather(x):
-        pad = torch.zeros((per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        pad[: x.shape[0]] = x
-        out = torch.empty((world * per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, pad)
+    # one collective instead of three: [optimal_u | cost | status] packed per instance (status values are small
+    # integers, exact in float64)
+    nu = u_opt.shape[1]
+    pad = torch.zeros((per, nu + 2), dtype=torch.float64, device=u_opt.device)
+    pad[: hi - lo, :nu] = u_opt
+    pad[: hi - lo, nu] = cost
+    pad[: hi - lo, nu + 1] = status.to(torch.float64)
+    out = torch.empty((world * per, nu + 2), dtype=torch.float64, device=u_opt.device)
+    dist.all_gather_into_tensor(out, pad)
+    if total == world * per:
+        full = out
+    else:
         parts = []
         for r in range(world):
             a, b = shard_bounds(total, r, world)
             parts.append(out[r * per: r * per + (b - a)])
-        return torch.cat(parts, dim=0)
-
-    return _gather(u_opt), _gather(cost), _gather(status)
+        full = torch.cat(parts, dim=0)
+    return full[:, :nu].contiguous(), full[:, nu].contiguous(), full[:, nu + 1].to(status.dtype)
