@@ -429,6 +429,14 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
       return fail(DDMPC_ERR_UNSUPPORTED, "problem too large for the single-workgroup kernels: (m+p)(L+n) = %d rows "
                   "(dense weighting matrices are limited to 271 rows)", k.r);
     }
+    {   // r-vectors and the Cholesky panel of the global-workspace kernels live in LDS (launch_cold / launch_nominal_rescue)
+      const size_t rv = ((size_t)k.r + 1) & ~(size_t)1;
+      const size_t lds = 6 * rv * sizeof(double) + 4 * rv * sizeof(int) + ((size_t)k.r * PSD_NB + PSD_NB * PSD_CH) * sizeof(double);
+      if (lds + 1024 > 160 * 1024) {
+        delete h;
+        return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: (m+p)(L+n) = %d rows (the global-workspace kernels hold about 840)", k.r);
+      }
+    }
     h->large = true;
     h->large_nominal = (p.controller_type == DDMPC_NOMINAL);
     h->kc = h->large_nominal ? kLargeNominal : kLargeSolve;
@@ -630,6 +638,7 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
     scratch = (double*)h->d_rr.p;
     lds = vec_bytes;
   }
+  if (lds + 1024 > 160 * 1024) return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: %zu rows", r);
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_nominal_rr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // rank tolerance 1e-8 (relative to the largest diagonal entry of the Gram): with the fixed-first ordering the

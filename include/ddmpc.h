@@ -120,7 +120,8 @@ int ddmpc_device_count(void);
  * matrices in a global workspace (correct but 1-2e4 solves/s at 608 rows): ROBUST ones on ddmpc_large_solve_kernel
  * (same outputs, status, iterations, ddmpc_get_solution), NOMINAL ones on the rank-revealing kernel (no variable
  * reconstruction).  No affine law at that size: ddmpc_prepare is a no-op, ddmpc_step == ddmpc_solve, ddmpc_get_gain
- * is DDMPC_ERR_UNSUPPORTED.  Dense weighting matrices beyond 271 rows are DDMPC_ERR_UNSUPPORTED.
+ * is DDMPC_ERR_UNSUPPORTED.  Dense weighting matrices beyond 271 rows, and any problem beyond ~840 rows, are
+ * DDMPC_ERR_UNSUPPORTED (reported by ddmpc_create).
  *
  * Replaces DirectDataDrivenMPCController.__init__ parameter validation
  * (controller.py:165-168,211-222,298-343,664-670) for a batch of instances on
