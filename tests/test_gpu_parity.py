@@ -444,6 +444,27 @@ def test_device_closed_loop_matches_oracle(gpu, kw, n_mpc_step):
         assert np.allclose(up_end[b], u_sys[b, -4:].reshape(-1)) and np.allclose(yp_end[b], y_sys[b, -4:].reshape(-1))
 
 
+def test_device_closed_loop_beyond_the_register_resident_kernels(gpu):
+    # the same loop at L = 70 (296 rows): every step is a full solve on ddmpc_large_solve_kernel (slack box on)
+    spec = orc.spec_from_params(L=70, N=1200, slack_var_constraint_type=1)
+    B, n_steps = 2, 6
+    insts = [orc.generate_instance(s, N=1200) for s in range(B)]
+    u_d = np.stack([i["u_d"] for i in insts]); y_d = np.stack([i["y_d"] for i in insts])
+    x0 = np.stack([i["plant"].x for i in insts])
+    w = np.stack([i["plant"].eps_max * i["rng"].uniform(-1.0, 1.0, (n_steps, 2)) for i in insts])
+    up = u_d[:, -4:, :].reshape(B, -1); yp = y_d[:, -4:, :].reshape(B, -1)
+    P = orc.FOUR_TANK
+    with _engine(spec, 1200, B) as eng:
+        assert "large_solve" in eng.kernel_name()
+        eng.set_data(u_d, y_d)
+        u_sys, y_sys, status, x_end, _, _ = eng.closed_loop(P["A"], P["B"], P["C"], P["D"], x0, up, yp, w, n_mpc_step=2)
+    assert np.all(status == 0)
+    for b in range(B):
+        u_ref, y_ref = orc.closed_loop(spec, u_d[b], y_d[b], insts[b]["plant"], w[b], n_mpc_step=2)
+        assert np.max(np.abs(u_sys[b] - u_ref)) / np.max(np.abs(u_ref)) < 1e-8
+        assert np.max(np.abs(y_sys[b] - y_ref)) < 1e-9
+
+
 def test_paper_reproduction_known_answers(gpu):
     # Behavioural known answers of the reference's reproduction script (seed 4, y_0 = [0.4, 0.4],
     # t_sim = 600; examples/robust_data_driven_mpc_reproduction.py:126-295, README figure): TEC and
