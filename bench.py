@@ -29,6 +29,8 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 2.4 GHz x 2048 flop / 64 clk 
 # FETCH_SIZE 28,911 KB x2 (gfx950 counts wide reads at half) + WRITE_SIZE 13,050 KB.
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 PMC_TRAFFIC_BYTES_DEFAULT = (2 * 28911 + 13050) * 1024
+# the same for ddmpc_warm_step_kernel at 4096 instances (profiles/r01_warm_step_pmc_*.csv)
+WARM_PMC_TRAFFIC_BYTES_DEFAULT = (2 * 37824 + 7296) * 1024
 
 
 _ORACLE = {}      # inputs of the CPU baseline, inherited by the forked workers
@@ -249,7 +251,8 @@ def main():
         warm = {"value": B / (wms * 1e-3), "unit": "control steps/s per GPU", "ms_per_step": wms, "prepare_ms": prep_ms,
                 "kernel": "ddmpc_warm_step_kernel", "bytes_per_step": wbytes,
                 "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                             "frac": gbps / HBM_PEAK_GBPS, "traffic": None},
+                             "frac": gbps / HBM_PEAK_GBPS,
+                             "traffic": (WARM_PMC_TRAFFIC_BYTES_DEFAULT if a.batch_per_gpu == 4096 else None)},
                 "max_rel_diff_vs_cold_u": float((u_opt - u_cold).abs().max() / u_cold.abs().max()),
                 "max_rel_diff_vs_cold_cost": float(((cost - c_cold).abs() / c_cold.abs()).max())}
         u_opt.copy_(u_cold); cost.copy_(c_cold)
