@@ -385,8 +385,10 @@ def test_robust_scheme_beyond_the_register_resident_kernels(gpu, slack):
         u, cost, status, iters = eng.solve(up, yp)
         u2, cost2, status2, _ = eng.step(up, yp)                    # no affine law at this size: a step is a solve
         al = eng.get_solution("alpha"); sg = eng.get_solution("sigma"); yb = eng.get_solution("ybar")
+        u3, cost3, status3, _ = eng.solve_from_host(u_d, y_d, up, yp)    # plain upload + solve at this size
     _check(spec, u_d, y_d, up, yp, u, cost, status, range(B))
     assert np.array_equal(u, u2) and np.array_equal(cost, cost2) and np.array_equal(status, status2)
+    assert np.array_equal(u, u3) and np.array_equal(cost, cost3) and np.array_equal(status, status3)
     for b in range(B):
         ref = orc.solve_fullspace(spec, u_d[b], y_d[b], up[b], yp[b])
         if slack == 1:
