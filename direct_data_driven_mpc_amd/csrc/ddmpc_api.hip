@@ -431,10 +431,10 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
     }
     {   // r-vectors and the Cholesky panel of the global-workspace kernels live in LDS (launch_cold / launch_nominal_rescue)
       const size_t rv = ((size_t)k.r + 1) & ~(size_t)1;
-      const size_t lds = 6 * rv * sizeof(double) + 4 * rv * sizeof(int) + ((size_t)k.r * PSD_NB + PSD_NB * PSD_CH) * sizeof(double);
-      if (lds + 1024 > 160 * 1024) {
+      const size_t lds = 6 * rv * sizeof(double) + 4 * rv * sizeof(int) + (size_t)PSD_PAN * sizeof(double);
+      if (lds + 1024 > 160 * 1024 || k.r > PSD_RPT * 512) {     // the packed Cholesky keeps PSD_RPT panel rows per thread (512 threads)
         delete h;
-        return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: (m+p)(L+n) = %d rows (the global-workspace kernels hold about 840)", k.r);
+        return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: (m+p)(L+n) = %d rows (the global-workspace kernels hold %d)", k.r, PSD_RPT * 512);
       }
     }
     h->large = true;
@@ -549,10 +549,8 @@ int ddmpc_set_data(ddmpc_handle* h, const double* u_d, const double* y_d, int me
   return DDMPC_OK;
 }
 
-static unsigned large_threads() {          // workgroup size of the global-workspace kernels (development knob)
-  const char* e = getenv("DDMPC_LARGE_THREADS");
-  const int v = e ? atoi(e) : 512;
-  return (v == 256 || v == 128) ? (unsigned)v : 512u;
+static unsigned large_threads(size_t r) {   // workgroup size of the global-workspace kernels: the packed Cholesky keeps
+  return r <= 256 ? 256u : 512u;           // PSD_RPT panel rows per thread in registers (r <= PSD_RPT * threads)
 }
 
 static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
@@ -571,11 +569,11 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
     if ((rc = h->d_rr.ensure((size_t)h->batch * stride * sizeof(double)))) return rc;
     if ((rc = h->d_beta.ensure((size_t)h->batch * h->kp.rE * sizeof(double)))) return rc;
     if ((rc = h->d_act.ensure((size_t)h->batch * h->kp.rE))) return rc;
-    const size_t lds = 4 * rv * sizeof(double) + 4 * rv * sizeof(int) + (r * PSD_NB + PSD_NB * PSD_CH) * sizeof(double);
+    const size_t lds = 4 * rv * sizeof(double) + 4 * rv * sizeof(int) + (size_t)PSD_PAN * sizeof(double);
     if (lds + 1024 > 160 * 1024) return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: %zu rows", r);
     if (lds > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_large_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ddmpc_large_solve_kernel, dim3((unsigned)h->batch), dim3(large_threads()), lds, h->stream,
+    hipLaunchKernelGGL(ddmpc_large_solve_kernel, dim3((unsigned)h->batch), dim3(large_threads(r)), lds, h->stream,
                        kp_override ? *kp_override : h->kp, 16 * h->kc.NT, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                        (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, (double*)h->d_rr.p, (long long)stride);
     HIP_TRY(hipGetLastError());
@@ -629,7 +627,7 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
   const size_t ndbl = r * (r + 1) / 2 + nR * (nR + 1) / 2;
   const size_t rv = (r + 1) & ~(size_t)1;
   const size_t vec_bytes = 6 * rv * sizeof(double) + 4 * rv * sizeof(int) +     // the kernel's r-vectors, always in LDS,
-                           (r * PSD_NB + PSD_NB * PSD_CH) * sizeof(double);        // and the panel scratch of its Cholesky
+                           (size_t)PSD_PAN * sizeof(double);                        // and the scratch of its Cholesky / Gram
   size_t lds = vec_bytes + ndbl * sizeof(double);
   double* scratch = nullptr;
   if (lds + 1024 > 160 * 1024) {                              // matrices too big for LDS: per-instance slices of a global workspace
@@ -644,7 +642,7 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
   // rank tolerance 1e-8 (relative to the largest diagonal entry of the Gram): with the fixed-first ordering the
   // pivots of dependent rows come out as rounding residue up to ~3e-10, genuine ones are >= ~5e-7 on exact
   // four-tank data (L = 10 .. 60)
-  hipLaunchKernelGGL(ddmpc_nominal_rr_kernel, dim3((unsigned)h->batch), dim3(large_threads()), lds, h->stream, h->kp, 16 * h->kc.NT,
+  hipLaunchKernelGGL(ddmpc_nominal_rr_kernel, dim3((unsigned)h->batch), dim3(large_threads(r)), lds, h->stream, h->kp, 16 * h->kc.NT,
                      h->ud, h->yd, up, yp, uo, cost, (int*)status, (int*)iters, 1e-8, 1e-7, scratch, (long long)ndbl,
                      (h->stamps_on && h->d_stamps.bytes >= (size_t)h->batch * 8 * sizeof(uint64_t)) ? (unsigned long long*)h->d_stamps.p
                                                                                                       : (unsigned long long*)nullptr);

@@ -622,79 +622,114 @@ __device__ __forceinline__ int tri_row(int e) {
   return i;
 }
 
-// In-place Cholesky of a packed lower matrix with `n` rows; pivots <= tol_abs are skipped (column zeroed,
-// skip[k] = 1).  Panel-blocked, left-looking: a panel of PSD_NB columns is pulled into LDS, updated with ALL the
-// columns factored so far in one sweep (each thread streams its own rows of the factor once per panel; the PSD_NB
-// factor rows the whole workgroup needs are staged through LDS in chunks), factored there and written back --
-// the matrix, which may live in global memory, is read ~n^3/(6 PSD_NB) times instead of being read and written
-// n^3/3 times by a column-at-a-time right-looking update.  `pan` = LDS scratch of n*PSD_NB + PSD_NB*PSD_CH doubles.
-// All threads of the workgroup must call it.
+// In-place Cholesky of a packed lower matrix with `n` rows (n <= PSD_RPT * blockDim.x); pivots <= tol_abs are
+// skipped (column zeroed, skip[k] = 1).  Panel-blocked, left-looking: every thread keeps the PSD_NB panel entries of
+// its (up to PSD_RPT) rows in REGISTERS, updates them with ALL the columns factored so far in one sweep (it streams
+// its own rows of the factor once per panel; the PSD_NB factor rows the whole workgroup needs are staged through
+// LDS in chunks of PSD_CH columns), the 16x16 diagonal block is factored in LDS, and the rows below it are finished
+// by a register-local triangular solve against that block.  LDS: 10 KB, independent of n.
 constexpr int PSD_NB = 16;      // panel width
 constexpr int PSD_CH = 64;      // columns of the factor staged per chunk
+constexpr int PSD_RPT = 2;      // panel rows per thread, held in registers: n <= PSD_RPT * blockDim.x
+constexpr int PSD_PAN = 2048;   // doubles of LDS scratch: diagonal block, its reciprocal pivots, staged chunk (1296 used);
+                                // the rest widens the trajectory chunks of hankel_gram_packed
 // `ncols` < n stops after the first ncols columns (rows >= ncols of those columns hold the factor's off-diagonal
 // block, the trailing block is left untouched).
 __device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol_abs, int* skip, double* pan, int ncols = -1) {
   const int tid = threadIdx.x, nthr = blockDim.x;
-  double* Pn = pan;                           // Pn[(i - k0) * PSD_NB + c] = A(i, k0 + c)
-  double* Lp = pan + (size_t)n * PSD_NB;      // Lp[c * PSD_CH + jj]      = A(k0 + c, j0 + jj)
+  double* Dg = pan;                                    // Dg[r * PSD_NB + c]   = A(k0 + r, k0 + c), the diagonal block
+  double* Dinv = pan + PSD_NB * PSD_NB;                // reciprocal pivots of the block (0 for a skipped pivot)
+  double* Lp = Dinv + PSD_NB;                          // Lp[c * PSD_CH + jj]  = A(k0 + c, j0 + jj)
   if (ncols < 0) ncols = n;
   for (int k0 = 0; k0 < ncols; k0 += PSD_NB) {
     const int nb = (ncols - k0) < PSD_NB ? (ncols - k0) : PSD_NB;
-    // (1) + (2): panel rows, minus the contribution of the columns factored so far
-    for (int i0 = k0; i0 < n; i0 += nthr) {
-      const int i = i0 + tid;
-      double acc[PSD_NB];
+    // (1) panel rows k0 + tid + e*nthr in registers: A(i, k0..k0+nb) minus the contribution of the columns factored so far
+    double P[PSD_RPT][PSD_NB];
 #pragma unroll
-      for (int c = 0; c < PSD_NB; ++c) acc[c] = 0.0;
-      const double* Ai = A + (size_t)(i < n ? i : k0) * ((i < n ? i : k0) + 1) / 2;
-      for (int j0 = 0; j0 < k0; j0 += PSD_CH) {
-        const int nj = (k0 - j0) < PSD_CH ? (k0 - j0) : PSD_CH;
-        __syncthreads();                       // previous chunk consumed
-        for (int e = tid; e < nb * nj; e += nthr) {
-          const int c = e / nj, jj = e - c * nj;
-          Lp[c * PSD_CH + jj] = A[(size_t)(k0 + c) * (k0 + c + 1) / 2 + j0 + jj];
-        }
-        __syncthreads();
-        if (i < n) {
+    for (int e = 0; e < PSD_RPT; ++e)
+#pragma unroll
+      for (int c = 0; c < PSD_NB; ++c) P[e][c] = 0.0;
+    const double* Ar[PSD_RPT];
+#pragma unroll
+    for (int e = 0; e < PSD_RPT; ++e) {
+      const int i = k0 + tid + e * nthr;
+      Ar[e] = A + (size_t)(i < n ? i : k0) * ((i < n ? i : k0) + 1) / 2;
+    }
+    for (int j0 = 0; j0 < k0; j0 += PSD_CH) {
+      const int nj = (k0 - j0) < PSD_CH ? (k0 - j0) : PSD_CH;
+      __syncthreads();                                 // previous chunk consumed
+      for (int x = tid; x < nb * nj; x += nthr) {
+        const int c = x / nj, jj = x - c * nj;
+        Lp[c * PSD_CH + jj] = A[(size_t)(k0 + c) * (k0 + c + 1) / 2 + j0 + jj];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < PSD_RPT; ++e) {
+        if (k0 + tid + e * nthr < n) {
           for (int jj = 0; jj < nj; ++jj) {
-            const double li = Ai[j0 + jj];
+            const double li = Ar[e][j0 + jj];
 #pragma unroll
-            for (int c = 0; c < PSD_NB; ++c) acc[c] += li * Lp[c * PSD_CH + jj];
+            for (int c = 0; c < PSD_NB; ++c) P[e][c] += li * Lp[c * PSD_CH + jj];
           }
         }
       }
-      if (i < n) {
+    }
 #pragma unroll
-        for (int c = 0; c < PSD_NB; ++c)
-          Pn[(i - k0) * PSD_NB + c] = (c < nb && k0 + c <= i) ? Ai[k0 + c] - acc[c] : 0.0;
-      }
+    for (int e = 0; e < PSD_RPT; ++e) {
+      const int i = k0 + tid + e * nthr;
+#pragma unroll
+      for (int c = 0; c < PSD_NB; ++c) P[e][c] = (i < n && c < nb && k0 + c <= i) ? Ar[e][k0 + c] - P[e][c] : 0.0;
+    }
+    // (2) the diagonal block goes to LDS (its rows belong to the first nb threads) and is factored there
+    __syncthreads();
+    if (tid < nb) {
+#pragma unroll
+      for (int c = 0; c < PSD_NB; ++c) Dg[tid * PSD_NB + c] = P[0][c];
     }
     __syncthreads();
-    // (3) factor the panel in LDS, column by column
     for (int c = 0; c < nb; ++c) {
-      const int k = k0 + c;
-      const double dk = Pn[c * PSD_NB + c];
-      const bool sk = !(dk > tol_abs);          // uniform: every thread reads the same value
-      if (tid == 0) skip[k] = sk ? 1 : 0;
+      const double dk = Dg[c * PSD_NB + c];
+      const bool sk = !(dk > tol_abs);                 // uniform: every thread reads the same value
       const double inv = sk ? 0.0 : 1.0 / sqrt(dk);
-      __syncthreads();                          // everyone has read the pivot
-      for (int i = k + tid; i < n; i += nthr) Pn[(i - k0) * PSD_NB + c] *= inv;
+      __syncthreads();                                 // everyone has read the pivot
+      if (tid < nb - c) Dg[(c + tid) * PSD_NB + c] *= inv;
+      if (tid == 0) { skip[k0 + c] = sk ? 1 : 0; Dinv[c] = inv; }
       __syncthreads();
       if (!sk) {
-        for (int i = k + 1 + tid; i < n; i += nthr) {
-          double* Pi = Pn + (i - k0) * PSD_NB;
-          const double ci = Pi[c];
-          for (int c2 = c + 1; c2 < nb; ++c2)
-            if (k0 + c2 <= i) Pi[c2] -= ci * Pn[c2 * PSD_NB + c];        // A(k0+c2, k) sits in row c2 of the panel
+        const int rem = nb - c - 1;                    // rows/columns c+1 .. nb-1
+        for (int x = tid; x < rem * rem; x += nthr) {
+          const int rr = c + 1 + x / rem, c2 = c + 1 + x % rem;
+          if (c2 <= rr) Dg[rr * PSD_NB + c2] -= Dg[rr * PSD_NB + c] * Dg[c2 * PSD_NB + c];
         }
       }
       __syncthreads();
     }
-    // (4) panel -> matrix
-    for (int i = k0 + tid; i < n; i += nthr) {
-      double* Ai = A + (size_t)i * (i + 1) / 2;
-      for (int c = 0; c < nb; ++c)
-        if (k0 + c <= i) Ai[k0 + c] = Pn[(i - k0) * PSD_NB + c];
+    // (3) rows below the block: P_i <- P_i L11^-T in registers (L11 and its reciprocal pivots broadcast from LDS);
+    //     rows of the block: the factored block itself; then (4) panel -> matrix
+#pragma unroll
+    for (int e = 0; e < PSD_RPT; ++e) {
+      const int i = k0 + tid + e * nthr;
+      if (i < n) {
+        double* Ai = A + (size_t)i * (i + 1) / 2;
+        if (i < k0 + nb) {
+          for (int c = 0; c < nb; ++c)
+            if (k0 + c <= i) Ai[k0 + c] = Dg[(i - k0) * PSD_NB + c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < PSD_NB; ++c) {
+            if (c < nb) {
+              double v = P[e][c];
+#pragma unroll
+              for (int c1 = 0; c1 < PSD_NB; ++c1)
+                if (c1 < c) v -= P[e][c1] * Dg[c * PSD_NB + c1];
+              P[e][c] = v * Dinv[c];
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < PSD_NB; ++c)
+            if (c < nb) Ai[k0 + c] = P[e][c];
+        }
+      }
     }
     __syncthreads();
   }
@@ -704,7 +739,7 @@ __device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol
 // cold kernel): with components (k, a) = (time offset, channel),
 //   G((k+d, a), (k, b)) = C_d(a,b) + sum_{j<k} ( x_a[j+c+d] x_b[j+c] - x_a[j+d] x_b[j] ),   C_d(a,b) = sum_{t<c} x_a[t+d] x_b[t],
 // so only the Ln*nch^2 lag sums need the full length-c dot product (cfg 5: 19 M instead of 363 M multiply-adds).
-// `Ctab` holds the Ln*nch^2 lag sums (any scratch of that size), `pan` >= r*PSD_NB + PSD_NB*PSD_CH doubles of LDS;
+// `Ctab` holds the Ln*nch^2 lag sums (any scratch of that size), `pan` = PSD_PAN doubles of LDS;
 // `iperm` maps component rho = k*nch + ch to its row in G (nullptr: identity; written by the caller BEFORE the call).
 __device__ __forceinline__ void hankel_gram_packed(const KParams& P, const double* __restrict__ ud,
                                                    const double* __restrict__ yd, double* G, double* Ctab,
@@ -715,7 +750,7 @@ __device__ __forceinline__ void hankel_gram_packed(const KParams& P, const doubl
   auto xat = [&](int a, int t) -> double { return (a < m) ? ud[(long long)t * m + a] : yd[(long long)t * p + (a - m)]; };
   // lag sums: the trajectory is streamed through LDS in chunks of time steps (the panel scratch of the Cholesky is
   // free at this point), every thread accumulating its own (d,a,b) entries
-  const int TCH = ((r * PSD_NB + PSD_NB * PSD_CH) / nch) - P.Ln;            // time steps per chunk that fit with the lag overlap
+  const int TCH = (PSD_PAN / nch) - P.Ln;                                   // time steps per chunk that fit with the lag overlap
   double* xc = pan;                                                         // xc[(t - t0) * nch + ch], t0 <= t < t0 + TCH + Ln
   for (int e = tid; e < nlag; e += nthr) Ctab[e] = 0.0;
   for (int t0 = 0; t0 < c; t0 += TCH) {
@@ -766,7 +801,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return t;
 }
 
-__global__ __launch_bounds__(512) void ddmpc_nominal_rr_kernel(KParams P, int RPs, const double* __restrict__ u_d,
+__global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int RPs, const double* __restrict__ u_d,
                                                                const double* __restrict__ y_d,
                                                                const double* __restrict__ u_past,
                                                                const double* __restrict__ y_past,
@@ -795,7 +830,7 @@ __global__ __launch_bounds__(512) void ddmpc_nominal_rr_kernel(KParams P, int RP
   int* skipT = skip + rv;
   int* iperm = skipT + rv;                              // component -> position in the fixed-first order
   double* pan = reinterpret_cast<double*>(iperm + rv);                 // panel + chunk scratch of the Cholesky (always LDS)
-  double* rsm = scratch ? scratch + b * scratch_stride : pan + (size_t)r * PSD_NB + PSD_NB * PSD_CH;
+  double* rsm = scratch ? scratch + b * scratch_stride : pan + PSD_PAN;
   double* G = rsm;                                      // r(r+1)/2
   double* T = G + r * (r + 1) / 2;                      // nR(nR+1)/2
   __shared__ double red[16];
@@ -894,18 +929,39 @@ __global__ __launch_bounds__(512) void ddmpc_nominal_rr_kernel(KParams P, int RP
   if (dbg && tid == 0) dbg[b * 8 + 3] = __builtin_amdgcn_s_memrealtime();
   // ---- reduced normal equations T = C' W C, rhs = C' W (zs - z0), C(i,a) = L(nF+i, nF+a), i >= a ----
   const int npt = nR * (nR + 1) / 2;
-  for (int e = tid; e < npt; e += nthr) {
-    const int a = tri_row(e), bb = e - a * (a + 1) / 2;                 // a >= bb
-    double s = 0.0;
-    if (!skip[nF + a] && !skip[nF + bb]) {
-      for (int i = a; i < nR; ++i) {
-        const double* Li = G + (nF + i) * (nF + i + 1) / 2 + nF;
-        s += Li[a] * wv[i] * Li[bb];
+  {   // 4x4 register blocks of T (16 multiply-adds per 8 loads); a skipped pivot has a zero column in L, so its
+      // row/column of T comes out zero and only the diagonal is set to one (identity row, zero rhs)
+    const int nb4 = (nR + 3) >> 2, nblk = nb4 * (nb4 + 1) / 2;
+    for (int e = tid; e < nblk; e += nthr) {
+      const int ba = tri_row(e), bq = e - ba * (ba + 1) / 2;               // ba >= bq
+      const int a0 = 4 * ba, b0 = 4 * bq;
+      double acc[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[q][t] = 0.0;
+      for (int i = a0; i < nR; ++i) {
+        const double* Li = G + (size_t)(nF + i) * (nF + i + 1) / 2 + nF;     // C(i, .), valid up to column i
+        const double w = wv[i];
+        double a[4], c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          a[q] = (a0 + q <= i) ? Li[a0 + q] * w : 0.0;
+          c[q] = (b0 + q <= i) ? Li[b0 + q] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[q][t] += a[q] * c[t];
       }
-    } else if (a == bb) {
-      s = 1.0;                                                        // a skipped direction: identity row, zero rhs
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int a = a0 + q, bb = b0 + t;
+          if (a < nR && bb <= a) T[a * (a + 1) / 2 + bb] = (a == bb && skip[nF + a]) ? 1.0 : acc[q][t];
+        }
     }
-    T[e] = s;
   }
   for (int a = tid; a < nR; a += nthr) {
     double s = 0.0;
@@ -978,7 +1034,7 @@ __global__ __launch_bounds__(512) void ddmpc_nominal_rr_kernel(KParams P, int RP
 // status and iteration count as ddmpc_cold_solve_kernel (ddmpc_kernels.hpp), diagonal weights only.  One workgroup
 // per instance.  Workspace per instance: r(r+1)/2 + max(Ln*nch^2, 2*|B|(|B|+1)/2) doubles.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void ddmpc_large_solve_kernel(KParams P, int RPs, const double* __restrict__ u_d,
+__global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, int RPs, const double* __restrict__ u_d,
                                                                 const double* __restrict__ y_d,
                                                                 const double* __restrict__ u_past,
                                                                 const double* __restrict__ y_past,
@@ -1051,15 +1107,40 @@ __global__ __launch_bounds__(512) void ddmpc_large_solve_kernel(KParams P, int R
   __syncthreads();
   if (st == 0) {
     // S = K_BB - L_BA L_BA'  (the diagonal shift of B is added per active set)
-    for (int e = tid; e < npB; e += nthr) {
-      const int i = tri_row(e), j = e - i * (i + 1) / 2;
-      const double* Li = G + (size_t)(nA + i) * (nA + i + 1) / 2;
-      const double* Lj = G + (size_t)(nA + j) * (nA + j + 1) / 2;
-      double s0 = 0.0, s1 = 0.0;
-      int k = 0;
-      for (; k + 1 < nA; k += 2) { s0 += Li[k] * Lj[k]; s1 += Li[k + 1] * Lj[k + 1]; }
-      if (k < nA) s0 += Li[k] * Lj[k];
-      S[e] = Li[nA + j] - (s0 + s1);
+    {   // 4x4 register blocks: 16 multiply-adds per 8 loads
+      const int nb4 = (nB + 3) >> 2, nblk = nb4 * (nb4 + 1) / 2;
+      for (int e = tid; e < nblk; e += nthr) {
+        const int bi = tri_row(e), bj = e - bi * (bi + 1) / 2;           // bi >= bj
+        const double* Li[4];
+        const double* Lj[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ri = (4 * bi + q < nB) ? 4 * bi + q : nB - 1, rj = (4 * bj + q < nB) ? 4 * bj + q : nB - 1;
+          Li[q] = G + (size_t)(nA + ri) * (nA + ri + 1) / 2;
+          Lj[q] = G + (size_t)(nA + rj) * (nA + rj + 1) / 2;
+        }
+        double acc[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[q][t] = 0.0;
+        for (int k = 0; k < nA; ++k) {
+          double a[4], c[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { a[q] = Li[q][k]; c[q] = Lj[q][k]; }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[q][t] += a[q] * c[t];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int i = 4 * bi + q, j = 4 * bj + t;
+            if (i < nB && j <= i) S[i * (i + 1) / 2 + j] = Li[q][nA + j] - acc[q][t];
+          }
+      }
     }
     // L_AA y_A = t_A, row by row, the dot product spread over the workgroup (t_A does not depend on the active set)
     for (int k = 0; k < nA; ++k) {

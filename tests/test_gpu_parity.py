@@ -396,7 +396,7 @@ def test_robust_scheme_beyond_the_register_resident_kernels(gpu, slack):
         assert np.max(np.abs(sg[b] - ref.sigma.ravel())) <= 1e-9 * max(1.0, np.max(np.abs(ref.sigma)))
         assert np.max(np.abs(yb[b] - ref.ybar.ravel())) <= 1e-9
         assert np.max(np.abs(al[b] - ref.alpha.ravel())) <= 1e-8 * max(1e-3, np.max(np.abs(ref.alpha)))
-    if slack == 0:      # beyond what the global-workspace kernels hold (~840 rows): reported when the controller is created
+    if slack == 0:      # beyond what the global-workspace kernels hold (1024 rows): reported when the controller is created
         with pytest.raises(L.DDMPCError, match="too large"):
             _engine(orc.spec_from_params(L=300, N=1000), 1000, 1)
 
