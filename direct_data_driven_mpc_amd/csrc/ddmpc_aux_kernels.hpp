@@ -666,7 +666,18 @@ __device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol
 #pragma unroll
       for (int e = 0; e < PSD_RPT; ++e) {
         if (k0 + tid + e * nthr < n) {
-          for (int jj = 0; jj < nj; ++jj) {
+          // eight consecutive entries of the own row are loaded back to back (one or two cache lines, fetched once)
+          int jj = 0;
+          for (; jj + 8 <= nj; jj += 8) {
+            double li[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) li[q] = Ar[e][j0 + jj + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+              for (int c = 0; c < PSD_NB; ++c) P[e][c] += li[q] * Lp[c * PSD_CH + jj + q];
+          }
+          for (; jj < nj; ++jj) {
             const double li = Ar[e][j0 + jj];
 #pragma unroll
             for (int c = 0; c < PSD_NB; ++c) P[e][c] += li * Lp[c * PSD_CH + jj];
@@ -687,23 +698,30 @@ __device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol
       for (int c = 0; c < PSD_NB; ++c) Dg[tid * PSD_NB + c] = P[0][c];
     }
     __syncthreads();
-    for (int c = 0; c < nb; ++c) {
-      const double dk = Dg[c * PSD_NB + c];
-      const bool sk = !(dk > tol_abs);                 // uniform: every thread reads the same value
-      const double inv = sk ? 0.0 : 1.0 / sqrt(dk);
-      __syncthreads();                                 // everyone has read the pivot
-      if (tid < nb - c) Dg[(c + tid) * PSD_NB + c] *= inv;
-      if (tid == 0) { skip[k0 + c] = sk ? 1 : 0; Dinv[c] = inv; }
-      __syncthreads();
-      if (!sk) {
-        const int rem = nb - c - 1;                    // rows/columns c+1 .. nb-1
-        for (int x = tid; x < rem * rem; x += nthr) {
-          const int rr = c + 1 + x / rem, c2 = c + 1 + x % rem;
-          if (c2 <= rr) Dg[rr * PSD_NB + c2] -= Dg[rr * PSD_NB + c] * Dg[c2 * PSD_NB + c];
+    if (tid < 64) {
+      // one wave factors the 16x16 block: its lanes run in lockstep and a wave's LDS operations complete in program
+      // order, so the column steps need no workgroup barrier (the wave barrier only pins the compiler's ordering)
+      for (int c = 0; c < nb; ++c) {
+        const double dk = Dg[c * PSD_NB + c];
+        const bool sk = !(dk > tol_abs);               // the same value in every lane
+        const double inv = sk ? 0.0 : 1.0 / sqrt(dk);
+        __builtin_amdgcn_wave_barrier();               // every lane holds the pivot before it is overwritten
+        if (tid < nb - c) Dg[(c + tid) * PSD_NB + c] *= inv;
+        if (tid == 0) { skip[k0 + c] = sk ? 1 : 0; Dinv[c] = inv; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (!sk) {
+          const int rem = nb - c - 1;                  // rows/columns c+1 .. nb-1
+          for (int x = tid; x < rem * rem; x += 64) {
+            const int rr = c + 1 + x / rem, c2 = c + 1 + x % rem;
+            if (c2 <= rr) Dg[rr * PSD_NB + c2] -= Dg[rr * PSD_NB + c] * Dg[c2 * PSD_NB + c];
+          }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
-      __syncthreads();
     }
+    __syncthreads();
     // (3) rows below the block: P_i <- P_i L11^-T in registers (L11 and its reciprocal pivots broadcast from LDS);
     //     rows of the block: the factored block itself; then (4) panel -> matrix
 #pragma unroll
@@ -731,6 +749,20 @@ __device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol
         }
       }
     }
+    __syncthreads();
+  }
+}
+
+// Back substitution L' x = y for a packed lower factor, row-oriented: once x[a] is known, row a of L (contiguous)
+// times x[a] is subtracted from the remaining right-hand side -- coalesced loads, no reduction, one barrier per row.
+// y is consumed (overwritten), x must not alias it; `skip` (optional) marks rows whose unknown is zero.
+__device__ __forceinline__ void packed_back_substitute(const double* Lm, int n, double* y, double* x, const int* skip) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int a = n - 1; a >= 0; --a) {
+    const double* La = Lm + (size_t)a * (a + 1) / 2;
+    const double xa = (skip && skip[a]) ? 0.0 : y[a] / La[a];      // every thread forms the same value
+    if (tid == 0) x[a] = xa;
+    for (int j = tid; j < a; j += nthr) y[j] -= La[j] * xa;
     __syncthreads();
   }
 }
@@ -922,7 +954,15 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   for (int i = tid; i < nR; i += nthr) {
     const double* Li = G + (nF + i) * (nF + i + 1) / 2;
     double s = 0.0;
-    for (int k = 0; k < nF; ++k) s += Li[k] * col[k];
+    int k = 0;
+    for (; k + 8 <= nF; k += 8) {
+      double l[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) l[q] = Li[k + q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += l[q] * col[k + q];
+    }
+    for (; k < nF; ++k) s += Li[k] * col[k];
     z0[i] = s;
   }
   __syncthreads();
@@ -984,13 +1024,9 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
     if (tid == 0) vv[a] = skipT[a] ? 0.0 : s / Ta[a];
     __syncthreads();
   }
-  for (int a = nR - 1; a >= 0; --a) {
-    double part = 0.0;
-    for (int i = a + 1 + tid; i < nR; i += nthr) part += T[i * (i + 1) / 2 + a] * vv[i];
-    const double s = vv[a] - block_sum(part, red);
-    if (tid == 0) vv[a] = skipT[a] ? 0.0 : s / T[a * (a + 1) / 2 + a];
-    __syncthreads();
-  }
+  packed_back_substitute(T, nR, vv, col, skipT);          // col (free since z0) takes the solution
+  for (int a = tid; a < nR; a += nthr) vv[a] = col[a];
+  __syncthreads();
   if (dbg && tid == 0) dbg[b * 8 + 6] = __builtin_amdgcn_s_memrealtime();
   // ---- z_R = z0 + C v; outputs -------------------------------------------------------------------
   double part = 0.0;
@@ -1124,7 +1160,21 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int t = 0; t < 4; ++t) acc[q][t] = 0.0;
-        for (int k = 0; k < nA; ++k) {
+        int k = 0;
+        for (; k + 4 <= nA; k += 4) {                    // four consecutive entries of each row loaded back to back
+          double a[4][4], c[4][4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[q][u] = Li[q][k + u]; c[q][u] = Lj[q][k + u]; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) acc[q][t] += a[q][u] * c[t][u];
+        }
+        for (; k < nA; ++k) {
           double a[4], c[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) { a[q] = Li[q][k]; c[q] = Lj[q][k]; }
@@ -1154,7 +1204,15 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
     for (int i = tid; i < nB; i += nthr) {               // zb = L_BA y_A
       const double* Li = G + (size_t)(nA + i) * (nA + i + 1) / 2;
       double s = 0.0;
-      for (int k = 0; k < nA; ++k) s += Li[k] * yv[k];
+      int k = 0;
+      for (; k + 8 <= nA; k += 8) {
+        double l[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) l[q] = Li[k + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += l[q] * yv[k + q];
+      }
+      for (; k < nA; ++k) s += Li[k] * yv[k];
       zb[i] = s;
     }
     __syncthreads();
@@ -1183,13 +1241,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
         if (tid == 0) yv[nA + k] = s / Tk[k];
         __syncthreads();
       }
-      for (int a = nB - 1; a >= 0; --a) {                // L_BB' beta_B = y_B
-        double part = 0.0;
-        for (int i = a + 1 + tid; i < nB; i += nthr) part += T[(size_t)i * (i + 1) / 2 + a] * bv[nA + i];
-        const double s = yv[nA + a] - block_sum(part, red);
-        if (tid == 0) bv[nA + a] = s / T[(size_t)a * (a + 1) / 2 + a];
-        __syncthreads();
-      }
+      packed_back_substitute(T, nB, yv + nA, bv + nA, nullptr);   // L_BB' beta_B = y_B
       // slack box: primal-dual active-set update (sigma[n*p:], controller.py:659); B holds exactly those components
       if (tid == 0) flag[0] = 0;
       __syncthreads();
@@ -1207,13 +1259,15 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
     }
   }
   if (st == 0) {
-    for (int a = nA - 1; a >= 0; --a) {                  // L_AA' beta_A = y_A - L_BA' beta_B
-      double part = 0.0;
-      for (int i = a + 1 + tid; i < r; i += nthr) part += G[(size_t)i * (i + 1) / 2 + a] * bv[i];
-      const double s = yv[a] - block_sum(part, red);
-      if (tid == 0) bv[a] = s / G[(size_t)a * (a + 1) / 2 + a];
-      __syncthreads();
+    // L_AA' beta_A = y_A - L_BA' beta_B: the B rows first (column j of L_BA read by thread j: coalesced), then the
+    // row-oriented back substitution through L_AA
+    for (int j = tid; j < nA; j += nthr) {
+      double w = yv[j];
+      for (int i = nA; i < r; ++i) w -= G[(size_t)i * (i + 1) / 2 + j] * bv[i];
+      yv[j] = w;
     }
+    __syncthreads();
+    packed_back_substitute(G, nA, yv, bv, nullptr);
   }
   // ---- outputs: z = t - lam*D*beta; cost = control cost + lam*beta'z + lamb_sigma*|sigma|^2 --------------------
   double part = 0.0, bad = 0.0;
