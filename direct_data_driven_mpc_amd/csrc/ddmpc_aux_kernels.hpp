@@ -780,7 +780,7 @@ __device__ __forceinline__ void hankel_gram_packed(const KParams& P, const doubl
   const int r = P.r, m = P.m, p = P.p, nch = P.nch, c = P.c;
   const int nlag = P.Ln * nch * nch;
   auto xat = [&](int a, int t) -> double { return (a < m) ? ud[(long long)t * m + a] : yd[(long long)t * p + (a - m)]; };
-  // lag sums: the trajectory is streamed through LDS in chunks of time steps (the panel scratch of the Cholesky is
+  // lag sums: the trajectory is streamed through LDS in chunks of time steps (the LDS scratch of the Cholesky is
   // free at this point), every thread accumulating its own (d,a,b) entries
   const int TCH = (PSD_PAN / nch) - P.Ln;                                   // time steps per chunk that fit with the lag overlap
   double* xc = pan;                                                         // xc[(t - t0) * nch + ch], t0 <= t < t0 + TCH + Ln
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   int* skip = perm + rv;
   int* skipT = skip + rv;
   int* iperm = skipT + rv;                              // component -> position in the fixed-first order
-  double* pan = reinterpret_cast<double*>(iperm + rv);                 // panel + chunk scratch of the Cholesky (always LDS)
+  double* pan = reinterpret_cast<double*>(iperm + rv);                 // PSD_PAN doubles: scratch of the Cholesky / Gram (always LDS)
   double* rsm = scratch ? scratch + b * scratch_stride : pan + PSD_PAN;
   double* G = rsm;                                      // r(r+1)/2
   double* T = G + r * (r + 1) / 2;                      // nR(nR+1)/2
@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
 // Problems with more rows than the register-resident cold kernels hold ((m+p)(L+n) > 271): the same reduced system
 //   (G + lam*D) beta = t,  z = t - lam*D*beta,  primal-dual active set on the slack box (CONVEX)
 // with the matrices in a per-instance slice of a global workspace (packed lower triangles), plain VALU code:
-// Hankel-structured Gram, panel-blocked Cholesky (panel in LDS), row-wise substitutions.  The components the slack
+// Hankel-structured Gram, panel-blocked Cholesky (panel rows in registers), row-wise substitutions.  The components the slack
 // box acts on (set B, the sigma rows of the prediction window) are ordered LAST: the factor of the other columns
 // (set A) and the Schur complement S = K_BB - L_BA L_BA' are formed once, and an active-set iteration only
 // re-factors S + lam*D_B(active set) (|B| = p*L rows) and substitutes through it.  Same component tables, outputs,
