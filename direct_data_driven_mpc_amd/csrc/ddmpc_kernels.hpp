@@ -102,6 +102,22 @@ struct TileMap {
   static constexpr int slot(int I, int J) { return tab.base[I - J] + J; }
 };
 
+// The lower tiles one wave owns, in column-major (J, then I) order: lets the per-step loops instantiate one body per
+// owned tile instead of one per (I, J) pair of the whole matrix (compile time of the large instances).
+template <int NT, int W, int WAVE>
+struct WaveTiles {
+  struct Tab { int I[NT * (NT + 1) / 2]; int J[NT * (NT + 1) / 2]; int n; };
+  static constexpr Tab make() {
+    Tab t{};
+    t.n = 0;
+    for (int J = 0; J < NT; ++J)
+      for (int I = J; I < NT; ++I)
+        if (TileMap<NT, W>::wave(I, J) == WAVE) { t.I[t.n] = I; t.J[t.n] = J; ++t.n; }
+    return t;
+  }
+  static constexpr Tab tab = make();
+};
+
 // By-value selects: keep ternaries over captured variables from turning into
 // pointer selects (which would pin the accumulators in scratch memory).
 __device__ __forceinline__ double sel4(int k, double a, double b, double c, double d) {
@@ -159,6 +175,7 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
                                           double* __restrict__ beta_ws, signed char* __restrict__ act_ws,
                                           unsigned long long* __restrict__ stamps, double* __restrict__ lfac) {
   using TM = TileMap<NT, W>;
+  using WT = WaveTiles<NT, W, WAVE>;
   using LD = Lds<NT>;
   constexpr int RP = 16 * NT;
   constexpr int NTHR = 64 * W;
@@ -246,26 +263,20 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
         double op[NT];
         static_for<NT>([&](auto I) __attribute__((always_inline)) { op[I] = xp[16 * I]; });
         xp += 4 * nch;
-        static_for<NT>([&](auto J) __attribute__((always_inline)) {
-          static_for<NT>([&](auto I) __attribute__((always_inline)) {
-            if constexpr (I >= J && TM::wave(I, J) == WAVE) {
-              acc[TM::slot(I, J)] =
-                  __builtin_amdgcn_mfma_f64_16x16x4f64(op[I], op[J], acc[TM::slot(I, J)], 0, 0, 0);
-            }
-          });
+        static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
+          constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
+          acc[TM::slot(I, J)] =
+              __builtin_amdgcn_mfma_f64_16x16x4f64(op[I], op[J], acc[TM::slot(I, J)], 0, 0, 0);
         });
       }
       if (cfull < c) {
         const bool kok = (cfull + l4) < c;
         double op[NT];
         static_for<NT>([&](auto I) __attribute__((always_inline)) { const double v = xp[16 * I]; op[I] = kok ? v : 0.0; });
-        static_for<NT>([&](auto J) __attribute__((always_inline)) {
-          static_for<NT>([&](auto I) __attribute__((always_inline)) {
-            if constexpr (I >= J && TM::wave(I, J) == WAVE) {
-              acc[TM::slot(I, J)] =
-                  __builtin_amdgcn_mfma_f64_16x16x4f64(op[I], op[J], acc[TM::slot(I, J)], 0, 0, 0);
-            }
-          });
+        static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
+          constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
+          acc[TM::slot(I, J)] =
+              __builtin_amdgcn_mfma_f64_16x16x4f64(op[I], op[J], acc[TM::slot(I, J)], 0, 0, 0);
         });
       }
       stamp();   // 2
@@ -398,45 +409,39 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
     // ---- accumulators := -(G + lam*D); identity on dummy rows; rhs row := -t -----------
     // The factorisation keeps the NEGATED matrix in the accumulators so that the rank-4
     // trailing updates are plain  acc += L_I L_J'  (MFMA has no operand-negate modifier).
-    static_for<NT>([&](auto J) __attribute__((always_inline)) {
-      static_for<NT>([&](auto I) __attribute__((always_inline)) {
-        if constexpr (I >= J && TM::wave(I, J) == WAVE) {
-          constexpr int S = TM::slot(I, J);
-          const int col = 16 * J + l15;
-          d4 v = -acc[S];
-          if constexpr (I == J) {
-            static_for<4>([&](auto j) __attribute__((always_inline)) {
-              const int row = 16 * I + l4 + 4 * j;
-              if (row == col && row < r) v[j()] -= P.lam * dvec[row];
-              if (row < col) v[j()] = 0.0;
-            });
-          }
-          if (16 * I + 15 >= r) {                 // wave-uniform: tile rows that touch the padding / rhs row
-            static_for<4>([&](auto j) __attribute__((always_inline)) {
-              const int row = 16 * I + l4 + 4 * j;
-              if (row >= r || col >= r) v[j()] = 0.0;
-              if (I == J && row == col && row >= r && row < rE) v[j()] = -1.0;
-              if (row == rE && col < r) v[j()] = -tvec[col];
-            });
-          }
-          acc[S] = v;
-        }
-      });
+    static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
+      constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
+      constexpr int S = TM::slot(I, J);
+      const int col = 16 * J + l15;
+      d4 v = -acc[S];
+      if constexpr (I == J) {
+        static_for<4>([&](auto j) __attribute__((always_inline)) {
+          const int row = 16 * I + l4 + 4 * j;
+          if (row == col && row < r) v[j()] -= P.lam * dvec[row];
+          if (row < col) v[j()] = 0.0;
+        });
+      }
+      if (16 * I + 15 >= r) {                 // wave-uniform: tile rows that touch the padding / rhs row
+        static_for<4>([&](auto j) __attribute__((always_inline)) {
+          const int row = 16 * I + l4 + 4 * j;
+          if (row >= r || col >= r) v[j()] = 0.0;
+          if (I == J && row == col && row >= r && row < rE) v[j()] = -1.0;
+          if (row == rE && col < r) v[j()] = -tvec[col];
+        });
+      }
+      acc[S] = v;
     });
 
     // ---- dense weighting matrices (controller.py:708-710 with non-diagonal Q, R): the penalty
     //      term lam * W^-1 is a full matrix, identical for the whole batch, read from L2
     if (P.dense_w) {
-      static_for<NT>([&](auto J) __attribute__((always_inline)) {
-        static_for<NT>([&](auto I) __attribute__((always_inline)) {
-          if constexpr (I >= J && TM::wave(I, J) == WAVE) {
-            constexpr int S = TM::slot(I, J);
-            const double* dm = P.dmat + (long long)(16 * I + l4) * RP + 16 * J + l15;
-            static_for<4>([&](auto j) __attribute__((always_inline)) {
-              const double dv = dm[4 * j() * RP];
-              if (I != J || l4 + 4 * j() >= l15) acc[S][j()] -= P.lam * dv;
-            });
-          }
+      static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
+        constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
+        constexpr int S = TM::slot(I, J);
+        const double* dm = P.dmat + (long long)(16 * I + l4) * RP + 16 * J + l15;
+        static_for<4>([&](auto j) __attribute__((always_inline)) {
+          const double dv = dm[4 * j() * RP];
+          if (I != J || l4 + 4 * j() >= l15) acc[S][j()] -= P.lam * dv;
         });
       });
     }
@@ -592,17 +597,16 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
           }
           __builtin_amdgcn_sched_barrier(0);
           // (3b) the rest of the trailing update
-          static_for<NT>([&](auto J) __attribute__((always_inline)) {
-            static_for<NT>([&](auto I) __attribute__((always_inline)) {
-              if constexpr (J > Jb && I >= J && TM::wave(I, J) == WAVE) {
-                constexpr int S = TM::slot(I, J);
-                if constexpr (J == Jb + 1) {
-                  if (q < 3) acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[I], op[J], acc[S], 0, 0, 0);
-                } else {
-                  acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[I], op[J], acc[S], 0, 0, 0);
-                }
+          static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
+            constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
+            if constexpr (J > Jb) {
+              constexpr int S = TM::slot(I, J);
+              if constexpr (J == Jb + 1) {
+                if (q < 3) acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[I], op[J], acc[S], 0, 0, 0);
+              } else {
+                acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[I], op[J], acc[S], 0, 0, 0);
               }
-            });
+            }
           });
           // (3c) keep the final L in the panel columns of this tile column
           if (lo == q) {
@@ -627,29 +631,23 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
     // ---- optional export of the factor (ddmpc_prepare): lower tiles, row-major 16x16 each,
     //      tile (I,J) at lfac[(I(I+1)/2 + J) * 256]; register j of lane l is row l4+4j, col l15
     if (lfac != nullptr) {
-      static_for<NT>([&](auto J) __attribute__((always_inline)) {
-        static_for<NT>([&](auto I) __attribute__((always_inline)) {
-          if constexpr (I >= J && TM::wave(I, J) == WAVE) {
-            constexpr int S = TM::slot(I, J);
-            double* dst = lfac + (I * (I + 1) / 2 + J) * 256 + lane;
-            static_for<4>([&](auto j) __attribute__((always_inline)) { dst[64 * j] = acc[S][j()]; });
-          }
-        });
+      static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
+        constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
+        constexpr int S = TM::slot(I, J);
+        double* dst = lfac + (I * (I + 1) / 2 + J) * 256 + lane;
+        static_for<4>([&](auto j) __attribute__((always_inline)) { dst[64 * j] = acc[S][j()]; });
       });
     }
 
     // ---- y = L^-1 t sits in row rE of the tiles -> tvec[] -----------------------------
-    static_for<NT>([&](auto J) __attribute__((always_inline)) {
-      static_for<NT>([&](auto I) __attribute__((always_inline)) {
-        if constexpr (I >= J && TM::wave(I, J) == WAVE) {
-          if (I == IR) {
-            constexpr int S = TM::slot(I, J);
-            static_for<4>([&](auto j) __attribute__((always_inline)) {
-              if (l4 + 4 * j == rr) tvec[16 * J + l15] = acc[S][j()];
-            });
-          }
-        }
-      });
+    static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
+      constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
+      if (I == IR) {
+        constexpr int S = TM::slot(I, J);
+        static_for<4>([&](auto j) __attribute__((always_inline)) {
+          if (l4 + 4 * j == rr) tvec[16 * J + l15] = acc[S][j()];
+        });
+      }
     });
     __syncthreads();
     // ---- back substitution L' beta = y, one 16-row tile row per round --------------------
