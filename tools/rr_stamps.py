@@ -1,3 +1,6 @@
+"""Dev tool: per-phase breakdown of ddmpc_nominal_rr_kernel at the cfg-5 size (in-kernel s_memrealtime stamps, median over
+the 512 instances of the batch; the phases' proportions are what matters, the clock's unit is nominal).  Reuses the
+problem set-up of tools/config5_check.py."""
 import sys; sys.path.insert(0,".")
 exec(open("tools/config5_check.py").read().split("eng.set_data")[0])
 eng.set_data(d["u_d"], d["y_d"])

@@ -1,3 +1,4 @@
+"""Dev timing: ddmpc_closed_loop for 1 / 512 / 4096 controllers (1-step and 4-step schemes), host arrays in and out."""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
