@@ -301,7 +301,8 @@ __device__ __forceinline__ void wave_body(const KParams& P, double* __restrict__
         constexpr int MAXG = (NT + W - 1) / W;             // lag groups per wave
         const int ngroups = (Ln + 3) >> 2;
         const int kq = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
-        if (WAVE * MAXG < ngroups) {
+        // The table only depends on the trajectory: later active-set iterations reuse it (ctab has its own LDS region).
+        if (iter == 1 && WAVE * MAXG < ngroups) {
           double cacc[MAXG];
           static_for<MAXG>([&](auto gi) __attribute__((always_inline)) { cacc[gi()] = 0.0; });
           const double* pB = xs + 4 * kq + ij;                                   // B[k][j] = x_j[t0 + k]
