@@ -149,6 +149,7 @@ struct ddmpc_handle {
   bool large_nominal = false;              // ... NOMINAL: every solve is the rank-revealing kernel; else ddmpc_large_solve_kernel
   int n_free = 0;                          // weighted (free) components, nominal scheme: rows of the reduced normal matrix
   bool stamps_on = false;
+  bool beta_stale = false;                 // the last solve was a warm step that skipped the beta / active-set workspace
   const double* last_up = nullptr;
   const double* last_yp = nullptr;
 };
@@ -557,6 +558,7 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
                        int32_t* status, int32_t* iters, double* lfac = nullptr, const int* only = nullptr,
                        const KParams* kp_override = nullptr) {
   int rc;
+  h->beta_stale = false;
   if (h->large_nominal) {          // no cold kernel at this size: every instance goes to the rank-revealing kernel
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)status, 4, (size_t)h->batch, h->stream));
     return DDMPC_OK;
@@ -609,10 +611,15 @@ static int launch_warm(ddmpc_handle* h, const double* up, const double* yp, doub
     if ((rc = h->d_need.ensure((size_t)h->batch * sizeof(int)))) return rc;
     need = (int*)h->d_need.p;
   }
+  // beta / active set are only needed by ddmpc_get_solution (and by the filtered cold launch below): without the slack
+  // box the step skips that 1.2 KB of writes per instance and ddmpc_get_solution re-evaluates the law on demand
+  const bool keep = h->kp.convex != 0;
   hipLaunchKernelGGL(ddmpc_warm_step_kernel, dim3((unsigned)h->batch), dim3(threads), 0, h->stream, h->kp,
                      16 * h->kc.NT, nf, (const double*)h->d_gain.p, (const int*)h->d_prep_status.p, up, yp, uo, cost,
-                     (int*)status, (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, need);
+                     (int*)status, (int*)iters, keep ? (double*)h->d_beta.p : (double*)nullptr,
+                     keep ? (signed char*)h->d_act.p : (signed char*)nullptr, need);
   HIP_TRY(hipGetLastError());
+  h->beta_stale = !keep;
   if (need)       // instances with an active slack bound: full active-set solve, same launch geometry, others exit at once
     return launch_cold(h, up, yp, uo, cost, status, iters, nullptr, need);
   return DDMPC_OK;
@@ -893,6 +900,21 @@ int ddmpc_get_solution(ddmpc_handle* h, int what, double* out, int mem) {
   if (h->large_nominal) return fail(DDMPC_ERR_UNSUPPORTED, "variables are not reconstructed at this problem size");
   HIP_TRY(hipSetDevice(h->device));
   const KParams& k = h->kp;
+  if (h->beta_stale) {             // last solve = warm step without the workspace: evaluate the affine law once more, keeping beta
+    const size_t B = (size_t)h->batch;
+    int rc;
+    if ((rc = h->d_uopt.ensure(B * h->prm.L * k.m * sizeof(double))) || (rc = h->d_cost.ensure(B * sizeof(double))) ||
+        (rc = h->d_status.ensure(B * sizeof(int32_t))) || (rc = h->d_iters.ensure(B * sizeof(int32_t))) ||
+        (rc = h->d_beta.ensure(B * k.rE * sizeof(double))) || (rc = h->d_act.ensure(B * k.rE)))
+      return rc;
+    const unsigned threads = (unsigned)(((k.r + 63) / 64) * 64 > 1024 ? 1024 : ((k.r + 63) / 64) * 64);
+    hipLaunchKernelGGL(ddmpc_warm_step_kernel, dim3((unsigned)h->batch), dim3(threads), 0, h->stream, k, 16 * h->kc.NT,
+                       h->prm.n * k.nch, (const double*)h->d_gain.p, (const int*)h->d_prep_status.p, h->last_up, h->last_yp,
+                       (double*)h->d_uopt.p, (double*)h->d_cost.p, (int*)h->d_status.p, (int*)h->d_iters.p,
+                       (double*)h->d_beta.p, (signed char*)h->d_act.p, (int*)nullptr);
+    HIP_TRY(hipGetLastError());
+    h->beta_stale = false;
+  }
   size_t per = 0;
   switch (what) {
     case DDMPC_SOL_ALPHA: per = k.c; break;
