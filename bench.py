@@ -30,7 +30,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 2.4 GHz x 2048 flop / 64 clk 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 PMC_TRAFFIC_BYTES_DEFAULT = (2 * 28911 + 13050) * 1024
 # the same for ddmpc_warm_step_kernel at 4096 instances (profiles/r01_warm_step_pmc_*.csv)
-WARM_PMC_TRAFFIC_BYTES_DEFAULT = (2 * 37824 + 7296) * 1024
+WARM_PMC_TRAFFIC_BYTES_DEFAULT = (2 * 37824 + 2304) * 1024
 
 
 _ORACLE = {}      # inputs of the CPU baseline, inherited by the forked workers
