@@ -1221,3 +1221,43 @@ def test_config5_size_nominal_runs_on_the_rank_revealing_kernel(gpu):
     with pytest.raises(L.DDMPCError, match="too large"):
         BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=3.0 * np.eye(p * Lh) + 0.01, R=1e-4 * np.eye(m * Lh), u_s=u_s, y_s=y_s,
                      batch=1, controller_type=L.ROBUST, eps_max=0.002, lamb_alpha=50.0, lamb_sigma=1000.0, c=1.0)
+
+
+def test_plain_c_caller_of_the_abi(gpu, tmp_path):
+    # the boundary used from C, not Python: tests/c/capi_caller.c is compiled with gcc against include/ddmpc.h and
+    # linked to libddmpc.so; its results must equal the Python layer's bit for bit (same library, same inputs)
+    import os, shutil, struct, subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "direct_data_driven_mpc_amd")
+    exe = str(tmp_path / "capi_caller")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c", "capi_caller.c"), "-o", exe, "-L", libdir, "-lddmpc",
+                    "-Wl,-rpath," + libdir], check=True)
+    for slack in (L.SLACK_NONE, L.SLACK_CONVEX):
+        spec = orc.spec_from_params(slack_var_constraint_type=1 if slack == L.SLACK_CONVEX else 0)
+        B = 5
+        u_d, y_d, up, yp = _instances(B, seed0=40)
+        fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("7i", B, 400, 2, 2, 4, 30, slack))
+            for a in (u_d, y_d, up, yp):
+                f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+        res = subprocess.run([exe, fin, fout], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+        raw = open(fout, "rb").read()
+        nu, ns = B * 60, B * 34 * 2
+        d = np.frombuffer(raw[: 8 * (2 * nu + 2 * B + ns)], dtype=np.float64)
+        i = np.frombuffer(raw[8 * (2 * nu + 2 * B + ns):], dtype=np.int32)
+        u_c, cost_c, u_s, cost_s, sig_c = d[:nu].reshape(B, 60), d[nu:nu + B], d[nu + B:2 * nu + B].reshape(B, 60), \
+            d[2 * nu + B:2 * nu + 2 * B], d[2 * nu + 2 * B:].reshape(B, 68)
+        with _engine(spec, 400, B) as eng:
+            eng.set_data(u_d, y_d)
+            u, cost, status, iters = eng.solve(up, yp)
+            sig = eng.get_solution("sigma")
+            us, cs, _, _ = eng.step(up, yp)
+        assert np.array_equal(u_c, u) and np.array_equal(cost_c, cost) and np.array_equal(sig_c, sig)
+        assert np.array_equal(u_s, us) and np.array_equal(cost_s, cs)
+        assert np.array_equal(i[:B], status) and np.array_equal(i[B:], iters) and np.all(status == 0)
+        _check(spec, u_d, y_d, up, yp, u_c, cost_c, i[:B], range(B))
