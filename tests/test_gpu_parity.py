@@ -1261,3 +1261,37 @@ def test_plain_c_caller_of_the_abi(gpu, tmp_path):
         assert np.array_equal(u_s, us) and np.array_equal(cost_s, cs)
         assert np.array_equal(i[:B], status) and np.array_equal(i[B:], iters) and np.all(status == 0)
         _check(spec, u_d, y_d, up, yp, u_c, cost_c, i[:B], range(B))
+
+
+def test_two_handles_from_two_threads(gpu):
+    # handles are independent (own stream, own buffers; the error string is thread-local): two host threads driving
+    # two controller batches at once must get what they get one after the other
+    import threading
+    spec = orc.spec_from_params()
+    B = 64
+    sets = [_instances(B, seed0=s) for s in (100, 300)]
+    serial = []
+    for u_d, y_d, up, yp in sets:
+        with _engine(spec, 400, B) as eng:
+            eng.set_data(u_d, y_d)
+            serial.append([x.copy() for x in eng.solve(up, yp)])
+    out = [None, None]
+
+    def work(k):
+        u_d, y_d, up, yp = sets[k]
+        with _engine(spec, 400, B) as eng:
+            eng.set_data(u_d, y_d)
+            for _ in range(20):
+                r = eng.solve(up, yp)
+            s = eng.step(up, yp)
+            out[k] = ([x.copy() for x in r], [x.copy() for x in s])
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        cold, warm = out[k]
+        assert all(np.array_equal(a, b) for a, b in zip(cold, serial[k]))
+        assert np.max(np.abs(warm[0] - serial[k][0])) <= 1e-10 * np.max(np.abs(serial[k][0])) and np.all(warm[2] == 0)
