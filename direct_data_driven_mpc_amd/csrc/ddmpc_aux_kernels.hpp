@@ -777,7 +777,7 @@ __device__ __forceinline__ void hankel_gram_packed(const KParams& P, const doubl
                                                    const double* __restrict__ yd, double* G, double* Ctab,
                                                    const int* iperm, double* pan) {
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int r = P.r, m = P.m, p = P.p, nch = P.nch, c = P.c;
+  const int m = P.m, p = P.p, nch = P.nch, c = P.c;
   const int nlag = P.Ln * nch * nch;
   auto xat = [&](int a, int t) -> double { return (a < m) ? ud[(long long)t * m + a] : yd[(long long)t * p + (a - m)]; };
   // lag sums: the trajectory is streamed through LDS in chunks of time steps (the LDS scratch of the Cholesky is
@@ -968,7 +968,6 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   __syncthreads();
   if (dbg && tid == 0) dbg[b * 8 + 3] = __builtin_amdgcn_s_memrealtime();
   // ---- reduced normal equations T = C' W C, rhs = C' W (zs - z0), C(i,a) = L(nF+i, nF+a), i >= a ----
-  const int npt = nR * (nR + 1) / 2;
   {   // 4x4 register blocks of T (16 multiply-adds per 8 loads); a skipped pivot has a zero column in L, so its
       // row/column of T comes out zero and only the diagonal is set to one (identity row, zero rhs)
     const int nb4 = (nR + 3) >> 2, nblk = nb4 * (nb4 + 1) / 2;
