@@ -140,7 +140,7 @@ struct ddmpc_handle {
   // warm path: per-instance affine law (ddmpc_prepare)
   DevBuf d_lfac, d_lfacT, d_gain, d_prep_status, d_zero, d_need;
   // host-pointer solves: one packed device buffer and its pinned host mirror (two copies per solve instead of six)
-  DevBuf d_io, d_rr;
+  DevBuf d_io, d_rr, d_alpha;
   HostBuf h_io;
   bool prepared = false;
   int closed_loop_path = DDMPC_PATH_AUTO;
@@ -432,7 +432,7 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
     }
     {   // r-vectors and the Cholesky panel of the global-workspace kernels live in LDS (launch_cold / launch_nominal_rescue)
       const size_t rv = ((size_t)k.r + 1) & ~(size_t)1;
-      const size_t lds = 6 * rv * sizeof(double) + 4 * rv * sizeof(int) + (size_t)PSD_PAN * sizeof(double);
+      const size_t lds = 10 * rv * sizeof(double) + 4 * rv * sizeof(int) + (size_t)PSD_PAN * sizeof(double);
       if (lds + 1024 > 160 * 1024 || k.r > PSD_RPT * 512) {     // the packed Cholesky keeps PSD_RPT panel rows per thread (512 threads)
         delete h;
         return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: (m+p)(L+n) = %d rows (the global-workspace kernels hold %d)", k.r, PSD_RPT * 512);
@@ -498,7 +498,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -633,7 +633,7 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
   const size_t r = (size_t)h->kp.r, nR = (size_t)h->n_free;
   const size_t ndbl = r * (r + 1) / 2 + nR * (nR + 1) / 2;
   const size_t rv = (r + 1) & ~(size_t)1;
-  const size_t vec_bytes = 6 * rv * sizeof(double) + 4 * rv * sizeof(int) +     // the kernel's r-vectors, always in LDS,
+  const size_t vec_bytes = 10 * rv * sizeof(double) + 4 * rv * sizeof(int) +    // the kernel's r-vectors, always in LDS,
                            (size_t)PSD_PAN * sizeof(double);                        // and the scratch of its Cholesky / Gram
   size_t lds = vec_bytes + ndbl * sizeof(double);
   double* scratch = nullptr;
@@ -644,6 +644,10 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
     lds = vec_bytes;
   }
   if (lds + 1024 > 160 * 1024) return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: %zu rows", r);
+  {   // c-vector per instance for the products with the implicit Hankel matrix (refinement step)
+    int rca = h->d_alpha.ensure((size_t)h->batch * (size_t)h->kp.c * sizeof(double));
+    if (rca) return rca;
+  }
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_nominal_rr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // rank tolerance 1e-8 (relative to the largest diagonal entry of the Gram): with the fixed-first ordering the
@@ -651,6 +655,7 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
   // four-tank data (L = 10 .. 60)
   hipLaunchKernelGGL(ddmpc_nominal_rr_kernel, dim3((unsigned)h->batch), dim3(large_threads(r)), lds, h->stream, h->kp, 16 * h->kc.NT,
                      h->ud, h->yd, up, yp, uo, cost, (int*)status, (int*)iters, 1e-8, 1e-7, scratch, (long long)ndbl,
+                     (double*)h->d_alpha.p,
                      (h->stamps_on && h->d_stamps.bytes >= (size_t)h->batch * 8 * sizeof(uint64_t)) ? (unsigned long long*)h->d_stamps.p
                                                                                                       : (unsigned long long*)nullptr);
   HIP_TRY(hipGetLastError());

@@ -767,6 +767,55 @@ __device__ __forceinline__ void packed_back_substitute(const double* Lm, int n, 
   }
 }
 
+__device__ __forceinline__ double block_sum(double v, double* red);       // defined below
+
+// L y = rhs over the rows that are not skipped (y = 0 on skipped ones) for a packed lower factor, row by row with the
+// dot products spread over the workgroup.  y must not alias rhs.
+__device__ __forceinline__ void packed_forward_substitute(const double* Lm, int n, const double* rhs, double* y,
+                                                          const int* skip, double* red) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int k = 0; k < n; ++k) {
+    const double* Lk = Lm + (size_t)k * (k + 1) / 2;
+    double part = 0.0;
+    for (int j = tid; j < k; j += nthr) part += Lk[j] * y[j];
+    const double s = rhs[k] - block_sum(part, red);
+    if (tid == 0) y[k] = (skip && skip[k]) ? 0.0 : s / Lk[k];
+    __syncthreads();
+  }
+}
+
+// Products with the implicit block-Hankel matrix H (rows rho = k*nch + ch, columns i < c): alpha = H' x and z = H alpha.
+// x and z are r-vectors in COMPONENT order (LDS), alpha is a c-vector in global memory.
+__device__ __forceinline__ void hankel_transpose_times(const KParams& P, const double* __restrict__ ud,
+                                                       const double* __restrict__ yd, const double* x, double* alpha) {
+  const int m = P.m, p = P.p, nch = P.nch;
+  for (int i = threadIdx.x; i < P.c; i += blockDim.x) {
+    double s = 0.0;
+    for (int k = 0; k < P.Ln; ++k) {
+      const double* ur = ud + (long long)(i + k) * m;
+      const double* yr = yd + (long long)(i + k) * p;
+      const double* xk = x + k * nch;
+      for (int ch = 0; ch < m; ++ch) s += ur[ch] * xk[ch];
+      for (int ch = 0; ch < p; ++ch) s += yr[ch] * xk[m + ch];
+    }
+    alpha[i] = s;
+  }
+}
+__device__ __forceinline__ void hankel_times(const KParams& P, const double* __restrict__ ud,
+                                             const double* __restrict__ yd, const double* alpha, double* z) {
+  const int m = P.m, p = P.p, nch = P.nch, c = P.c;
+  for (int rho = threadIdx.x; rho < P.r; rho += blockDim.x) {
+    const int k = rho / nch, ch = rho - k * nch;
+    const double* x = (ch < m) ? ud + (long long)k * m + ch : yd + (long long)k * p + (ch - m);
+    const int st = (ch < m) ? m : p;
+    double s0 = 0.0, s1 = 0.0;
+    int i = 0;
+    for (; i + 1 < c; i += 2) { s0 += x[(long long)i * st] * alpha[i]; s1 += x[(long long)(i + 1) * st] * alpha[i + 1]; }
+    if (i < c) s0 += x[(long long)i * st] * alpha[i];
+    z[rho] = s0 + s1;
+  }
+}
+
 // Packed lower triangle of G = H H' for the block-Hankel H of one instance, through the Hankel structure (as in the
 // cold kernel): with components (k, a) = (time offset, channel),
 //   G((k+d, a), (k, b)) = C_d(a,b) + sum_{j<k} ( x_a[j+c+d] x_b[j+c] - x_a[j+d] x_b[j] ),   C_d(a,b) = sum_{t<c} x_a[t+d] x_b[t],
@@ -840,7 +889,8 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
                                                                double* __restrict__ u_opt, double* __restrict__ cost,
                                                                int* __restrict__ status, int* __restrict__ iters,
                                                                double rank_tol, double feas_tol, double* scratch,
-                                                               long long scratch_stride, unsigned long long* dbg) {
+                                                               long long scratch_stride, double* alpha_ws,
+                                                               unsigned long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) double rsm_lds[];
   const long long b = blockIdx.x;
   if (status[b] != 4) return;                           // uniform: only instances the fast path gave up on
@@ -857,7 +907,11 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   double* z0 = zs + rv;
   double* vv = z0 + rv;
   double* col = vv + rv;
-  int* perm = reinterpret_cast<int*>(col + rv);
+  double* ra = col + rv;                                // four work vectors of the refinement step
+  double* rb = ra + rv;
+  double* rz = rb + rv;
+  double* rd = rz + rv;
+  int* perm = reinterpret_cast<int*>(rd + rv);
   int* skip = perm + rv;
   int* skipT = skip + rv;
   int* iperm = skipT + rv;                              // component -> position in the fixed-first order
@@ -1023,16 +1077,81 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
     if (tid == 0) vv[a] = skipT[a] ? 0.0 : s / Ta[a];
     __syncthreads();
   }
-  packed_back_substitute(T, nR, vv, col, skipT);          // col (free since z0) takes the solution
-  for (int a = tid; a < nR; a += nthr) vv[a] = col[a];
+  packed_back_substitute(T, nR, vv, ra, skipT);           // w2; col keeps w1 for the refinement step
+  for (int a = tid; a < nR; a += nthr) vv[a] = ra[a];
   __syncthreads();
   if (dbg && tid == 0) dbg[b * 8 + 6] = __builtin_amdgcn_s_memrealtime();
-  // ---- z_R = z0 + C v; outputs -------------------------------------------------------------------
+  // ---- one step of iterative refinement on the KKT system of the problem in the coordinates w of
+  //        z = B w,   B = H H_I' L_I^-T   (H_I: the rows with a pivot; B equals L up to the rounding of the Gram route):
+  //        min (B_R w - zs)' W (B_R w - zs)   s.t.  B_F w = f,   multipliers mu on the independent fixed rows.
+  //      B and B' are applied EXACTLY -- two products with the implicit Hankel matrix and one triangular solve each --
+  //      while the correction is solved with the factors at hand (L in place of B).  The Gram route squares cond(H);
+  //      this step brings the result back to what cond(H) itself allows.
+  double* alpha = alpha_ws + b * (long long)c;
+  // (a) z_ex = B w:  w (position order) -> x = L^-T w (zero on rows without a pivot) -> H' x -> H (H' x)
+  for (int k = tid; k < r; k += nthr) ra[k] = (k < nF) ? col[k] : vv[k - nF];
+  __syncthreads();
+  packed_back_substitute(G, r, ra, rb, skip);
+  for (int k = tid; k < r; k += nthr) ra[perm[k]] = rb[k];           // component order
+  __syncthreads();
+  hankel_transpose_times(P, ud, yd, ra, alpha);
+  __syncthreads();
+  hankel_times(P, ud, yd, alpha, rd);
+  __syncthreads();
+  for (int k = tid; k < r; k += nthr) rz[k] = rd[perm[k]];           // z_ex in position order
+  // (b) multipliers of the starting point: L_FF' mu = -L_RF' W (z_R - zs), z_R = z0 + C w2 (the unrefined solution)
+  for (int i = tid; i < nR; i += nthr) {
+    const double* Li = G + (size_t)(nF + i) * (nF + i + 1) / 2 + nF;
+    double z = z0[i];
+    for (int a = 0; a <= i; ++a) z += Li[a] * vv[a];
+    rb[nF + i] = wv[i] * (z - zs[i]);
+  }
+  __syncthreads();
+  for (int k = tid; k < nF; k += nthr) {
+    double sacc = 0.0;
+    for (int i = 0; i < nR; ++i) sacc += G[(size_t)(nF + i) * (nF + i + 1) / 2 + k] * rb[nF + i];
+    ra[k] = -sacc;
+  }
+  __syncthreads();
+  packed_back_substitute(G, nF, ra, rd, skip);                          // mu -> rd[0..nF)
+  // (c) residual of the stationarity rows: rw = -B' v,  v = [mu on the independent fixed rows ; W (z_ex,R - zs)]
+  for (int k = tid; k < r; k += nthr) rb[k] = (k < nF) ? (skip[k] ? 0.0 : rd[k]) : wv[k - nF] * (rz[k] - zs[k - nF]);
+  __syncthreads();
+  for (int k = tid; k < r; k += nthr) ra[perm[k]] = rb[k];
+  __syncthreads();
+  hankel_transpose_times(P, ud, yd, ra, alpha);
+  __syncthreads();
+  hankel_times(P, ud, yd, alpha, rd);
+  __syncthreads();
+  for (int k = tid; k < r; k += nthr) rb[k] = rd[perm[k]];
+  __syncthreads();
+  packed_forward_substitute(G, r, rb, ra, skip, red);                    // ra = L_I^-1 (H_I H' v) = -rw
+  // (d) correction with the factors at hand:  dw1 = L_FF^-1 (f - z_ex,F);  T dw2 = rw2 - C' W L_RF dw1
+  for (int k = tid; k < nF; k += nthr) rd[k] = fv[k] - rz[k];
+  __syncthreads();
+  packed_forward_substitute(G, nF, rd, rb, skip, red);                   // dw1 -> rb[0..nF)
+  for (int i = tid; i < nR; i += nthr) {
+    const double* Li = G + (size_t)(nF + i) * (nF + i + 1) / 2;
+    double sacc = 0.0;
+    for (int k = 0; k < nF; ++k) sacc += Li[k] * rb[k];
+    rd[nF + i] = sacc;                                                   // L_RF dw1
+  }
+  __syncthreads();
+  for (int a = tid; a < nR; a += nthr) {
+    double sacc = 0.0;
+    if (!skip[nF + a])
+      for (int i = a; i < nR; ++i) sacc += G[(size_t)(nF + i) * (nF + i + 1) / 2 + nF + a] * wv[i] * rd[nF + i];
+    vv[a] = skip[nF + a] ? 0.0 : -ra[nF + a] - sacc;                      // rhs of the T system (w2 itself is no longer needed)
+  }
+  __syncthreads();
+  packed_forward_substitute(T, nR, vv, col, skipT, red);                 // col: free now (w1 was consumed in (a))
+  packed_back_substitute(T, nR, col, vv, skipT);                         // dw2 -> vv
+  // ---- z_R = z_ex,R + L_RF dw1 + C dw2; outputs ------------------------------------------------------
   double part = 0.0;
   double* uo = u_opt + b * (long long)((P.Ln - n) * m);
   for (int i = tid; i < nR; i += nthr) {
-    const double* Li = G + (nF + i) * (nF + i + 1) / 2 + nF;
-    double z = z0[i];
+    const double* Li = G + (size_t)(nF + i) * (nF + i + 1) / 2 + nF;
+    double z = rz[nF + i] + rd[nF + i];
     for (int a = 0; a <= i; ++a) z += Li[a] * vv[a];
     const double dlt = z - zs[i];
     part += wv[i] * dlt * dlt;
