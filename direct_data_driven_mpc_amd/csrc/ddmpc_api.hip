@@ -571,13 +571,15 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
     if ((rc = h->d_rr.ensure((size_t)h->batch * stride * sizeof(double)))) return rc;
     if ((rc = h->d_beta.ensure((size_t)h->batch * h->kp.rE * sizeof(double)))) return rc;
     if ((rc = h->d_act.ensure((size_t)h->batch * h->kp.rE))) return rc;
-    const size_t lds = 4 * rv * sizeof(double) + 4 * rv * sizeof(int) + (size_t)PSD_PAN * sizeof(double);
+    const size_t lds = 6 * rv * sizeof(double) + 4 * rv * sizeof(int) + (size_t)PSD_PAN * sizeof(double);
     if (lds + 1024 > 160 * 1024) return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: %zu rows", r);
+    if ((rc = h->d_alpha.ensure((size_t)h->batch * (size_t)h->kp.c * sizeof(double)))) return rc;
     if (lds > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_large_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(ddmpc_large_solve_kernel, dim3((unsigned)h->batch), dim3(large_threads(r)), lds, h->stream,
                        kp_override ? *kp_override : h->kp, 16 * h->kc.NT, h->ud, h->yd, up, yp, uo, cost, (int*)status,
-                       (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, (double*)h->d_rr.p, (long long)stride);
+                       (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, (double*)h->d_rr.p, (long long)stride,
+                       (double*)h->d_alpha.p);
     HIP_TRY(hipGetLastError());
     return DDMPC_OK;
   }

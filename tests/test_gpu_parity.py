@@ -1197,8 +1197,8 @@ def test_config5_size_nominal_runs_on_the_rank_revealing_kernel(gpu):
     for b in range(B):
         ref = solve_nominal_exact(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
         assert ref["status"] == "optimal" and ref["rank"] == m * (Lh + n) + ns and int(status[b]) == 0
-        assert np.max(np.abs(u[b] - ref["optimal_u"])) / np.max(np.abs(ref["optimal_u"])) < 1e-7, b
-        assert abs(cost[b] - ref["cost"]) <= 1e-9 * abs(ref["cost"])
+        assert np.max(np.abs(u[b] - ref["optimal_u"])) / np.max(np.abs(ref["optimal_u"])) < 2e-8, b   # see DESIGN 9: the SVD
+        assert abs(cost[b] - ref["cost"]) <= 1e-9 * abs(ref["cost"])                                     # oracle is ~1e-8 here
     # the robust scheme at this size runs on ddmpc_large_solve_kernel (noisy data of the same plant)
     specr = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=3.0 * np.eye(p * Lh), R=1e-4 * np.eye(m * Lh), u_s=u_s, y_s=y_s, robust=True,
                        eps_max=0.002, lamb_alpha=50.0, lamb_sigma=1000.0, c=1.0, slack="convex", tec=True)
@@ -1208,15 +1208,11 @@ def test_config5_size_nominal_runs_on_the_rank_revealing_kernel(gpu):
         assert eng.kernel_name() == "ddmpc_large_solve_kernel"
         eng.set_data(dn["u_d"], dn["y_d"])
         ur, costr, statusr, itr = eng.solve(upn, ypn)
-    # cond(G + lam*D) is ~8e11 at this size (G grows with N and r, lam*D does not): the reduced route in fp64 is good to
-    # ~1e-7 here (the full-space oracle agrees with an 80-bit solve of the reduced system to 1e-9) -- partial parity,
-    # like the nominal scheme above; well-conditioned large problems meet the 1e-8 bar
-    # (test_robust_scheme_beyond_the_register_resident_kernels)
+    # cond(G + lam*D) is ~8e11 at this size (G grows with N and r, lam*D does not) and the Gram route alone is good to
+    # ~1e-7 there; the kernel's refinement step (residual through two exact Hankel products) restores the 1e-8 / 1e-9 bar
+    _check(specr, dn["u_d"], dn["y_d"], upn, ypn, ur, costr, statusr, range(B))
     for b in range(B):
-        sol = orc.solve_fullspace(specr, dn["u_d"][b], dn["y_d"][b], upn[b], ypn[b])
-        assert L.STATUS_STRINGS[int(statusr[b])] == sol.status == "optimal" and int(itr[b]) == sol.iters
-        assert np.max(np.abs(ur[b] - sol.optimal_u)) / np.max(np.abs(sol.optimal_u)) < 1e-6
-        assert abs(costr[b] - sol.cost) / abs(sol.cost) < 1e-7
+        assert int(itr[b]) == orc.solve_fullspace(specr, dn["u_d"][b], dn["y_d"][b], upn[b], ypn[b]).iters
     # dense weighting matrices stay limited to the register-resident kernels
     with pytest.raises(L.DDMPCError, match="too large"):
         BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=3.0 * np.eye(p * Lh) + 0.01, R=1e-4 * np.eye(m * Lh), u_s=u_s, y_s=y_s,
