@@ -117,7 +117,7 @@ int ddmpc_device_count(void);
 
 /* Problem sizes: (m+p)(L+n) <= 271 rows run on the register-resident cold-solve kernels (all schemes, all weight
  * kinds).  Beyond that, controllers with scalar/diagonal weights run on single-workgroup kernels that keep their
- * matrices in a global workspace (correct but 3.7e4 solves/s at 608 rows): ROBUST ones on ddmpc_large_solve_kernel
+ * matrices in a global workspace (a Gram-route solve plus one refinement step with exact Hankel products; 2.5-2.9e4 solves/s at 608 rows): ROBUST ones on ddmpc_large_solve_kernel
  * (same outputs, status, iterations, ddmpc_get_solution), NOMINAL ones on the rank-revealing kernel (no variable
  * reconstruction).  No affine law at that size: ddmpc_prepare is a no-op, ddmpc_step == ddmpc_solve, ddmpc_get_gain
  * is DDMPC_ERR_UNSUPPORTED.  Dense weighting matrices beyond 271 rows, and any problem beyond 1024 rows, are
