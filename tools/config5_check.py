@@ -74,3 +74,52 @@ eu = max(np.max(np.abs(u[b] - refs[b][1])) / np.max(np.abs(refs[b][1])) for b in
 ec = max(abs(cost[b] - refs[b][2]) / abs(refs[b][2]) for b in range(K))
 print("first %d instances vs the SVD-based oracle (all '%s', rank %d of 608): max rel err u %.3e, cost %.3e" % (
     K, ",".join(sorted(set(r[0] for r in refs))), refs[0][3], eu, ec))
+
+
+def model_based_solution(b):
+    """The same constrained least-squares problem on a basis of the plant's trajectory space built from (A, B, C) --
+    not data-driven, well conditioned: a yardstick for GPU and oracle alike (exact data only)."""
+    Ln = Lh + n
+    A_, B_, C_ = plant["A"], plant["B"], plant["C"]
+    M = np.zeros((Ln * (m + p), ns + Ln * m))
+    for k in range(Ln):
+        M[k * m:(k + 1) * m, ns + k * m: ns + (k + 1) * m] = np.eye(m)
+    Ak = np.eye(ns); O = []
+    for k in range(Ln):
+        O.append(C_ @ Ak); Ak = A_ @ Ak
+    for k in range(Ln):
+        M[Ln * m + k * p: Ln * m + (k + 1) * p, :ns] = O[k]
+        for j in range(k):
+            M[Ln * m + k * p: Ln * m + (k + 1) * p, ns + j * m: ns + (j + 1) * m] = O[k - 1 - j] @ B_
+    F, R, f, W, zs = [], [], [], [], []
+    for k in range(Ln):
+        kp = k - n
+        for ch in range(m):
+            i = k * m + ch
+            if kp < 0: F.append(i); f.append(up[b][k * m + ch])
+            elif kp >= Lh - n: F.append(i); f.append(u_s[ch])
+            else: R.append(i); W.append(1e-4); zs.append(u_s[ch])
+    for k in range(Ln):
+        kp = k - n
+        for ch in range(p):
+            i = Ln * m + k * p + ch
+            if kp < 0: F.append(i); f.append(yp[b][k * p + ch])
+            elif kp >= Lh - n: F.append(i); f.append(y_s[ch])
+            else: R.append(i); W.append(3.0); zs.append(y_s[ch])
+    f, W, zs = np.array(f), np.array(W), np.array(zs)
+    Qb, _ = np.linalg.qr(M)
+    Uf, Sf, Vft = np.linalg.svd(Qb[F], True)
+    kf = int(np.sum(Sf > Sf[0] * 1e-9))
+    c_p = Vft[:kf].T @ ((Uf[:, :kf].T @ f) / Sf[:kf]); Nn = Vft[kf:].T
+    sw = np.sqrt(W)
+    dd = np.linalg.lstsq(sw[:, None] * (Qb[R] @ Nn), sw * (zs - Qb[R] @ c_p), rcond=None)[0]
+    z = Qb @ (c_p + Nn @ dd)
+    return z[:Ln * m][n * m:]
+
+
+errs = np.array([np.max(np.abs(u[b] - refs[b][1])) / np.max(np.abs(refs[b][1])) for b in range(K)])
+print("instances above 5e-9 against the oracle: %d of %d" % (int(np.sum(errs > 5e-9)), K))
+for b in np.argsort(-errs)[:4]:
+    ut = model_based_solution(b); sc = np.max(np.abs(ut))
+    print("instance %3d: GPU vs oracle %.2e | GPU vs model-based solution %.2e | oracle vs model-based solution %.2e" % (
+        b, errs[b], np.max(np.abs(u[b] - ut)) / sc, np.max(np.abs(refs[b][1] - ut)) / sc))
