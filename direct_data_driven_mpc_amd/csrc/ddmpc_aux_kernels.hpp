@@ -758,13 +758,19 @@ __device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol
 // y is consumed (overwritten), x must not alias it; `skip` (optional) marks rows whose unknown is zero.
 __device__ __forceinline__ void packed_back_substitute(const double* Lm, int n, double* y, double* x, const int* skip) {
   const int tid = threadIdx.x, nthr = blockDim.x;
+  if (skip) {                                                     // rows without an unknown cost nothing below
+    for (int a = tid; a < n; a += nthr)
+      if (skip[a]) x[a] = 0.0;
+  }
   for (int a = n - 1; a >= 0; --a) {
+    if (skip && skip[a]) continue;                                // uniform
     const double* La = Lm + (size_t)a * (a + 1) / 2;
-    const double xa = (skip && skip[a]) ? 0.0 : y[a] / La[a];      // every thread forms the same value
+    const double xa = y[a] / La[a];                               // every thread forms the same value
     if (tid == 0) x[a] = xa;
     for (int j = tid; j < a; j += nthr) y[j] -= La[j] * xa;
     __syncthreads();
   }
+  __syncthreads();
 }
 
 __device__ __forceinline__ double block_sum(double v, double* red);       // defined below
@@ -774,12 +780,18 @@ __device__ __forceinline__ double block_sum(double v, double* red);       // def
 __device__ __forceinline__ void packed_forward_substitute(const double* Lm, int n, const double* rhs, double* y,
                                                           const int* skip, double* red) {
   const int tid = threadIdx.x, nthr = blockDim.x;
+  if (skip) {                                                     // skipped rows: y = 0, no dot product, no barrier
+    for (int k = tid; k < n; k += nthr)
+      if (skip[k]) y[k] = 0.0;
+    __syncthreads();
+  }
   for (int k = 0; k < n; ++k) {
+    if (skip && skip[k]) continue;                                // uniform
     const double* Lk = Lm + (size_t)k * (k + 1) / 2;
     double part = 0.0;
     for (int j = tid; j < k; j += nthr) part += Lk[j] * y[j];
     const double s = rhs[k] - block_sum(part, red);
-    if (tid == 0) y[k] = (skip && skip[k]) ? 0.0 : s / Lk[k];
+    if (tid == 0) y[k] = s / Lk[k];
     __syncthreads();
   }
 }
@@ -790,15 +802,27 @@ __device__ __forceinline__ void hankel_transpose_times(const KParams& P, const d
                                                        const double* __restrict__ yd, const double* x, double* alpha) {
   const int m = P.m, p = P.p, nch = P.nch;
   for (int i = threadIdx.x; i < P.c; i += blockDim.x) {
-    double s = 0.0;
+    // four independent accumulators and a twice-unrolled row loop: the loads of a group are in flight together
+    // (a single dependent load-multiply-add chain over the 608 terms is bound by the memory latency)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 2
     for (int k = 0; k < P.Ln; ++k) {
       const double* ur = ud + (long long)(i + k) * m;
       const double* yr = yd + (long long)(i + k) * p;
       const double* xk = x + k * nch;
-      for (int ch = 0; ch < m; ++ch) s += ur[ch] * xk[ch];
-      for (int ch = 0; ch < p; ++ch) s += yr[ch] * xk[m + ch];
+      int ch = 0;
+      for (; ch + 4 <= m; ch += 4) {
+        s0 += ur[ch] * xk[ch]; s1 += ur[ch + 1] * xk[ch + 1]; s2 += ur[ch + 2] * xk[ch + 2]; s3 += ur[ch + 3] * xk[ch + 3];
+      }
+      for (; ch < m; ++ch) s0 += ur[ch] * xk[ch];
+      ch = 0;
+      for (; ch + 4 <= p; ch += 4) {
+        s0 += yr[ch] * xk[m + ch]; s1 += yr[ch + 1] * xk[m + ch + 1]; s2 += yr[ch + 2] * xk[m + ch + 2];
+        s3 += yr[ch + 3] * xk[m + ch + 3];
+      }
+      for (; ch < p; ++ch) s1 += yr[ch] * xk[m + ch];
     }
-    alpha[i] = s;
+    alpha[i] = (s0 + s1) + (s2 + s3);
   }
 }
 __device__ __forceinline__ void hankel_times(const KParams& P, const double* __restrict__ ud,
@@ -808,11 +832,16 @@ __device__ __forceinline__ void hankel_times(const KParams& P, const double* __r
     const int k = rho / nch, ch = rho - k * nch;
     const double* x = (ch < m) ? ud + (long long)k * m + ch : yd + (long long)k * p + (ch - m);
     const int st = (ch < m) ? m : p;
-    double s0 = 0.0, s1 = 0.0;
+    double sa[8];                                      // eight loads in flight per lane: the loop is latency-bound otherwise
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sa[q] = 0.0;
     int i = 0;
-    for (; i + 1 < c; i += 2) { s0 += x[(long long)i * st] * alpha[i]; s1 += x[(long long)(i + 1) * st] * alpha[i + 1]; }
-    if (i < c) s0 += x[(long long)i * st] * alpha[i];
-    z[rho] = s0 + s1;
+    for (; i + 8 <= c; i += 8) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sa[q] += x[(long long)(i + q) * st] * alpha[i + q];
+    }
+    for (; i < c; ++i) sa[0] += x[(long long)i * st] * alpha[i];
+    z[rho] = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]));
   }
 }
 
