@@ -7,13 +7,19 @@ resident in HBM.  One "step" = one cold QP solve (implicit Hankel -> Gram ->
 reduced KKT -> Cholesky -> solve) for every instance of the batch.
 
     python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks
+(python -m torch.distributed.run, one process per GPU, RCCL) BEFORE anything touches the GPU
+runtime and relays rank 0's JSON line; under torch.distributed.run it is one of the ranks.
 
 Prints ONE JSON line on rank 0.  See DESIGN.md "Measurement".
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,16 +30,36 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 2.4 GHz x 2048 flop / 64 clk (v_mfma_f64_16x16x4_f64),
                                # measured 64 clk/instr/SIMD in profiles/r01_mfma_f64_probe.log
-# HBM traffic of one default launch (4096 instances, slack NONE, structured Gram) from separate
-# rocprofv3 --pmc passes of this same command (profiles/r01_final_pmc_fetch.csv / _write.csv):
-# FETCH_SIZE 28,911 KB x2 (gfx950 counts wide reads at half) + WRITE_SIZE 13,050 KB.
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_TRAFFIC_BYTES_DEFAULT = (2 * 28911 + 13050) * 1024
-# the same for ddmpc_warm_step_kernel at 4096 instances (profiles/r01_warm_step_pmc_*.csv)
-WARM_PMC_TRAFFIC_BYTES_DEFAULT = (2 * 37824 + 2304) * 1024
+WARM_HBM_BATCH = 32768          # warm-step HBM figure: gains of this many instances (613 MB) exceed the 256 MB Infinity Cache
 
 
-_ORACLE = {}      # inputs of the CPU baseline, inherited by the forked workers
+def kernel_source_hash():
+    """Hash of the device sources: the key under which tools/install_profiles.py files PMC traffic numbers."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "direct_data_driven_mpc_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hpp", ".hip", ".inc")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode()); h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel, batch, slack):
+    """HBM bytes per launch (FETCH_SIZE x2 per the guide's gfx950 correction + WRITE_SIZE) from the rocprofv3 --pmc
+    passes filed in profiles/traffic.json -- only when they were taken from THIS build of the kernels on this
+    workload; otherwise null (never a stale constant)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            tab = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    cur = kernel_source_hash()
+    for e in tab.get("entries", []):
+        if (e.get("kernel") == kernel and e.get("code_hash") == cur and e.get("batch") == batch
+                and e.get("slack", "none") == slack):
+            return e.get("traffic_bytes")
+    return None
 
 
 def _oracle_spec(cfg):
@@ -44,63 +70,53 @@ def _oracle_spec(cfg):
                       slack=cfg["slack"], tec=cfg["tec"])
 
 
-def _oracle_chunk(bounds):
-    """Worker: full-space oracle solves of instances [lo, hi), one BLAS thread."""
-    from oracle import ddmpc_oracle as orc
+def host_cores():
+    """CPUs this process may actually use: affinity mask, capped by a cgroup CPU quota if one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
-        from threadpoolctl import threadpool_limits
-        threadpool_limits(limits=1)
-    except Exception:       # pragma: no cover
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
         pass
-    lo, hi = bounds
-    g = _ORACLE
-    u = np.empty((hi - lo, g["spec"].L * g["spec"].m)); c = np.empty(hi - lo)
-    for i, b in enumerate(range(lo, hi)):
-        sol = orc.solve_fullspace(g["spec"], g["u_d"][b], g["y_d"][b], g["up"][b], g["yp"][b])
-        u[i] = sol.optimal_u; c[i] = sol.cost
-    return u, c
+    return n
 
 
-def cpu_baseline(cfg, u_d, y_d, up, yp, n_sample):
-    """Time the CPU oracle (full-space KKT restatement of the reference QP) on a bounded sample of the same
-    workload, instances spread over `cores` single-threaded worker processes (forked BEFORE the GPU runtime is
-    initialised).  Returns the baseline record and the oracle's (optimal_u, cost) for the parity check."""
-    import multiprocessing as mp
+def cpu_baseline(cfg, u_d, y_d, up, yp, n_sample, repeats=5):
+    """the compiled fp64 CPU restatement (oracle/ddmpc_oracle_c.c: structured Hankel Gram ->
+    reduced KKT -> Cholesky -> solve, the same cold definition the GPU executes) on the first `n_sample` instances
+    of the batch, (i) on ONE thread and (ii) on all host cores with one instance per thread, median of `repeats`
+    runs after one warm-up run each.  Also returns its (optimal_u, cost) and -- on a small sub-sample -- the
+    numpy full-space oracle's, for the parity check.  Runs before the GPU runtime is initialised."""
     from oracle import ddmpc_oracle as orc
-    from oracle import reduced_form as rf
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:       # pragma: no cover
-        threadpool_limits = None
-    cores = min(16, os.cpu_count() or 1)
+    from oracle import oracle_c
     spec = _oracle_spec(cfg)
-    _ORACLE.update(spec=spec, u_d=u_d, y_d=y_d, up=up, yp=yp)
-    edges = np.linspace(0, n_sample, 4 * cores + 1).astype(int)
-    chunks = [(int(edges[i]), int(edges[i + 1])) for i in range(4 * cores) if edges[i + 1] > edges[i]]
-    with mp.get_context("fork").Pool(cores) as pool:
-        pool.map(_oracle_chunk, [(0, 1)] * cores)              # start the workers outside the timed region
-        t0 = time.perf_counter()
-        parts = pool.map(_oracle_chunk, chunks, chunksize=1)
-        run_t = time.perf_counter() - t0
-    u_ref = np.concatenate([p[0] for p in parts]); c_ref = np.concatenate([p[1] for p in parts])
+    cores = host_cores()
+    sl = slice(0, n_sample)
+    args = (spec, cfg["N"], u_d[sl], y_d[sl], up[sl], yp[sl])
 
-    def timed(fn, n):
-        t0 = time.perf_counter()
-        for b in range(n):
-            fn(spec, u_d[b], y_d[b], up[b], yp[b])
-        return time.perf_counter() - t0
+    def timed(threads, n):
+        a = (spec, cfg["N"], u_d[:n], y_d[:n], up[:n], yp[:n])
+        oracle_c.solve_batch(*a, threads=threads)                       # warm-up (thread pool, caches)
+        ts = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            oracle_c.solve_batch(*a, threads=threads)
+            ts.append(time.perf_counter() - t0)
+        return n / float(np.median(ts)), float(np.sum(ts))
 
-    # the same oracle on ONE thread of one process (SURVEY 8d asks for both), and -- for context only -- the same
-    # CPU on the REDUCED r x r formulation the GPU kernels use (oracle/reduced_form.py: numpy BLAS Gram + LAPACK
-    # Cholesky): the algorithmic change alone, without the GPU
-    n_one, n_red = min(n_sample, 128), min(n_sample, 256)
-    if threadpool_limits is not None:
-        with threadpool_limits(limits=1):
-            one_t = timed(orc.solve_fullspace, n_one)
-            red_t = timed(rf.solve_reduced, n_red)
-    else:
-        one_t = timed(orc.solve_fullspace, n_one)
-        red_t = timed(rf.solve_reduced, n_red)
+    n_one = min(n_sample, 2048)                   # ~1 s per repeat on one thread
+    one_rate, one_t = timed(1, n_one)
+    all_rate, all_t = timed(cores, n_sample)
+    u_c, c_c, st_c, _ = oracle_c.solve_batch(*args, threads=cores)
+    n_full = min(n_sample, 64)                    # full-space numpy oracle (the reference's formulation), sub-sample
+    u_f = np.empty((n_full, spec.L * spec.m)); c_f = np.empty(n_full)
+    t0 = time.perf_counter()
+    for b in range(n_full):
+        sol = orc.solve_fullspace(spec, u_d[b], y_d[b], up[b], yp[b])
+        u_f[b] = sol.optimal_u; c_f[b] = sol.cost
+    full_rate = n_full / (time.perf_counter() - t0)
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as fh:
@@ -110,15 +126,31 @@ def cpu_baseline(cfg, u_d, y_d, up, yp, n_sample):
                     break
     except OSError:
         pass
-    rec = dict(value=n_sample / run_t, unit="QP solves/s", cores=cores, kind="port", cpu_model=cpu_model,
-               host_cpus=os.cpu_count(),
-               sample="%d cold solves (first %d instances of the batch), full-space dense KKT in numpy/LAPACK, %d worker "
-                      "processes x 1 thread, %.1f s" % (n_sample, n_sample, cores, run_t),
-               single_thread_value=n_one / one_t,
-               reduced_form_single_thread_value=n_red / red_t,
-               reduced_form_note="same CPU, one thread, the reduced r x r formulation of oracle/reduced_form.py (numpy BLAS "
-                                 "Gram + LAPACK Cholesky) on %d instances: context for the algorithmic share of the speed-up" % n_red)
-    return rec, u_ref, c_ref
+    rec = dict(value=all_rate, unit="QP solves/s", cores=cores, kind="port", cpu_model=cpu_model,
+               host_cpus=os.cpu_count(), repeats=repeats,
+               sample="first %d instances of the batch, compiled C restatement (oracle/ddmpc_oracle_c.c, gcc -O3, "
+                      "structured Hankel Gram + Cholesky of the reduced system), %d OpenMP threads x one instance each, "
+                      "median of %d runs (%.1f s); single_thread_value: the same code on 1 thread, %d instances, median "
+                      "of %d (%.1f s)" % (n_sample, cores, repeats, all_t, n_one, repeats, one_t),
+               single_thread_value=one_rate,
+               fullspace_numpy_single_process_value=full_rate,
+               fullspace_note="the reference's un-reduced formulation (571 variables + 168 equalities, dense KKT via "
+                              "numpy/LAPACK, oracle/ddmpc_oracle.py) on %d instances in this process: context only" % n_full)
+    return rec, (u_c, c_c, st_c), (u_f, c_f)
+
+
+def self_launch(a, argv):
+    """--gpus N > 1 from a bare shell: start the N ranks as child processes (nothing here has touched the GPU
+    runtime, and this process never does), relay their output, exit with their code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    res = subprocess.run(cmd, env=env)
+    raise SystemExit(res.returncode)
 
 
 def main():
@@ -134,7 +166,18 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: run all ranks on device 0 with the gloo backend (exercises the "
                          "multi-rank code path on a one-GPU box; numbers are meaningless)")
+    ap.add_argument("--dump-gathered", default=None,
+                    help="rank 0 saves the gathered optimal_u/cost/status to this .npz (tests)")
     a = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        self_launch(a, sys.argv[1:])
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE=%d" % (a.gpus, world))
 
     import torch
     import torch.distributed as dist
@@ -143,14 +186,7 @@ def main():
     from direct_data_driven_mpc_amd.engine import BatchedDDMPC
     from direct_data_driven_mpc_amd.harness import controller_params, generate_batch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
-    # synthetic inputs (host) and, at N=1, the CPU baseline -- before anything touches the GPU runtime, so
-    # that the baseline's worker processes can simply be forked
+    # synthetic inputs (host) and, at N=1, the CPU baseline -- before anything touches the GPU runtime
     cfg = controller_params(dict(slack_var_constraint_type=1 if a.slack == "convex" else 0))
     total = a.batch_per_gpu * world
     lo, hi = shard_bounds(total, rank, world)
@@ -175,10 +211,14 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
 
-    eng = BatchedDDMPC(n=n, m=m, p=p, L_=cfg["L"], N=cfg["N"], Q=cfg["Q"], R=cfg["R"], u_s=cfg["u_s"], y_s=cfg["y_s"],
-                       batch=B, controller_type=L.ROBUST, slack_type=L.SLACK_CONVEX if a.slack == "convex" else L.SLACK_NONE,
-                       eps_max=cfg["eps_max"], lamb_alpha=cfg["lamb_alpha"], lamb_sigma=cfg["lamb_sigma"], c=cfg["c"],
-                       use_terminal_constraint=cfg["tec"], device=local_rank)
+    def make_engine(batch):
+        return BatchedDDMPC(n=n, m=m, p=p, L_=cfg["L"], N=cfg["N"], Q=cfg["Q"], R=cfg["R"], u_s=cfg["u_s"], y_s=cfg["y_s"],
+                            batch=batch, controller_type=L.ROBUST,
+                            slack_type=L.SLACK_CONVEX if a.slack == "convex" else L.SLACK_NONE,
+                            eps_max=cfg["eps_max"], lamb_alpha=cfg["lamb_alpha"], lamb_sigma=cfg["lamb_sigma"], c=cfg["c"],
+                            use_terminal_constraint=cfg["tec"], device=local_rank)
+
+    eng = make_engine(B)
     u_d = torch.from_numpy(u_d_h).to(dev); y_d = torch.from_numpy(y_d_h).to(dev)
     up = torch.from_numpy(up_h).to(dev); yp = torch.from_numpy(yp_h).to(dev)
     u_opt = torch.empty((B, cfg["L"] * m), dtype=torch.float64, device=dev)
@@ -227,35 +267,63 @@ def main():
     if world > 1:
         n_bad = int(np.count_nonzero(g_s.cpu().numpy() != 0))
         assert g_u.shape[0] == total and torch.equal(g_u[lo:hi].cpu(), u_opt.cpu()), "gather mismatch"
+        if rank == 0 and a.dump_gathered:
+            np.savez(a.dump_gathered, u=g_u.cpu().numpy(), cost=g_c.cpu().numpy(), status=g_s.cpu().numpy())
+    elif a.dump_gathered:
+        np.savez(a.dump_gathered, u=u_opt.cpu().numpy(), cost=cost.cpu().numpy(), status=st)
 
     # ---- secondary metric (SURVEY 8d "warm" step), outside the timed region: rank 0, one GPU's share.
     # After ddmpc_prepare a control step only evaluates the per-instance affine law (slack NONE).
     warm = None
     if rank == 0 and world == 1 and a.slack == "none" and not a.no_warm:      # N=1 only: the other ranks must not wait on it
         u_cold = u_opt.clone(); c_cold = cost.clone()
+        nf, r = n * (m + p), (m + p) * (cfg["L"] + n)
+        wbytes = 8.0 * ((nf + 1) * r + nf + cfg["L"] * m + 1) + 8.0       # gain + past window in, u_opt/cost/status/iters out
+
+        def time_warm(e, upw, ypw, uo, co, so, io, kw=100):
+            for _ in range(5):
+                e.step(upw, ypw, uo, co, so, io)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(kw):
+                e.step(upw, ypw, uo, co, so, io)
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / kw
+
         torch.cuda.synchronize(); tp = time.perf_counter()
         eng.prepare()
         torch.cuda.synchronize(); prep_ms = (time.perf_counter() - tp) * 1e3
-        for _ in range(5):
-            eng.step(up, yp, u_opt, cost, status, iters)
-        kw = 100
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(kw):
-            eng.step(up, yp, u_opt, cost, status, iters)
-        e1.record(); torch.cuda.synchronize()
-        wms = e0.elapsed_time(e1) / kw
-        nf, r = n * (m + p), (m + p) * (cfg["L"] + n)
-        wbytes = 8.0 * ((nf + 1) * r + nf + cfg["L"] * m + 1) + 8.0       # gain + past window in, u_opt/cost/status/iters out
+        wms = time_warm(eng, up, yp, u_opt, cost, status, iters)
         gbps = wbytes * B / (wms * 1e-3) / 1e9
         warm = {"value": B / (wms * 1e-3), "unit": "control steps/s per GPU", "ms_per_step": wms, "prepare_ms": prep_ms,
-                "kernel": "ddmpc_warm_step_kernel", "bytes_per_step": wbytes,
-                "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                             "frac": gbps / HBM_PEAK_GBPS,
-                             "traffic": (WARM_PMC_TRAFFIC_BYTES_DEFAULT if a.batch_per_gpu == 4096 else None)},
+                "kernel": "ddmpc_warm_step_kernel", "bytes_per_step": wbytes, "batch": B,
+                "note": "at this batch the %.0f MB of gains sit in the 256 MB Infinity Cache: cache-resident rate, NOT an HBM "
+                        "figure; the HBM roofline is the one below" % (wbytes * B / 1e6),
+                "cache_resident_GBps": gbps,
                 "max_rel_diff_vs_cold_u": float((u_opt - u_cold).abs().max() / u_cold.abs().max()),
                 "max_rel_diff_vs_cold_cost": float(((cost - c_cold).abs() / c_cold.abs()).max())}
         u_opt.copy_(u_cold); cost.copy_(c_cold)
+        # HBM figure: a batch whose gains exceed the Infinity Cache (the 4096 data sets tiled; the warm step's
+        # traffic does not depend on the data values)
+        if B < WARM_HBM_BATCH and WARM_HBM_BATCH % B == 0:
+            rep = WARM_HBM_BATCH // B
+            big = make_engine(WARM_HBM_BATCH)
+            big.set_data(u_d.repeat(rep, 1, 1), y_d.repeat(rep, 1, 1))
+            big.prepare()
+            upb, ypb = up.repeat(rep, 1), yp.repeat(rep, 1)
+            uob = torch.empty((WARM_HBM_BATCH, cfg["L"] * m), dtype=torch.float64, device=dev)
+            cob = torch.empty((WARM_HBM_BATCH,), dtype=torch.float64, device=dev)
+            sob = torch.empty((WARM_HBM_BATCH,), dtype=torch.int32, device=dev)
+            iob = torch.empty((WARM_HBM_BATCH,), dtype=torch.int32, device=dev)
+            wms_b = time_warm(big, upb, ypb, uob, cob, sob, iob, kw=50)
+            gb = wbytes * WARM_HBM_BATCH / (wms_b * 1e-3) / 1e9
+            warm["roofline"] = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": gb / HBM_PEAK_GBPS, "batch": WARM_HBM_BATCH, "ms_per_step": wms_b,
+                                "steps_per_s": WARM_HBM_BATCH / (wms_b * 1e-3),
+                                "traffic": pmc_traffic("ddmpc_warm_step_kernel", WARM_HBM_BATCH, "none")}
+            assert torch.equal(uob[:B], u_cold) or float((uob[:B] - u_cold).abs().max() / u_cold.abs().max()) < 1e-9
+            big.close()
+            del big, upb, ypb, uob, cob, sob, iob
 
     if rank == 0:
         flops, bytes_ = eng.cost_model()
@@ -268,23 +336,30 @@ def main():
             "config": {"workload": "four-tank robust DD-MPC cold solve, L=30 N=400 n=4 m=p=2, slack %s, TEC, "
                                    "batch=%d noise seeds per GPU (BASELINE configs[1])" % (a.slack.upper(), a.batch_per_gpu),
                        "global_batch": total, "parallelism": "instances sharded dp%d, no data-path collective, one final all-gather" % world,
-                       "kernel": eng.kernel_name(), "non_optimal_instances": n_bad},
+                       "kernel": eng.kernel_name(), "non_optimal_instances": n_bad, "kernel_source_hash": kernel_source_hash()},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": (PMC_TRAFFIC_BYTES_DEFAULT if (a.batch_per_gpu == 4096 and a.slack == "none") else None),
+                         "traffic": pmc_traffic("ddmpc_cold_solve_kernel", a.batch_per_gpu, a.slack),
                          "kernel_ms": kern_ms, "flops_per_solve": flops, "hbm_bytes_per_solve": bytes_,
                          "hbm_GBps_algorithmic": bytes_ * B / (kern_ms * 1e-3) / 1e9},
         }
         if warm is not None:
             out["warm_step"] = warm
         if cpu is not None:
-            base, u_ref, c_ref = cpu
-            ns = u_ref.shape[0]
-            u_gpu, c_gpu = u_opt.cpu().numpy()[:ns], cost.cpu().numpy()[:ns]
-            eu = float(np.max(np.max(np.abs(u_gpu - u_ref), axis=1) / np.max(np.abs(u_ref), axis=1)))
-            ec = float(np.max(np.abs(c_gpu - c_ref) / np.abs(c_ref)))
+            base, (u_c, c_c, st_c), (u_f, c_f) = cpu
+            ns = u_c.shape[0]
+            u_gpu, c_gpu = u_opt.cpu().numpy(), cost.cpu().numpy()
+
+            def err(ug, cg, ur, cr):
+                k = ur.shape[0]
+                return (float(np.max(np.max(np.abs(ug[:k] - ur), axis=1) / np.max(np.abs(ur), axis=1))),
+                        float(np.max(np.abs(cg[:k] - cr) / np.abs(cr))))
+            eu, ec = err(u_gpu, c_gpu, u_c, c_c)
+            fu, fc = err(u_gpu, c_gpu, u_f, c_f)
             out["cpu_baseline"] = base
-            out["parity"] = dict(max_rel_err_u=eu, max_rel_err_cost=ec, checked=ns, tol_u=1e-8, tol_cost=1e-9)
+            out["parity"] = dict(max_rel_err_u=max(eu, fu), max_rel_err_cost=max(ec, fc), checked=ns, tol_u=1e-8, tol_cost=1e-9,
+                                 vs_c_restatement=dict(u=eu, cost=ec, checked=ns, oracle_non_optimal=int(np.count_nonzero(st_c))),
+                                 vs_fullspace_numpy=dict(u=fu, cost=fc, checked=int(u_f.shape[0])))
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

@@ -141,6 +141,8 @@ struct ddmpc_handle {
   DevBuf d_lfac, d_lfacT, d_gain, d_prep_status, d_zero, d_need;
   // host-pointer solves: one packed device buffer and its pinned host mirror (two copies per solve instead of six)
   DevBuf d_io, d_rr, d_alpha;
+  DevBuf d_zws, d_resc;                    // NOMINAL rescue kernel: z per component and a per-instance "rescued" flag (ddmpc_get_solution)
+  bool rescue_ran = false;                 // the last solve launched the rescue kernel (its flags are current)
   HostBuf h_io;
   bool prepared = false;
   int closed_loop_path = DDMPC_PATH_AUTO;
@@ -498,7 +500,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -509,9 +511,22 @@ int ddmpc_destroy(ddmpc_handle* h) {
 
 int ddmpc_set_stream(ddmpc_handle* h, void* hip_stream) {
   if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
+  if (h->stream == (hipStream_t)hip_stream && !h->own_stream) return DDMPC_OK;     // unchanged: nothing to order
   (void)hipSetDevice(h->device);
-  if (h->stream) HIP_TRY(hipStreamSynchronize(h->stream));
-  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  // work already queued on the old stream must precede what is queued on the new one: order the two streams with
+  // an event on the device instead of blocking the host
+  if (h->stream != (hipStream_t)hip_stream) {
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, h->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)hip_stream, ev, 0);
+    (void)hipEventDestroy(ev);
+    if (e != hipSuccess) return fail(DDMPC_ERR_HIP, "ddmpc_set_stream: %s", hipGetErrorString(e));
+  }
+  if (h->own_stream && h->stream) {
+    HIP_TRY(hipStreamSynchronize(h->stream));           // only the handle's own stream is destroyed (once)
+    (void)hipStreamDestroy(h->stream);
+  }
   h->stream = (hipStream_t)hip_stream;
   h->own_stream = false;
   return DDMPC_OK;
@@ -559,6 +574,7 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
                        const KParams* kp_override = nullptr) {
   int rc;
   h->beta_stale = false;
+  h->rescue_ran = false;
   if (h->large_nominal) {          // no cold kernel at this size: every instance goes to the rank-revealing kernel
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)status, 4, (size_t)h->batch, h->stream));
     return DDMPC_OK;
@@ -591,14 +607,6 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
                      h->stamps_on ? (unsigned long long*)h->d_stamps.p : (unsigned long long*)nullptr, lfac, only);
   HIP_TRY(hipGetLastError());
   return DDMPC_OK;
-}
-
-static bool warm_capable(const ddmpc_handle* h) {
-  // Without an inequality (nominal, robust with slack NONE) the solution is an affine law.  With the slack
-  // box the same law is the first active-set iterate: optimal for every instance it keeps inside the box,
-  // the others are re-solved cold.
-  (void)h;
-  return true;
 }
 
 static int launch_warm(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
@@ -650,6 +658,12 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
     int rca = h->d_alpha.ensure((size_t)h->batch * (size_t)h->kp.c * sizeof(double));
     if (rca) return rca;
   }
+  {   // z per component + "rescued" flag per instance, read by ddmpc_get_solution
+    int rcz = h->d_zws.ensure((size_t)h->batch * h->kp.rE * sizeof(double));
+    if (!rcz) rcz = h->d_resc.ensure((size_t)h->batch * sizeof(int));
+    if (rcz) return rcz;
+    HIP_TRY(hipMemsetAsync(h->d_resc.p, 0, (size_t)h->batch * sizeof(int), h->stream));
+  }
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_nominal_rr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // rank tolerance 1e-8 (relative to the largest diagonal entry of the Gram): with the fixed-first ordering the
@@ -659,8 +673,10 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
                      h->ud, h->yd, up, yp, uo, cost, (int*)status, (int*)iters, 1e-8, 1e-7, scratch, (long long)ndbl,
                      (double*)h->d_alpha.p,
                      (h->stamps_on && h->d_stamps.bytes >= (size_t)h->batch * 8 * sizeof(uint64_t)) ? (unsigned long long*)h->d_stamps.p
-                                                                                                      : (unsigned long long*)nullptr);
+                                                                                                      : (unsigned long long*)nullptr,
+                     (double*)h->d_zws.p, (int*)h->d_resc.p);
   HIP_TRY(hipGetLastError());
+  h->rescue_ran = true;
   return DDMPC_OK;
 }
 
@@ -754,6 +770,16 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
   double *dud = (double*)h->d_ud.p, *dyd = (double*)h->d_yd.p, *dup = (double*)h->d_up.p, *dyp = (double*)h->d_yp.p;
   double *duo = (double*)h->d_uopt.p, *dco = (double*)h->d_cost.p;
   int32_t *dst = (int32_t*)h->d_status.p, *dit = (int32_t*)h->d_iters.p;
+  {   // earlier asynchronous work on the compute stream may still read the buffers the uploads overwrite
+    hipEvent_t ev0;
+    HIP_TRY(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
+    hipError_t e0 = hipEventRecord(ev0, h->stream);
+    if (e0 == hipSuccess) e0 = hipStreamWaitEvent(h->copy_stream, ev0, 0);
+    (void)hipEventDestroy(ev0);
+    if (e0 != hipSuccess) return fail(DDMPC_ERR_HIP, "ddmpc_solve_from_host: %s", hipGetErrorString(e0));
+  }
+  h->beta_stale = false;
+  h->rescue_ran = false;
   HIP_TRY(hipMemcpyAsync(dup, u_past, B * sup * sizeof(double), hipMemcpyHostToDevice, h->copy_stream));
   HIP_TRY(hipMemcpyAsync(dyp, y_past, B * syp * sizeof(double), hipMemcpyHostToDevice, h->copy_stream));
   // chunks of instances: upload chunk k+1 on the copy stream while chunk k is being solved on the compute stream
@@ -775,6 +801,10 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
                        (double*)h->d_beta.p + b0 * h->kp.rE, (signed char*)h->d_act.p + b0 * h->kp.rE,
                        (unsigned long long*)nullptr, (double*)nullptr, (const int*)nullptr);
     if (hipGetLastError() != hipSuccess) rcl = fail(DDMPC_ERR_HIP, "ddmpc_solve_from_host: launch of chunk %zu failed", k);
+  }
+  if (rcl == DDMPC_OK) {            // NOMINAL on exact data: same rank-revealing rescue as ddmpc_solve (all chunks are uploaded
+    h->ud = dud; h->yd = dyd;       // and solved by now in stream order)
+    rcl = launch_nominal_rescue(h, dup, dyp, duo, dco, dst, dit);
   }
   if (rcl == DDMPC_OK) {
     if (hipMemcpyAsync(u_opt, duo, B * suo * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
@@ -904,7 +934,6 @@ int ddmpc_set_setpoints(ddmpc_handle* h, const double* u_s, const double* y_s) {
 int ddmpc_get_solution(ddmpc_handle* h, int what, double* out, int mem) {
   if (!h || !out) return fail(DDMPC_ERR_INVALID, "null argument");
   if (!h->solved) return fail(DDMPC_ERR_NOT_READY, "no solve to read a solution from");
-  if (h->large_nominal) return fail(DDMPC_ERR_UNSUPPORTED, "variables are not reconstructed at this problem size");
   HIP_TRY(hipSetDevice(h->device));
   const KParams& k = h->kp;
   if (h->beta_stale) {             // last solve = warm step without the workspace: evaluate the affine law once more, keeping beta
@@ -940,8 +969,12 @@ int ddmpc_get_solution(ddmpc_handle* h, int what, double* out, int mem) {
     if (rc) return rc;
     dst = (double*)h->d_out.p;
   }
+  // instances solved by the NOMINAL rescue kernel have no beta: ubar / ybar come from the z it exported, alpha is NaN
+  const bool resc = h->rescue_ran && h->d_resc.p && h->d_zws.p;
+  if (h->large_nominal && !resc) return fail(DDMPC_ERR_NOT_READY, "no solve to read a solution from");
   hipLaunchKernelGGL(ddmpc_reconstruct_kernel, dim3((unsigned)h->batch), dim3(256), 0, h->stream, k, 16 * h->kc.NT, what, h->ud,
-                     h->yd, h->last_up, h->last_yp, (const double*)h->d_beta.p, (const signed char*)h->d_act.p, dst);
+                     h->yd, h->last_up, h->last_yp, (const double*)h->d_beta.p, (const signed char*)h->d_act.p, dst,
+                     resc ? (const double*)h->d_zws.p : (const double*)nullptr, resc ? (const int*)h->d_resc.p : (const int*)nullptr);
   HIP_TRY(hipGetLastError());
   if (mem == DDMPC_MEM_HOST) {
     HIP_TRY(hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -1072,7 +1105,7 @@ int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps
     dx = (double*)h->d_x.p; dup = (double*)h->d_up.p; dyp = (double*)h->d_yp.p; dw = (const double*)h->d_w.p;
     dus = (double*)h->d_usys.p; dys = (double*)h->d_ysys.p;
   }
-  const bool warm_ok = warm_capable(h) && h->closed_loop_path != DDMPC_PATH_COLD &&
+  const bool warm_ok = h->closed_loop_path != DDMPC_PATH_COLD &&
                        (size_t)n_mpc_step * m <= (size_t)WARM_MAX_NF && n * h->kp.nch <= WARM_MAX_NF;
   bool warm = warm_ok && !h->kp.convex && !h->large;   // no inequality: fused loop, one launch
   const bool warm_box = warm_ok && h->kp.convex && !h->large;     // slack box: per step, affine iterate + cold re-solve where a bound is active
@@ -1105,7 +1138,8 @@ int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps
   // while instantiating the ~1200-node graph costs more than it saves (25.2 ms) -- it only pays if a graph is
   // replayed many times, which a closed loop with new data is not.
   const int n_solves = (n_steps + n_mpc_step - 1) / n_mpc_step;
-  bool use_graph = !warm && h->closed_loop_graph && n_solves >= 4;
+  bool use_graph = !warm && h->closed_loop_graph && n_solves >= 4 &&
+                   !h->large && p.controller_type != DDMPC_NOMINAL;   // those paths size workspaces / set attributes per launch
   hipGraph_t graph = nullptr;
   if (!warm) {
     if ((rc = h->d_beta.ensure(B * h->kp.rE * sizeof(double))) || (rc = h->d_act.ensure(B * h->kp.rE))) return rc;

@@ -35,9 +35,26 @@ __global__ void ddmpc_hankel_kernel(const double* __restrict__ X, double* __rest
 __global__ void ddmpc_reconstruct_kernel(KParams P, int RPs, int what, const double* __restrict__ u_d,
                                          const double* __restrict__ y_d, const double* __restrict__ u_past,
                                          const double* __restrict__ y_past, const double* __restrict__ beta_ws,
-                                         const signed char* __restrict__ act_ws, double* __restrict__ out) {
+                                         const signed char* __restrict__ act_ws, double* __restrict__ out,
+                                         const double* __restrict__ z_ws, const int* __restrict__ rescued) {
   const long long b = blockIdx.x;
   const int n = P.npu / P.m;
+  if (rescued != nullptr && rescued[b] != 0) {
+    // NOMINAL instance solved by the rank-revealing kernel (exact data): it exports z = [ubar; ybar] per component;
+    // alpha is not formed there (any alpha with H alpha = z is optimal; the kernel never picks one) -> NaN
+    const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+    if (what == 0) {
+      for (int i = threadIdx.x; i < P.c; i += blockDim.x) out[b * (long long)P.c + i] = nanv;
+      return;
+    }
+    for (int rho = threadIdx.x; rho < P.r; rho += blockDim.x) {
+      const int k = rho / P.nch, ch = rho - k * P.nch;
+      const double z = z_ws[b * (long long)P.rE + rho];
+      if (ch < P.m) { if (what == 1) out[b * (long long)(P.Ln * P.m) + k * P.m + ch] = z; }
+      else if (what == 2) out[b * (long long)(P.Ln * P.p) + k * P.p + (ch - P.m)] = z;
+    }
+    return;
+  }
   const double* bw = beta_ws + b * (long long)P.rE;
   const signed char* aw = act_ws + b * (long long)P.rE;
   const double* up = u_past + b * (long long)P.npu;
@@ -919,7 +936,8 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
                                                                int* __restrict__ status, int* __restrict__ iters,
                                                                double rank_tol, double feas_tol, double* scratch,
                                                                long long scratch_stride, double* alpha_ws,
-                                                               unsigned long long* dbg) {
+                                                               unsigned long long* dbg, double* __restrict__ z_ws,
+                                                               int* __restrict__ rescued) {
   extern __shared__ __attribute__((aligned(16))) double rsm_lds[];
   const long long b = blockIdx.x;
   if (status[b] != 4) return;                           // uniform: only instances the fast path gave up on
@@ -1186,11 +1204,14 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
     part += wv[i] * dlt * dlt;
     const int oidx = P.tabi[2 * RPs + perm[nF + i]];
     if (oidx >= 0) uo[oidx] = z;
+    if (z_ws) z_ws[b * (long long)P.rE + perm[nF + i]] = z;
   }
   for (int k = tid; k < nF; k += nthr) {
     const int oidx = P.tabi[2 * RPs + perm[k]];
     if (oidx >= 0) uo[oidx] = fv[k];                    // terminal inputs are part of optimal_u
+    if (z_ws) z_ws[b * (long long)P.rE + perm[k]] = fv[k];
   }
+  if (rescued && tid == 0) rescued[b] = 1;
   part = wave_sum(part);
   __syncthreads();
   if ((tid & 63) == 0) red[tid >> 6] = part;

@@ -162,3 +162,41 @@ def reproduction_start(plant: Dict, rngs, y_0, u_s, n: int):
     W = np.stack([plant["eps_max"] * rng.uniform(-1.0, 1.0, (n, p)) for rng in rngs])
     Y, x_start = simulate_batch(plant["A"], plant["B"], plant["C"], plant["D"], np.tile(x_eq, (Bt, 1)), U, W)
     return x_start, U.reshape(Bt, n * m), Y.reshape(Bt, n * p)
+
+
+def step_report_line(t: int, cost: float, u_s, y_s, u_k, y_k) -> str:
+    """The per-solve report line of the reference's control loop at verbosity 2
+    (utilities/controller/controller_operation.py:310-329): solve time step, cost, setpoint errors of the
+    last applied step."""
+    u_error = np.asarray(u_s, float).flatten() - np.asarray(u_k, float).flatten()
+    y_error = np.asarray(y_s, float).flatten() - np.asarray(y_k, float).flatten()
+    ue = ', '.join([f'u_{i + 1}e = {e:>6.3f}' for i, e in enumerate(u_error)])
+    ye = ', '.join([f'y_{i + 1}e = {e:>6.3f}' for i, e in enumerate(y_error)])
+    return f"    Time step: {t:>4} - MPC cost value: {cost:>8.4f} - Error: {ue}, {ye}"
+
+
+def simulate_control_loop(plant: Dict, x0, controller, n_steps: int, rng, verbose: int = 0):
+    """Drive ONE controller object in closed loop with the plant, the way the reference's
+    `simulate_data_driven_mpc_control_loop` does (utilities/controller/controller_operation.py:201-331):
+    noise drawn first (`eps_max * uniform(-1, 1, (n_steps, p))`), then per solve: update_and_solve ->
+    for each of the next n_mpc_step steps: apply optimal_u[k - t], y = Cx + Du + w before x <- Ax + Bu
+    (utilities/model_simulation.py:93-98), store the measurement.  `controller` is any object with the
+    reference class's per-step methods.  Returns (u_sys, y_sys, x_end)."""
+    A, Bm, C, D, eps = plant["A"], plant["B"], plant["C"], plant["D"], plant["eps_max"]
+    m, p = Bm.shape[1], C.shape[0]
+    x = np.array(x0, dtype=float).reshape(-1)
+    n_mpc_step = controller.n_mpc_step
+    u_sys = np.zeros((n_steps, m)); y_sys = np.zeros((n_steps, p))
+    w_sys = eps * rng.uniform(-1.0, 1.0, (n_steps, p))
+    for t in range(0, n_steps, n_mpc_step):
+        controller.update_and_solve_data_driven_mpc()
+        for k in range(t, min(t + n_mpc_step, n_steps)):
+            u_sys[k, :] = controller.get_optimal_control_input_at_step(n_step=k - t)
+            y_sys[k, :] = C @ x + D @ u_sys[k, :] + w_sys[k, :]
+            x = A @ x + Bm @ u_sys[k, :]
+            controller.store_input_output_measurement(u_current=u_sys[k, :].reshape(-1, 1),
+                                                      y_current=y_sys[k, :].reshape(-1, 1))
+        if verbose > 1:
+            print(step_report_line(t, controller.get_optimal_cost_value(), controller.u_s, controller.y_s,
+                                   u_sys[k, :], y_sys[k, :]))
+    return u_sys, y_sys, x

@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "examples"))
 from direct_data_driven_mpc_amd import _lib as L                                  # noqa: E402
 from direct_data_driven_mpc_amd.engine import BatchedDDMPC                        # noqa: E402
 from direct_data_driven_mpc_amd.harness import (controller_params_from_yaml, generate_batch,   # noqa: E402
-                                                plant_from_yaml)
+                                                plant_from_yaml, step_report_line)
 
 CFG = os.path.join(ROOT, "examples", "config")
 
@@ -103,12 +103,10 @@ def main():
                           c=cfg["c"], use_terminal_constraint=cfg["tec"], device=a.device) as one:
             one.set_data(data["u_d"][:1], data["y_d"][:1])
             U = np.concatenate([data["u_d"][0, -n:], u_sys[0]]); Y = np.concatenate([data["y_d"][0, -n:], y_sys[0]])
-            for t in range(0, n_steps, n_mpc_step):
+            for t in range(0, n_steps, n_mpc_step):                              # one line per solve, controller_operation.py:310-329
                 _, cst, _, _ = one.step(U[t:t + n].reshape(1, -1), Y[t:t + n].reshape(1, -1))
-                for k in range(t, min(t + n_mpc_step, n_steps)):
-                    ue = ", ".join(f"u_{i + 1}e = {e:>6.3f}" for i, e in enumerate(cfg["u_s"] - u_sys[0, k]))
-                    ye = ", ".join(f"y_{i + 1}e = {e:>6.3f}" for i, e in enumerate(cfg["y_s"] - y_sys[0, k]))
-                    print(f"    Time step: {k:>4} - MPC cost value: {float(cst[0]):>8.4f} - Error: {ue}, {ye}")
+                k = min(t + n_mpc_step, n_steps) - 1                             # errors of the last applied step
+                print(step_report_line(t, float(cst[0]), cfg["u_s"], cfg["y_s"], u_sys[0, k], y_sys[0, k]))
     if a.verbose:
         n_bad = int(np.count_nonzero(status > 1))
         err_y = np.abs(y_sys[:, -1, :] - cfg["y_s"]); err_u = np.abs(u_sys[:, -1, :] - cfg["u_s"])

@@ -50,7 +50,7 @@ def main():
     n, B = cfg["n"], a.batch
     data = generate_batch(range(a.seed, a.seed + B), N=cfg["N"], plant=plant, u_range=cfg["u_range"])
     x_start, U_n, Y_n = reproduction_start(plant, data["rngs"], a.y_0, cfg["u_s"], n)
-    n_steps = a.t_sim - n                                                        # the n warm-up steps count
+    n_steps = a.t_sim + 1 - n            # robust_data_driven_mpc_reproduction.py: n_steps = t_sim + 1, loops run n_steps - n
     results = {}
     for tag, tec, step in (("TEC 1-step", True, 1), ("TEC n-step", True, n), ("UCON 1-step", False, 1)):
         w = np.stack([plant["eps_max"] * rng.uniform(-1.0, 1.0, (n_steps, p)) for rng in data["rngs"]])   # per controller, in order

@@ -117,9 +117,9 @@ int ddmpc_device_count(void);
 
 /* Problem sizes: (m+p)(L+n) <= 271 rows run on the register-resident cold-solve kernels (all schemes, all weight
  * kinds).  Beyond that, controllers with scalar/diagonal weights run on single-workgroup kernels that keep their
- * matrices in a global workspace (a Gram-route solve plus one refinement step with exact Hankel products; 2.5-2.9e4 solves/s at 608 rows): ROBUST ones on ddmpc_large_solve_kernel
- * (same outputs, status, iterations, ddmpc_get_solution), NOMINAL ones on the rank-revealing kernel (no variable
- * reconstruction).  No affine law at that size: ddmpc_prepare is a no-op, ddmpc_step == ddmpc_solve, ddmpc_get_gain
+ * matrices in a global workspace (a Gram-route solve plus refinement with exact Hankel products; throughput: see
+ * profiles/README.md): ROBUST ones on ddmpc_large_solve_kernel (same outputs, status, iterations, ddmpc_get_solution),
+ * NOMINAL ones on the rank-revealing kernel (ddmpc_get_solution: ubar / ybar; alpha is not formed there and reads NaN).  No affine law at that size: ddmpc_prepare is a no-op, ddmpc_step == ddmpc_solve, ddmpc_get_gain
  * is DDMPC_ERR_UNSUPPORTED.  Dense weighting matrices beyond 271 rows, and any problem beyond 1024 rows, are
  * DDMPC_ERR_UNSUPPORTED (reported by ddmpc_create).
  *
@@ -191,7 +191,9 @@ int ddmpc_set_option(ddmpc_handle* h, int option, int value);
 int ddmpc_set_setpoints(ddmpc_handle* h, const double* u_s, const double* y_s);
 
 /* Values of the optimisation variables after the last ddmpc_solve
- * (controller.py:434-445 `.value`); `out` sized as listed at DDMPC_SOL_*. */
+ * (controller.py:434-445 `.value`); `out` sized as listed at DDMPC_SOL_*.  Instances of a NOMINAL controller that
+ * were solved by the rank-revealing rescue kernel (exact, rank-deficient data) report ubar / ybar from that kernel's
+ * own solution and NaN for alpha (any alpha with H alpha = [ubar; ybar] is optimal there; none is formed). */
 int ddmpc_get_solution(ddmpc_handle* h, int what, double* out, int mem);
 
 /* hankel_matrix(X, L) for a batch (direct_data_driven_mpc/utilities/hankel_matrix.py:5-53):

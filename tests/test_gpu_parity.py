@@ -1030,7 +1030,7 @@ def test_batched_reproduction_script(gpu, tmp_path):
     assert np.allclose(z["TEC_n-step_u"][0, 0], [8.6604991, 8.53323249], atol=2e-7)
     assert np.allclose(z["UCON_1-step_u"][0, 0], [7.89630434, 9.2946719], atol=2e-7)
     assert "instance 0 at step 384" in res.stdout
-    assert np.all(z["TEC_1-step_status"] == 0) and z["TEC_1-step_u"].shape == (3, 596, 2)
+    assert np.all(z["TEC_1-step_status"] == 0) and z["TEC_1-step_u"].shape == (3, 597, 2)
 
 
 def test_device_memory_variants_of_every_entry_point(gpu):
