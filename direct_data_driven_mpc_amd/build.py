@@ -43,14 +43,17 @@ LARGE_NT = 16
 def instances():
     txt = open(os.path.join(CSRC, "ddmpc_instances.inc")).read()
     inst = [(int(a), int(b)) for a, b in re.findall(r"^DDMPC_INSTANCE\((\d+),\s*(\d+)\)", txt, re.M)]
-    return [(nt, w) for nt, w in inst if not (SKIP_LARGE and nt > LARGE_NT)]
+    return [(nt, w) for nt, w in inst if not (SKIP_LARGE and nt > LARGE_NT) and (not ONLY_NT or nt == ONLY_NT)]
 
 
 # what each kind of translation unit is built from; an object is rebuilt when the hash of these files
 # and of its command line differs from the one recorded next to it (content-based: immune to
 # checkouts and copies that only change modification times)
-INST_DEPS = ["ddmpc_inst.hip", "ddmpc_kernels.hpp"]
-API_DEPS = ["ddmpc_api.hip", "ddmpc_aux_kernels.hpp", "ddmpc_kernels.hpp", "ddmpc_instances.inc"]
+INST_DEPS = ["ddmpc_inst.hip", "ddmpc_kernels.hpp", "ddmpc_cold2.hpp"]
+API_DEPS = ["ddmpc_api.hip", "ddmpc_aux_kernels.hpp", "ddmpc_kernels.hpp", "ddmpc_cold2.hpp", "ddmpc_instances.inc"]
+# first-generation kernels (DDMPC_KERNEL=1, A/B measurements): built too unless DDMPC_SKIP_V1 is set (development)
+SKIP_V1 = os.environ.get("DDMPC_SKIP_V1", "") not in ("", "0")
+ONLY_NT = int(os.environ.get("DDMPC_ONLY_NT", "0") or 0)          # development: build just this instance of the kernels
 
 
 def _fingerprint(cmd, names, extra=()) -> str:
@@ -84,17 +87,20 @@ def build(force: bool = False, jobs: int = 0, verbose: bool = True) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     header = os.path.join(os.path.dirname(PKG_DIR), "include", "ddmpc.h")
     tasks = []
-    api_obj = os.path.join(OBJ_DIR, "ddmpc_api_nolarge.o" if SKIP_LARGE else "ddmpc_api.o")
-    api_flags = ["-DDDMPC_NO_LARGE"] if SKIP_LARGE else []
+    dev = SKIP_LARGE or SKIP_V1 or ONLY_NT
+    api_obj = os.path.join(OBJ_DIR, "ddmpc_api_dev.o" if dev else "ddmpc_api.o")
+    api_flags = (["-DDDMPC_NO_LARGE"] if SKIP_LARGE else []) + (["-DDDMPC_NO_V1"] if SKIP_V1 else []) + \
+                (["-DDDMPC_ONLY_NT=%d" % ONLY_NT] if ONLY_NT else [])
     cmd = [hipcc] + COMMON_FLAGS + api_flags + ["-c", os.path.join(CSRC, "ddmpc_api.hip"), "-o", api_obj]
     tasks.append((cmd, api_obj, _fingerprint(cmd, API_DEPS, [header])))
     for nt, w in instances():
-        obj = os.path.join(OBJ_DIR, "ddmpc_inst_%d_%d.o" % (nt, w))
-        cmd = [hipcc] + COMMON_FLAGS + ["-DDDMPC_INST_NT=%d" % nt, "-DDDMPC_INST_W=%d" % w, "-c",
-                                        os.path.join(CSRC, "ddmpc_inst.hip"), "-o", obj]
-        tasks.append((cmd, obj, _fingerprint(cmd, INST_DEPS)))
+        for gen in ((2,) if SKIP_V1 else (2, 1)):
+            obj = os.path.join(OBJ_DIR, "ddmpc_inst%s_%d_%d.o" % ("" if gen == 1 else "2", nt, w))
+            cmd = [hipcc] + COMMON_FLAGS + ["-DDDMPC_INST_NT=%d" % nt, "-DDDMPC_INST_W=%d" % w] + \
+                  (["-DDDMPC_INST_V1"] if gen == 1 else []) + ["-c", os.path.join(CSRC, "ddmpc_inst.hip"), "-o", obj]
+            tasks.append((cmd, obj, _fingerprint(cmd, INST_DEPS)))
     todo = [t for t in tasks if force or not _is_current(t[1], t[2])]
-    todo.sort(key=lambda t: -int(re.search(r"ddmpc_inst_(\d+)_", t[1]).group(1)) if "ddmpc_inst_" in t[1] else 0)  # longest first
+    todo.sort(key=lambda t: -int(re.search(r"ddmpc_inst2?_(\d+)_", t[1]).group(1)) if "ddmpc_inst" in t[1] else 0)  # longest first
     if todo:
         jobs = jobs or min(len(todo), max(1, (os.cpu_count() or 2) - 1), 8)
         if verbose:

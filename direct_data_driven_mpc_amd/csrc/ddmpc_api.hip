@@ -18,10 +18,18 @@ using namespace ddmpc;
 
 // The kernels are instantiated in their own translation units (ddmpc_inst.hip).
 namespace ddmpc {
+#ifndef DDMPC_NO_V1
 #define DDMPC_INSTANCE(NT, W)                                                                        \
   extern template __global__ void ddmpc_cold_solve_kernel<NT, W>(                                    \
       KParams, const double*, const double*, const double*, const double*, double*, double*, int*,  \
       int*, double*, signed char*, unsigned long long*, double*, const int*);
+#include "ddmpc_instances.inc"
+#undef DDMPC_INSTANCE
+#endif
+#define DDMPC_INSTANCE(NT, W)                                                                        \
+  extern template __global__ void ddmpc_cold_solve_kernel2<NT, W>(                                   \
+      KParams, const double*, const double*, const double*, const double*, double*, double*, int*,  \
+      int*, double*, signed char*, unsigned long long*, double*, double*, const int*);
 #include "ddmpc_instances.inc"
 #undef DDMPC_INSTANCE
 }  // namespace ddmpc
@@ -89,26 +97,35 @@ struct HostBuf {            // pinned host staging
 typedef void (*cold_kernel_t)(KParams, const double*, const double*, const double*, const double*, double*,
                               double*, int*, int*, double*, signed char*, unsigned long long*, double*, const int*);
 
+typedef void (*cold_kernel2_t)(KParams, const double*, const double*, const double*, const double*, double*,
+                               double*, int*, int*, double*, signed char*, unsigned long long*, double*, double*, const int*);
+
 struct KernelChoice {
   int NT, W;
-  cold_kernel_t fn;
+  cold_kernel_t fn;          // first-generation kernel (4-wide panels), DDMPC_KERNEL=1
   const char* name;
-  size_t reserved;
+  cold_kernel2_t fn2;        // 16-wide-panel kernel (ddmpc_cold2.hpp), the default
+  const char* name2;
 };
 
 // Instantiated (tile rows, waves) pairs.  A problem uses the smallest NT that
 // holds rE+1 rows; larger problems are rejected as unsupported.
+#ifndef DDMPC_NO_V1
+#define DDMPC_V1_FN(NT, W) &ddmpc_cold_solve_kernel<NT, W>
+#else
+#define DDMPC_V1_FN(NT, W) nullptr
+#endif
 const KernelChoice kKernels[] = {
 #define DDMPC_INSTANCE(NT, W) \
-  {NT, W, &ddmpc_cold_solve_kernel<NT, W>, "ddmpc_cold_solve_kernel<" #NT "," #W ">", sizeof(double) * 0},
+  {NT, W, DDMPC_V1_FN(NT, W), "ddmpc_cold_solve_kernel_v1<" #NT "," #W ">", &ddmpc_cold_solve_kernel2<NT, W>, "ddmpc_cold_solve_kernel<" #NT "," #W ">"},
 #include "ddmpc_instances.inc"
 #undef DDMPC_INSTANCE
 };
 
-size_t lds_doubles_for(int NT, int xs_len) {
+size_t lds_doubles_for(int NT, int xs_len, bool v2) {
   // the LDS carve-up depends on NT only (several W may share an NT)
 #define DDMPC_INSTANCE(NT_, W_) \
-  if (NT == NT_) return (size_t)Lds<NT_>::total(xs_len);
+  if (NT == NT_) return v2 ? (size_t)Lds2<NT_>::total(xs_len) : (size_t)Lds<NT_>::total(xs_len);
 #include "ddmpc_instances.inc"
 #undef DDMPC_INSTANCE
   return 0;
@@ -142,7 +159,9 @@ struct ddmpc_handle {
   // host-pointer solves: one packed device buffer and its pinned host mirror (two copies per solve instead of six)
   DevBuf d_io, d_rr, d_alpha;
   DevBuf d_zws, d_resc;                    // NOMINAL rescue kernel: z per component and a per-instance "rescued" flag (ddmpc_get_solution)
-  bool rescue_ran = false;                 // the last solve launched the rescue kernel (its flags are current)
+  bool rescue_ran = false;
+  bool v2 = true;                          // 16-wide-panel cold kernel (default); false: first-generation kernel (DDMPC_KERNEL=1)
+  bool ws_stale = false;                   // the last solve was a cold solve that skipped the beta / active-set workspace                 // the last solve launched the rescue kernel (its flags are current)
   HostBuf h_io;
   bool prepared = false;
   int closed_loop_path = DDMPC_PATH_AUTO;
@@ -420,8 +439,8 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
         if (cand.NT == kc->NT && cand.W == want) { kc = &cand; break; }
     }
   }
-  static const KernelChoice kLargeNominal = {0, 4, nullptr, "ddmpc_nominal_rr_kernel", 0};
-  static const KernelChoice kLargeSolve = {0, 4, nullptr, "ddmpc_large_solve_kernel", 0};
+  static const KernelChoice kLargeNominal = {0, 4, nullptr, "ddmpc_nominal_rr_kernel", nullptr, "ddmpc_nominal_rr_kernel"};
+  static const KernelChoice kLargeSolve = {0, 4, nullptr, "ddmpc_large_solve_kernel", nullptr, "ddmpc_large_solve_kernel"};
   if (!kc) {
     // No register-resident kernel holds this many rows.  With scalar/diagonal weights the problem is served by the
     // global-workspace kernels (plain VALU code): ROBUST controllers by
@@ -465,7 +484,9 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   // x[c + 4*NT + 2]; everything past N*nch is zero padding
   k.xs_len = ((p.N - k.Ln + 4) * k.nch + 16 * h->kc.NT + 8 + 64 + 1) & ~1;   // + lag groups past Ln in the 4x4x4 base loop
   if (k.xs_len < (p.N + 2) * k.nch) k.xs_len = ((p.N + 2) * k.nch + 1) & ~1;
-  const size_t lds_doubles = lds_doubles_for(h->kc.NT, k.xs_len);
+  if (const char* gen = getenv("DDMPC_KERNEL")) h->v2 = atoi(gen) != 1;    // development knob: 1 = first-generation kernel
+  if (!h->v2 && !h->kc.fn) h->v2 = true;
+  const size_t lds_doubles = lds_doubles_for(h->kc.NT, k.xs_len, h->v2);
   h->lds_bytes = lds_doubles * sizeof(double);
   if (const char* pad = getenv("DDMPC_LDS_PAD")) {        // development knob: extra LDS bytes to lower the occupancy
     const long v = atol(pad);
@@ -483,7 +504,7 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   }
   h->own_stream = true;
   if (h->lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(h->kc.fn),
+    hipError_t e = hipFuncSetAttribute(h->v2 ? reinterpret_cast<const void*>(h->kc.fn2) : reinterpret_cast<const void*>(h->kc.fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
     if (e != hipSuccess) { ddmpc_destroy(h); return fail(DDMPC_ERR_HIP, "hipFuncSetAttribute(LDS=%zu) failed: %s", h->lds_bytes, hipGetErrorString(e)); }
   }
@@ -569,12 +590,15 @@ static unsigned large_threads(size_t r) {   // workgroup size of the global-work
   return r <= 256 ? 256u : 512u;           // PSD_RPT panel rows per thread in registers (r <= PSD_RPT * threads)
 }
 
+// want_ws: also write the beta / active-set workspace (what ddmpc_get_solution, the gain kernel and the slack-box warm
+// step read).  A plain cold solve skips it (1.2 KB of HBM writes per instance) and ddmpc_get_solution re-solves on demand.
 static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
                        int32_t* status, int32_t* iters, double* lfac = nullptr, const int* only = nullptr,
-                       const KParams* kp_override = nullptr) {
+                       const KParams* kp_override = nullptr, bool want_ws = true, double* lfacT = nullptr) {
   int rc;
   h->beta_stale = false;
   h->rescue_ran = false;
+  h->ws_stale = !want_ws && !h->large;
   if (h->large_nominal) {          // no cold kernel at this size: every instance goes to the rank-revealing kernel
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)status, 4, (size_t)h->batch, h->stream));
     return DDMPC_OK;
@@ -599,12 +623,20 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
     HIP_TRY(hipGetLastError());
     return DDMPC_OK;
   }
-  if ((rc = h->d_beta.ensure((size_t)h->batch * h->kp.rE * sizeof(double)))) return rc;
-  if ((rc = h->d_act.ensure((size_t)h->batch * h->kp.rE))) return rc;
+  if (want_ws) {
+    if ((rc = h->d_beta.ensure((size_t)h->batch * h->kp.rE * sizeof(double)))) return rc;
+    if ((rc = h->d_act.ensure((size_t)h->batch * h->kp.rE))) return rc;
+  }
+  double* bws = want_ws ? (double*)h->d_beta.p : nullptr;
+  signed char* aws = want_ws ? (signed char*)h->d_act.p : nullptr;
+  unsigned long long* stp = h->stamps_on ? (unsigned long long*)h->d_stamps.p : (unsigned long long*)nullptr;
   dim3 grid((unsigned)h->batch), block(64 * h->kc.W);
-  hipLaunchKernelGGL(h->kc.fn, grid, block, h->lds_bytes, h->stream, kp_override ? *kp_override : h->kp, h->ud, h->yd,
-                     up, yp, uo, cost, (int*)status, (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p,
-                     h->stamps_on ? (unsigned long long*)h->d_stamps.p : (unsigned long long*)nullptr, lfac, only);
+  if (h->v2)
+    hipLaunchKernelGGL(h->kc.fn2, grid, block, h->lds_bytes, h->stream, kp_override ? *kp_override : h->kp, h->ud, h->yd,
+                       up, yp, uo, cost, (int*)status, (int*)iters, bws, aws, stp, lfac, lfacT, only);
+  else
+    hipLaunchKernelGGL(h->kc.fn, grid, block, h->lds_bytes, h->stream, kp_override ? *kp_override : h->kp, h->ud, h->yd,
+                       up, yp, uo, cost, (int*)status, (int*)iters, bws, aws, stp, lfac, only);
   HIP_TRY(hipGetLastError());
   return DDMPC_OK;
 }
@@ -630,6 +662,7 @@ static int launch_warm(ddmpc_handle* h, const double* up, const double* yp, doub
                      keep ? (signed char*)h->d_act.p : (signed char*)nullptr, need);
   HIP_TRY(hipGetLastError());
   h->beta_stale = !keep;
+  h->ws_stale = false;
   if (need)       // instances with an active slack bound: full active-set solve, same launch geometry, others exit at once
     return launch_cold(h, up, yp, uo, cost, status, iters, nullptr, need);
   return DDMPC_OK;
@@ -683,7 +716,7 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
 typedef int (*launch_fn)(ddmpc_handle*, const double*, const double*, double*, double*, int32_t*, int32_t*);
 static int launch_cold_plain(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
                              int32_t* status, int32_t* iters) {
-  int rc = launch_cold(h, up, yp, uo, cost, status, iters, nullptr);
+  int rc = launch_cold(h, up, yp, uo, cost, status, iters, nullptr, nullptr, nullptr, /*want_ws=*/false);
   return rc ? rc : launch_nominal_rescue(h, up, yp, uo, cost, status, iters);
 }
 
@@ -763,8 +796,7 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
   if ((rc = h->d_ud.ensure(B * su * sizeof(double))) || (rc = h->d_yd.ensure(B * sy * sizeof(double))) ||
       (rc = h->d_up.ensure(B * sup * sizeof(double))) || (rc = h->d_yp.ensure(B * syp * sizeof(double))) ||
       (rc = h->d_uopt.ensure(B * suo * sizeof(double))) || (rc = h->d_cost.ensure(B * sizeof(double))) ||
-      (rc = h->d_status.ensure(B * sizeof(int32_t))) || (rc = h->d_iters.ensure(B * sizeof(int32_t))) ||
-      (rc = h->d_beta.ensure(B * h->kp.rE * sizeof(double))) || (rc = h->d_act.ensure(B * h->kp.rE)))
+      (rc = h->d_status.ensure(B * sizeof(int32_t))) || (rc = h->d_iters.ensure(B * sizeof(int32_t))))
     return rc;
   if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
   double *dud = (double*)h->d_ud.p, *dyd = (double*)h->d_yd.p, *dup = (double*)h->d_up.p, *dyp = (double*)h->d_yp.p;
@@ -780,6 +812,7 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
   }
   h->beta_stale = false;
   h->rescue_ran = false;
+  h->ws_stale = true;
   HIP_TRY(hipMemcpyAsync(dup, u_past, B * sup * sizeof(double), hipMemcpyHostToDevice, h->copy_stream));
   HIP_TRY(hipMemcpyAsync(dyp, y_past, B * syp * sizeof(double), hipMemcpyHostToDevice, h->copy_stream));
   // chunks of instances: upload chunk k+1 on the copy stream while chunk k is being solved on the compute stream
@@ -795,11 +828,18 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
       rcl = fail(DDMPC_ERR_HIP, "ddmpc_solve_from_host: upload of chunk %zu failed", k);
       break;
     }
-    hipLaunchKernelGGL(h->kc.fn, dim3((unsigned)nb), dim3(64 * h->kc.W), h->lds_bytes, h->stream, h->kp,
-                       (const double*)(dud + b0 * su), (const double*)(dyd + b0 * sy), (const double*)(dup + b0 * sup),
-                       (const double*)(dyp + b0 * syp), duo + b0 * suo, dco + b0, (int*)(dst + b0), (int*)(dit + b0),
-                       (double*)h->d_beta.p + b0 * h->kp.rE, (signed char*)h->d_act.p + b0 * h->kp.rE,
-                       (unsigned long long*)nullptr, (double*)nullptr, (const int*)nullptr);
+    if (h->v2)
+      hipLaunchKernelGGL(h->kc.fn2, dim3((unsigned)nb), dim3(64 * h->kc.W), h->lds_bytes, h->stream, h->kp,
+                         (const double*)(dud + b0 * su), (const double*)(dyd + b0 * sy), (const double*)(dup + b0 * sup),
+                         (const double*)(dyp + b0 * syp), duo + b0 * suo, dco + b0, (int*)(dst + b0), (int*)(dit + b0),
+                         (double*)nullptr, (signed char*)nullptr, (unsigned long long*)nullptr, (double*)nullptr,
+                         (double*)nullptr, (const int*)nullptr);
+    else
+      hipLaunchKernelGGL(h->kc.fn, dim3((unsigned)nb), dim3(64 * h->kc.W), h->lds_bytes, h->stream, h->kp,
+                         (const double*)(dud + b0 * su), (const double*)(dyd + b0 * sy), (const double*)(dup + b0 * sup),
+                         (const double*)(dyp + b0 * syp), duo + b0 * suo, dco + b0, (int*)(dst + b0), (int*)(dit + b0),
+                         (double*)nullptr, (signed char*)nullptr, (unsigned long long*)nullptr, (double*)nullptr,
+                         (const int*)nullptr);
     if (hipGetLastError() != hipSuccess) rcl = fail(DDMPC_ERR_HIP, "ddmpc_solve_from_host: launch of chunk %zu failed", k);
   }
   if (rcl == DDMPC_OK) {            // NOMINAL on exact data: same rank-revealing rescue as ddmpc_solve (all chunks are uploaded
@@ -849,12 +889,13 @@ int ddmpc_prepare(ddmpc_handle* h) {
   KParams k0 = h->kp;                              // slack box: factor of the EMPTY active set (one iteration)
   k0.convex = 0;
   if ((rc = launch_cold(h, z, z + B * p.n * p.m, (double*)h->d_uopt.p, (double*)h->d_cost.p,
-                        (int32_t*)h->d_prep_status.p, nullptr, (double*)h->d_lfac.p, nullptr, &k0)))
+                        (int32_t*)h->d_prep_status.p, nullptr, (double*)h->d_lfac.p, nullptr, &k0, true, (double*)h->d_lfacT.p)))
     return rc;
   const size_t ntiles = B * (size_t)(NT * (NT + 1) / 2);
   if (ntiles > 0x7fffffffULL) return fail(DDMPC_ERR_INVALID, "batch too large for ddmpc_prepare");
-  hipLaunchKernelGGL(ddmpc_transpose_tiles_kernel, dim3((unsigned)ntiles), dim3(256), 0, h->stream,
-                     (const double*)h->d_lfac.p, (double*)h->d_lfacT.p);
+  if (!h->v2)       // the first-generation kernel exports L only; the 16-wide-panel kernel writes both layouts itself
+    hipLaunchKernelGGL(ddmpc_transpose_tiles_kernel, dim3((unsigned)ntiles), dim3(256), 0, h->stream,
+                       (const double*)h->d_lfac.p, (double*)h->d_lfacT.p);
   if ((rc = h->d_beta.ensure(B * k.rE * sizeof(double)))) return rc;     // beta of the cold launch above
   bool launched = false;
 #define DDMPC_INSTANCE(NT_, W_)                                                                              \
@@ -936,6 +977,19 @@ int ddmpc_get_solution(ddmpc_handle* h, int what, double* out, int mem) {
   if (!h->solved) return fail(DDMPC_ERR_NOT_READY, "no solve to read a solution from");
   HIP_TRY(hipSetDevice(h->device));
   const KParams& k = h->kp;
+  if (h->ws_stale && !(h->rescue_ran && h->large_nominal)) {
+    // last solve = a cold solve that skipped the workspace: solve once more at the same past window, keeping beta / active set
+    const size_t B = (size_t)h->batch;
+    int rc;
+    if ((rc = h->d_uopt.ensure(B * h->prm.L * k.m * sizeof(double))) || (rc = h->d_cost.ensure(B * sizeof(double))) ||
+        (rc = h->d_status.ensure(B * sizeof(int32_t))) || (rc = h->d_iters.ensure(B * sizeof(int32_t))))
+      return rc;
+    const bool resc0 = h->rescue_ran;
+    if ((rc = launch_cold(h, h->last_up, h->last_yp, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int32_t*)h->d_status.p,
+                          (int32_t*)h->d_iters.p)))
+      return rc;
+    h->rescue_ran = resc0;         // the rescue kernel's z / flags of the real solve stay valid
+  }
   if (h->beta_stale) {             // last solve = warm step without the workspace: evaluate the affine law once more, keeping beta
     const size_t B = (size_t)h->batch;
     int rc;
@@ -1129,6 +1183,7 @@ int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps
                        (const double*)h->d_pl.p, n_steps, n_mpc_step, dx, dup, dyp, dw, dus, dys, (int*)h->d_stacc.p,
                        (double*)h->d_beta.p, (signed char*)h->d_act.p);
     HIP_TRY(hipGetLastError());
+    h->ws_stale = false;
   }
   const unsigned pblocks = (unsigned)((B + 127) / 128);
   // The per-step paths are loops of two or three small launches per control step.  Optionally
@@ -1213,7 +1268,7 @@ int ddmpc_cost_model(ddmpc_handle* h, double* flops_per_solve, double* bytes_per
   return DDMPC_OK;
 }
 
-const char* ddmpc_kernel_name(ddmpc_handle* h) { return h ? h->kc.name : ""; }
+const char* ddmpc_kernel_name(ddmpc_handle* h) { return h ? (h->v2 ? h->kc.name2 : h->kc.name) : ""; }
 
 int ddmpc_debug_stamps(ddmpc_handle* h, int enable, uint64_t* out) {
   if (!h) return fail(DDMPC_ERR_INVALID, "null handle");

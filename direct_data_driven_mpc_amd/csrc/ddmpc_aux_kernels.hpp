@@ -3,7 +3,7 @@
 // closed loop) and the persistent-excitation guard.  Included by the API translation unit only, so
 // editing it does not rebuild the (slow to compile) cold-solve instantiations.
 #pragma once
-#include "ddmpc_kernels.hpp"
+#include "ddmpc_cold2.hpp"
 
 namespace ddmpc {
 

@@ -1,0 +1,718 @@
+// ddmpc_cold2.hpp -- second-generation cold-solve kernel for gfx950: same mathematics, inputs and outputs as
+// ddmpc_cold_solve_kernel (ddmpc_kernels.hpp), with the factorisation restructured around 16-wide panels:
+//
+//   * tiles are kept K-MAJOR: register j of lane (l4, l15) of tile (I,J), I >= J, holds K[16J + l4 + 4j][16I + l15]
+//     (the transpose of what the first kernel keeps).  In this orientation an accumulator tile is directly the B
+//     operand of a LEFT multiplication, so the triangular solve of a whole tile is 4 MFMAs with no LDS round trip:
+//         U(J,I) = L_JJ^-1 K(J,I)          <-  D = (-M) * T,  M = L_JJ^-1 from LDS, T = the (negated) accumulator tile
+//     and a dumped tile (PB[k][16I + i], k-major) is both the A and the B operand of the trailing update
+//         K(J1,J2) -= U(Jp,J1)' U(Jp,J2)   <-  acc += mfma(PB[.][16 J1 + .], PB[.][16 J2 + .])    (matrix kept negated)
+//   * wave 0 (the "panel wave") owns the main-diagonal tiles.  It factors the 16x16 diagonal tile by itself in four
+//     4-wide sub-steps that never leave the wave (no workgroup barrier): 32 lanes = 16 tile rows + 16 rows of an
+//     identity block that ride along, so the same substitution that produces L_JJ also produces M = L_JJ^-1; the
+//     rank-4 updates inside the tile are 2 MFMAs per sub-step.  The other waves do nothing but MFMAs.
+//   * per 16 columns: 2 workgroup barriers (M ready -> TRSM; panel dumped -> trailing update) instead of 8, and the
+//     redundant per-thread 4x4 factorisations of the first kernel happen on one wave only.
+//   * L y = t rides along as column rE of the matrix; L' beta = y is a VALU sweep over the register tiles
+//     (4 multiply-adds per tile + one 16-lane DPP reduction per tile column and wave) and a 16x16 product with M.
+//   * the beta / active-set workspace is written only when asked for (ddmpc_get_solution re-solves on demand).
+//
+// Reference formulation: direct_data_driven_mpc_controller.py:409-445 (variables), :506-677 (constraints),
+// :679-722 (cost), :780-808 (extraction).  DESIGN.md sections 3-5.
+#pragma once
+#include "ddmpc_kernels.hpp"
+
+namespace ddmpc {
+
+// Tile ownership: the main diagonal goes to wave 0, the other tile diagonals are dealt (longest first, to the least
+// loaded wave) to waves 1..W-1; with a single wave everything is on wave 0.  Whole diagonals stay on one wave so that
+// the structured Gram can walk down a diagonal inside one lane's registers.
+template <int NT, int W>
+struct TileMap2 {
+  struct Tab { int wave[NT]; int base[NT]; int maxs; };
+  static constexpr Tab make() {
+    Tab t{};
+    int load[W] = {};
+    t.wave[0] = 0; t.base[0] = 0; load[0] = NT;
+    for (int d = 1; d < NT; ++d) {
+      int w = (W > 1) ? 1 : 0;
+      for (int i = w + 1; i < W; ++i) if (load[i] < load[w]) w = i;
+      t.wave[d] = w;
+      t.base[d] = load[w];
+      load[w] += NT - d;
+    }
+    t.maxs = 0;
+    for (int i = 0; i < W; ++i) if (load[i] > t.maxs) t.maxs = load[i];
+    return t;
+  }
+  static constexpr Tab tab = make();
+  static constexpr int MAXS = tab.maxs;
+  static constexpr int wave(int I, int J) { return tab.wave[I - J]; }
+  static constexpr int slot(int I, int J) { return tab.base[I - J] + J; }
+  // does wave w own a tile (I, J) with I > J in tile column J?
+  static constexpr bool has_col(int w, int J) {
+    for (int I = J + 1; I < NT; ++I) if (wave(I, J) == w) return true;
+    return false;
+  }
+};
+
+template <int NT, int W, int WAVE>
+struct WaveTiles2 {
+  struct Tab { int I[NT * (NT + 1) / 2]; int J[NT * (NT + 1) / 2]; int n; };
+  static constexpr Tab make() {
+    Tab t{};
+    t.n = 0;
+    for (int J = 0; J < NT; ++J)
+      for (int I = J; I < NT; ++I)
+        if (TileMap2<NT, W>::wave(I, J) == WAVE) { t.I[t.n] = I; t.J[t.n] = J; ++t.n; }
+    return t;
+  }
+  static constexpr Tab tab = make();
+};
+
+// Sum over the 16 lanes of a DPP row (every lane of the row receives the total): four rotate-and-add steps.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_total(double v) {
+  v += dpp_mov_f64<0x128>(v);   // row_ror:8
+  v += dpp_mov_f64<0x124>(v);   // row_ror:4
+  v += dpp_mov_f64<0x122>(v);   // row_ror:2
+  v += dpp_mov_f64<0x121>(v);   // row_ror:1
+  return v;
+}
+
+// LDS carve-up (doubles) of the second kernel.
+template <int NT>
+struct Lds2 {
+  static constexpr int RP = 16 * NT;
+  static constexpr int dvec = 0;
+  static constexpr int tvec = dvec + RP;
+  static constexpr int beta = tvec + RP;
+  static constexpr int part = beta + RP;               // back substitution: [8 waves][16] partial sums
+  static constexpr int red = part + 128;               // 32
+  static constexpr int ints = red + 32;                // int act[RP], int flags[8]
+  static constexpr int pt2 = (ints + (RP + 8 + 1) / 2 + 2) & ~1;   // in-tile panel, row-major: [32 rows][4]
+  static constexpr int LRS = 36;                       // row stride of lt16: 32 rows + 4 (spreads the 4 k-rows of an operand read over the banks)
+  static constexpr int lt16 = pt2 + 128;               // in-tile factor, k-major: [16][LRS]: x < 16 -> L_JJ[x][k], 16 + x' -> M[k][x']
+  static constexpr int RSB = RP + 4;                   // row stride of the panel buffer
+  static constexpr int pb = lt16 + 16 * LRS;           // panel buffer, k-major: PB[k][16 I + i] = U(Jp, I)[k][i]
+  static constexpr int ctab = pb + 16 * RSB;           // lag blocks C[d][a][b], d < RP/4 (structured Gram)
+  static constexpr int xs = ctab + 4 * RP;             // trajectory, channel-interleaved
+  __host__ __device__ static constexpr int total(int xs_len) { return (xs + xs_len + 1) & ~1; }
+};
+
+template <int NT, int W, int WAVE>
+__device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict__ sm,
+                                           const double* __restrict__ up, const double* __restrict__ yp,
+                                           double* __restrict__ u_opt, double* __restrict__ cost_out,
+                                           int* __restrict__ status_out, int* __restrict__ iters_out,
+                                           double* __restrict__ beta_ws, signed char* __restrict__ act_ws,
+                                           unsigned long long* __restrict__ stamps, double* __restrict__ lfac,
+                                           double* __restrict__ lfacT) {
+  using TM = TileMap2<NT, W>;
+  using WT = WaveTiles2<NT, W, WAVE>;
+  using LD = Lds2<NT>;
+  constexpr int RP = 16 * NT;
+  constexpr int NTHR = 64 * W;
+  constexpr int LRS = LD::LRS, RSB = LD::RSB;
+  int nstamp = 1;
+  auto stamp = [&]() __attribute__((always_inline)) {
+    if (stamps != nullptr && WAVE == 0) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (threadIdx.x == 0 && nstamp < 7) stamps[nstamp] = t;
+      ++nstamp;
+    }
+  };
+  double* xs = sm + LD::xs;
+  double* dvec = sm + LD::dvec;
+  double* tvec = sm + LD::tvec;
+  double* beta = sm + LD::beta;
+  double* part = sm + LD::part;
+  double* red = sm + LD::red;
+  double* ctab = sm + LD::ctab;
+  double* PT2 = sm + LD::pt2;
+  double* LT = sm + LD::lt16;
+  double* PB = sm + LD::pb;
+  int* act = reinterpret_cast<int*>(sm + LD::ints);
+  int* flags = act + RP;            // [0] fail, [1] active set changed
+
+  const int tid0 = threadIdx.x;
+  const int r = P.r, rE = P.rE, nch = P.nch;
+  const int NS = rE >> 2;           // 4-wide pivot groups
+  const int IR = rE >> 4;           // tile column holding the rhs column (column index rE)
+  const int rr = rE & 15;
+
+  d4 acc[TM::MAXS];
+
+  constexpr int NE = (RP + NTHR - 1) / NTHR;
+  double cD0[NE], cD1[NE], cT[NE];
+  int cK[NE];
+  static_for<NE>([&](auto e) __attribute__((always_inline)) {
+    const int rho = tid0 + e * NTHR;
+    cD0[e()] = 0.0; cD1[e()] = 0.0; cT[e()] = 0.0; cK[e()] = K_PAD;
+    if (rho < RP) {
+      cD0[e()] = P.tabd[0 * RP + rho];
+      cD1[e()] = P.tabd[1 * RP + rho];
+      cT[e()] = P.tabd[2 * RP + rho];
+      cK[e()] = P.tabi[0 * RP + rho];
+      const int pidx = P.tabi[1 * RP + rho];
+      if (pidx >= 0) cT[e()] = (pidx < P.npu) ? up[pidx] : yp[pidx - P.npu];
+      act[rho] = 0;
+    }
+  });
+  if (tid0 < 8) flags[tid0] = 0;
+
+  int iter = 0;
+  int status = 0;
+  int tid = tid0;
+  long long tphF = 0, tphB = 0, tphT = 0, tphA = 0, tphU = 0;
+  const bool timing = (stamps != nullptr) && (WAVE == 0);
+  auto now = [&]() __attribute__((always_inline)) -> long long { return timing ? (long long)__builtin_amdgcn_s_memtime() : 0; };
+  for (;;) {
+    ++iter;
+    asm volatile("" : "+v"(tid));       // opaque per-iteration thread id (keeps LICM from hoisting every LDS address)
+    const int lane = tid & 63;
+    const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lo = l15 >> 2;
+    static_for<NE>([&](auto e) __attribute__((always_inline)) {
+      const int rho = tid + e * NTHR;
+      if (rho < RP) {
+        const int s_act = act[rho];
+        dvec[rho] = s_act ? cD1[e()] : cD0[e()];
+        tvec[rho] = cT[e()] + s_act * P.bound;
+        beta[rho] = 0.0;
+      }
+    });
+    if (tid == 0) flags[1] = 0;
+    __syncthreads();   // trajectory staged (first pass), tables visible
+    stamp();           // 1
+
+    if (P.gram_dense) {
+      // ---- G = H H' by fp64 MFMA over the implicit Hankel operand (k-major: rows of tile column J are the A operand)
+      static_for<TM::MAXS>([&](auto S) __attribute__((always_inline)) { acc[S] = d4{0.0, 0.0, 0.0, 0.0}; });
+      const int c = P.c;
+      const int cfull = c & ~3;
+      const double* xp = xs + l4 * nch + l15;
+      for (int i0 = 0; i0 < cfull; i0 += 4) {
+        double op[NT];
+        static_for<NT>([&](auto I) __attribute__((always_inline)) { op[I] = xp[16 * I]; });
+        xp += 4 * nch;
+        static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
+          constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
+          acc[TM::slot(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[J], op[I], acc[TM::slot(I, J)], 0, 0, 0);
+        });
+      }
+      if (cfull < c) {
+        const bool kok = (cfull + l4) < c;
+        double op[NT];
+        static_for<NT>([&](auto I) __attribute__((always_inline)) { const double v = xp[16 * I]; op[I] = kok ? v : 0.0; });
+        static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
+          constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
+          acc[TM::slot(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[J], op[I], acc[TM::slot(I, J)], 0, 0, 0);
+        });
+      }
+      stamp();   // 2
+      stamp();   // 3
+    } else {
+      // ---- structured Gram (nch == 4): lag blocks by v_mfma_f64_4x4x4, then 2 MFMAs per tile down every tile diagonal
+      //      (the Hankel sliding-window recurrence in matrix form, see ddmpc_kernels.hpp) -- k-major tiles.
+      const int c = P.c, Ln = P.Ln;
+      {
+        constexpr int MAXG = (NT + W - 1) / W;             // lag groups per wave
+        const int ngroups = (Ln + 3) >> 2;
+        const int kq = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
+        if (iter == 1 && WAVE * MAXG < ngroups) {
+          double cacc[MAXG];
+          static_for<MAXG>([&](auto gi) __attribute__((always_inline)) { cacc[gi()] = 0.0; });
+          const double* pB = xs + 4 * kq + ij;                                   // B[k][j] = x_j[t0 + k]
+          const double* pA = xs + 4 * (kq + blk) + ij + 16 * (WAVE * MAXG);      // A[i][k] = x_i[t0 + k + 4g + blk]
+          const int cfull = c & ~3;
+          int t0 = 0;
+          for (; t0 + 16 <= cfull; t0 += 16) {
+            double bv[4], av[MAXG + 3];
+            static_for<4>([&](auto u) __attribute__((always_inline)) { bv[u()] = pB[16 * u]; });
+            static_for<MAXG + 3>([&](auto q) __attribute__((always_inline)) { av[q()] = pA[16 * q]; });
+            static_for<4>([&](auto u) __attribute__((always_inline)) {
+              static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
+                cacc[gi()] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[gi() + u()], bv[u()], cacc[gi()], 0, 0, 0);
+              });
+            });
+            pA += 64; pB += 64;
+          }
+          for (; t0 < cfull; t0 += 4) {
+            const double bv = pB[0];
+            static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
+              cacc[gi()] = __builtin_amdgcn_mfma_f64_4x4x4f64(pA[16 * gi], bv, cacc[gi()], 0, 0, 0);
+            });
+            pA += 16; pB += 16;
+          }
+          if (cfull < c) {
+            const bool kok = (cfull + kq) < c;
+            const double bv = kok ? pB[0] : 0.0;
+            static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
+              const double a1 = pA[16 * gi];
+              cacc[gi()] = __builtin_amdgcn_mfma_f64_4x4x4f64(kok ? a1 : 0.0, bv, cacc[gi()], 0, 0, 0);
+            });
+          }
+          static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
+            constexpr int g = WAVE * MAXG + gi;
+            const int d = 4 * g + blk;                     // D layout: i = lane>>4, j = lane&3
+            if (g < ngroups && d < Ln) ctab[d * 16 + kq * 4 + ij] = cacc[gi()];
+          });
+        }
+      }
+      __syncthreads();
+      stamp();   // 2
+      static_for<TM::MAXS>([&](auto S) __attribute__((always_inline)) { acc[S] = d4{0.0, 0.0, 0.0, 0.0}; });
+      // (2) first tile of every owned tile diagonal from the lag blocks.  Register j of lane (l4, l15 = 4 lo + l3) of
+      //     tile (d, 0) is K[(time j, channel l4)][(time 4d + lo, channel l3)] = G(t1, t2)(a, b) with
+      //       G(l + del, l)(a, b) = C_del(a, b) + sum_{q<l} ( x_a[q+c+del] x_b[q+c] - x_a[q+del] x_b[q] ),
+      //     the later time index taking the role of "l + del" (the matrix is symmetric).  Diagonal tiles are filled
+      //     on both sides of their diagonal.
+      {
+#pragma nounroll
+        for (int d = 0; d < NT; ++d) {                     // runtime loop (an unrolled one gets hoisted into spills)
+          bool mine = false;
+          static_for<NT>([&](auto DD) __attribute__((always_inline)) {
+            if constexpr (TM::tab.wave[DD] == WAVE) mine = mine || (d == DD);
+          });
+          if (!mine) continue;
+          auto base = [&](int j) __attribute__((always_inline)) -> double {
+            int del = 4 * d + lo - j;
+            const bool neg = del < 0;
+            del = neg ? -del : del;
+            del = del >= Ln ? Ln - 1 : del;                // padded rows: cleared in the fix-up
+            const int pa = neg ? l4 : l3, pb = neg ? l3 : l4;
+            const int nl = neg ? lo : j;                   // window terms: the earlier of the two time indices
+            const double* qa0 = xs + 4 * del + pa;         // x_pa[del + .]
+            const double* qa1 = qa0 + 4 * c;
+            const double* qb0 = xs + pb;
+            const double* qb1 = qb0 + 4 * c;
+            double t = ctab[del * 16 + pa * 4 + pb];
+            const double e0 = qa1[0] * qb1[0] - qa0[0] * qb0[0];
+            const double e1 = qa1[4] * qb1[4] - qa0[4] * qb0[4];
+            const double e2 = qa1[8] * qb1[8] - qa0[8] * qb0[8];
+            t += (0 < nl) ? e0 : 0.0;
+            t += (1 < nl) ? e1 : 0.0;
+            t += (2 < nl) ? e2 : 0.0;
+            return t;
+          };
+          const d4 v = d4{base(0), base(1), base(2), base(3)};
+          static_for<NT>([&](auto DD) __attribute__((always_inline)) {
+            if constexpr (TM::tab.wave[DD] == WAVE) { if (d == DD) acc[TM::slot(DD, 0)] = v; }
+          });
+        }
+      }
+      // (3) walk down the diagonals: tile(I+1,J+1) = tile(I,J) - (first 4 Hankel columns) + (columns c..c+3)
+      static_for<NT>([&](auto DD) __attribute__((always_inline)) {
+        constexpr int d = DD;
+        if constexpr (TM::tab.wave[d] == WAVE && d + 1 < NT) {
+          const double* pb = xs + 4 * l4 + l15;          // rows of tile column J = t: the A operand (k side)
+          const double* pa = pb + 16 * d;                // rows of tile row I = d + t: the B operand (i side)
+#pragma nounroll
+          for (int t = 0; t + 1 < NT - d; ++t) {
+            const double a1 = pa[0], b1 = pb[0], a2 = pa[4 * c], b2 = pb[4 * c];
+            static_for<NT - d - 1>([&](auto T) __attribute__((always_inline)) {
+              if (t == T) {
+                const d4 v = __builtin_amdgcn_mfma_f64_16x16x4f64(-b1, a1, acc[TM::slot(d + T, T)], 0, 0, 0);
+                acc[TM::slot(d + T + 1, T + 1)] = __builtin_amdgcn_mfma_f64_16x16x4f64(b2, a2, v, 0, 0, 0);
+              }
+            });
+            pa += 16; pb += 16;
+          }
+        }
+      });
+      stamp();   // 3
+    }
+
+    // ---- accumulators := -(G + lam*D); -identity on dummy rows; rhs COLUMN rE := -t (mirrored into the diagonal tile)
+    static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
+      constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
+      constexpr int S = TM::slot(I, J);
+      const int gc = 16 * I + l15;                        // global column (i side)
+      d4 v = -acc[S];
+      if constexpr (I == J) {
+        static_for<4>([&](auto j) __attribute__((always_inline)) {
+          const int gr = 16 * J + l4 + 4 * j;
+          if (gr == gc && gr < r) v[j()] -= P.lam * dvec[gr];
+        });
+      }
+      if (16 * I + 15 >= r) {                             // wave-uniform: tile columns that touch the padding / rhs column
+        static_for<4>([&](auto j) __attribute__((always_inline)) {
+          const int gr = 16 * J + l4 + 4 * j;
+          if (gr >= r || gc >= r) v[j()] = 0.0;
+          if (I == J && gr == gc && gr >= r && gr < rE) v[j()] = -1.0;
+          if (gc == rE && gr < r) v[j()] = -tvec[gr];
+          if (I == J && gr == rE && gc < r) v[j()] = -tvec[gc];
+        });
+      }
+      acc[S] = v;
+    });
+    if (P.dense_w) {      // dense weighting matrices: lam * W^-1 is a full symmetric matrix shared by the batch (L2)
+      static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
+        constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
+        constexpr int S = TM::slot(I, J);
+        const double* dm = P.dmat + (long long)(16 * J + l4) * RP + 16 * I + l15;
+        static_for<4>([&](auto j) __attribute__((always_inline)) { acc[S][j()] -= P.lam * dm[4 * j() * RP]; });
+      });
+    }
+    __syncthreads();      // every wave has read tvec (targets) for its rhs entries; LT / PT2 / PB are free
+
+    // ---- blocked Cholesky, 16-wide panels --------------------------------------------------------------------
+    static_for<NT>([&](auto JB) __attribute__((always_inline)) {
+      constexpr int Jb = JB;
+      const int nq = (NS - 4 * Jb) < 4 ? (NS - 4 * Jb) : 4;         // pivot groups in this tile column (<= 0: none)
+      if (nq > 0) {                                                   // workgroup-uniform
+        const bool more = 16 * (Jb + 1) < rE + 1;                     // live columns to the right of this panel
+        const long long t0 = now();
+        // (F) panel wave: factor the diagonal tile, L_JJ and M = L_JJ^-1 -> LT
+        if constexpr (WAVE == 0) {
+          constexpr int SD = TM::slot(Jb, Jb);
+          d4 Ad = acc[SD];
+          d4 Et;
+          static_for<4>([&](auto j) __attribute__((always_inline)) { Et[j()] = (l4 + 4 * j() == l15) ? -1.0 : 0.0; });
+          const int x = lane & 31;                                    // lanes 32..63 mirror lanes 0..31 (reads only)
+          if (lo == 0) {
+            static_for<4>([&](auto j) __attribute__((always_inline)) {
+              PT2[(l4 + 4 * j) * 4 + l3] = Ad[j()];
+              PT2[(16 + l4 + 4 * j) * 4 + l3] = Et[j()];
+            });
+          }
+          bool okall = true;
+#pragma nounroll
+          for (int q = 0; q < nq; ++q) {
+            const int c0 = 4 * q;
+            const double* Pd = PT2 + c0 * 4;                          // rows c0..c0+3 of the tile, 4 panel entries each
+            const double p00 = -Pd[0];
+            const double p10 = -Pd[4], p11 = -Pd[5];
+            const double p20 = -Pd[8], p21 = -Pd[9], p22 = -Pd[10];
+            const double p30 = -Pd[12], p31 = -Pd[13], p32 = -Pd[14], p33 = -Pd[15];
+            const double r0 = PT2[x * 4 + 0], r1 = PT2[x * 4 + 1], r2 = PT2[x * 4 + 2], r3 = PT2[x * 4 + 3];
+            const double d0 = p00;
+            const double i0 = rsq_nr(d0);
+            const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
+            const double d1 = p11 - l10 * l10;
+            const double i1 = rsq_nr(d1);
+            const double l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
+            const double d2v = p22 - l20 * l20 - l21 * l21;
+            const double i2 = rsq_nr(d2v);
+            const double l32 = (p32 - l30 * l20 - l31 * l21) * i2;
+            const double d3 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
+            const double i3 = rsq_nr(d3);
+            okall = okall && (d0 > 0.0) && (d1 > 0.0) && (d2v > 0.0) && (d3 > 0.0) &&
+                    (i0 < 1e150) && (i1 < 1e150) && (i2 < 1e150) && (i3 < 1e150);
+            // forward substitution of this lane's row (the panel holds negated entries).  Tile rows above the pivot
+            // group are finished (zero here); inside the group the strictly upper part is zero; the identity rows
+            // (x >= 16) yield the columns of M.
+            double x0 = -r0 * i0;
+            double x1 = -(r1 + x0 * l10) * i1;
+            double x2 = -(r2 + x0 * l20 + x1 * l21) * i2;
+            double x3 = -(r3 + x0 * l30 + x1 * l31 + x2 * l32) * i3;
+            const int ii = (x < 16) ? (x - c0) : 4;
+            x0 = (ii < 0) ? 0.0 : x0;
+            x1 = (ii < 1) ? 0.0 : x1;
+            x2 = (ii < 2) ? 0.0 : x2;
+            x3 = (ii < 3) ? 0.0 : x3;
+            if (lane < 32) {
+              LT[(c0 + 0) * LRS + x] = x0; LT[(c0 + 1) * LRS + x] = x1;
+              LT[(c0 + 2) * LRS + x] = x2; LT[(c0 + 3) * LRS + x] = x3;
+            }
+            // rank-4 update inside the tile (negated matrix: plain accumulate) and the next panel's columns
+            const double opA = LT[(c0 + l4) * LRS + l15];
+            const double opE = LT[(c0 + l4) * LRS + 16 + l15];
+            Ad = __builtin_amdgcn_mfma_f64_16x16x4f64(opA, opA, Ad, 0, 0, 0);
+            Et = __builtin_amdgcn_mfma_f64_16x16x4f64(opE, opA, Et, 0, 0, 0);
+            if (q + 1 < nq && lo == q + 1) {
+              static_for<4>([&](auto j) __attribute__((always_inline)) {
+                PT2[(l4 + 4 * j) * 4 + l3] = Ad[j()];
+                PT2[(16 + l4 + 4 * j) * 4 + l3] = Et[j()];
+              });
+            }
+          }
+          if (lane == 0 && !okall) flags[0] = 1;
+          // M (lower triangular) replaces the diagonal tile: register j of lane (l4, l15) = M[l4 + 4j][l15]
+          static_for<4>([&](auto j) __attribute__((always_inline)) {
+            const int k = l4 + 4 * j();
+            const double mv = LT[k * LRS + 16 + l15];
+            acc[SD][j()] = (k < 4 * nq) ? mv : 0.0;
+          });
+          if (Jb == IR) {                                             // y of the last tile column = the substituted rhs row
+            if (lane < 4 * nq) tvec[16 * Jb + lane] = LT[lane * LRS + rr];
+          }
+          if (lfac != nullptr) {                                      // ddmpc_prepare: L_JJ row-major and its transpose
+            static_for<4>([&](auto e) __attribute__((always_inline)) {
+              const int idx = lane + 64 * e(), xr = idx >> 4, kc = idx & 15;
+              double v = (kc <= xr && kc < 4 * nq) ? LT[kc * LRS + xr] : 0.0;
+              if (xr == kc && kc >= 4 * nq) v = 1.0;
+              lfac[(Jb * (Jb + 1) / 2 + Jb) * 256 + idx] = v;
+              lfacT[(Jb * (Jb + 1) / 2 + Jb) * 256 + kc * 16 + xr] = v;
+            });
+          }
+        }
+        const long long t1 = now();
+        __syncthreads();                                              // (B) M is in LT
+        const long long t2 = now();
+        if (more) {
+          // (T) U(Jb, I) = M * K(Jb, I) for the tiles right of the diagonal: 4 MFMAs per tile, then the tile goes to PB
+          double am[4];
+          static_for<4>([&](auto ks) __attribute__((always_inline)) { am[ks()] = -LT[l15 * LRS + 16 + 4 * ks() + l4]; });
+          static_for<NT>([&](auto I) __attribute__((always_inline)) {
+            if constexpr (I > Jb && TM::wave(I, Jb) == WAVE) {
+              if (16 * I < rE + 1) {
+                constexpr int S = TM::slot(I, Jb);
+                const d4 T = acc[S];
+                d4 dd = d4{0.0, 0.0, 0.0, 0.0};
+                dd = __builtin_amdgcn_mfma_f64_16x16x4f64(am[0], T[0], dd, 0, 0, 0);
+                dd = __builtin_amdgcn_mfma_f64_16x16x4f64(am[1], T[1], dd, 0, 0, 0);
+                dd = __builtin_amdgcn_mfma_f64_16x16x4f64(am[2], T[2], dd, 0, 0, 0);
+                dd = __builtin_amdgcn_mfma_f64_16x16x4f64(am[3], T[3], dd, 0, 0, 0);
+                acc[S] = dd;
+                static_for<4>([&](auto j) __attribute__((always_inline)) {
+                  PB[(l4 + 4 * j) * RSB + 16 * I + l15] = dd[j()];
+                });
+              }
+            }
+          });
+        }
+        const long long t3 = now();
+        __syncthreads();                                              // (A) the panel is in PB
+        const long long t4 = now();
+        if (more) {
+          // (U) trailing update K(J, I) += U(Jb, J)' U(Jb, I) (negated matrix), 4 k-steps of 4; the panel wave does
+          //     the next diagonal tile first
+          if constexpr (WAVE == 0 && Jb + 1 < NT) {
+            constexpr int S = TM::slot(Jb + 1, Jb + 1);
+            static_for<4>([&](auto ks) __attribute__((always_inline)) {
+              const double o = PB[(4 * ks() + l4) * RSB + 16 * (Jb + 1) + l15];
+              acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(o, o, acc[S], 0, 0, 0);
+            });
+          }
+          static_for<4>([&](auto ks) __attribute__((always_inline)) {
+            double op[NT];
+            static_for<NT>([&](auto X) __attribute__((always_inline)) {
+              if constexpr (X > Jb) op[X] = PB[(4 * ks() + l4) * RSB + 16 * X + l15];
+            });
+            static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
+              constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
+              if constexpr (J > Jb && !(WAVE == 0 && I == Jb + 1 && J == Jb + 1)) {
+                if (16 * I < rE + 1) {
+                  constexpr int S = TM::slot(I, J);
+                  acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[J], op[I], acc[S], 0, 0, 0);
+                }
+              }
+            });
+          });
+        }
+        const long long t5 = now();
+        tphF += t1 - t0; tphB += t2 - t1; tphT += t3 - t2; tphA += t4 - t3; tphU += t5 - t4;
+      }
+    });
+    if (timing && threadIdx.x == 0) { stamps[7] = tphF; stamps[8] = tphB; stamps[9] = tphT; stamps[10] = tphA; stamps[11] = tphU; }
+    stamp();   // 4
+
+    // ---- optional export of the factor (ddmpc_prepare): lower tiles L(I,J), row-major 16x16 each, at
+    //      lfac[(I(I+1)/2 + J) * 256]; lfacT holds the transposed tiles (what the accumulators hold as they are)
+    if (lfac != nullptr) {
+      static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
+        constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
+        if constexpr (I > J) {
+          constexpr int S = TM::slot(I, J);
+          static_for<4>([&](auto j) __attribute__((always_inline)) {
+            lfacT[(I * (I + 1) / 2 + J) * 256 + (l4 + 4 * j) * 16 + l15] = acc[S][j()];
+            lfac[(I * (I + 1) / 2 + J) * 256 + l15 * 16 + l4 + 4 * j] = acc[S][j()];
+          });
+        }
+      });
+    }
+
+    // ---- y = L^-1 t: column rr of the tiles in tile row IR (the last tile column wrote its part above) ----------
+    static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
+      constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
+      if constexpr (I > J) {
+        if (I == IR && l15 == rr) {
+          constexpr int S = TM::slot(I, J);
+          static_for<4>([&](auto j) __attribute__((always_inline)) { tvec[16 * J + l4 + 4 * j] = acc[S][j()]; });
+        }
+      }
+    });
+    __syncthreads();
+    // ---- back substitution U beta = y, one tile column per round, right to left:
+    //   (1) every wave: s[k] = sum over its tiles (I > J) of U(J,I)[k][.] beta_I  (4 multiply-adds per tile, then one
+    //       16-lane reduction per register) -> part[wave][k]
+    //   (2) panel wave: beta_J = M_J' (y_J - sum of the parts)
+    static_for<NT>([&](auto JREV) __attribute__((always_inline)) {
+      constexpr int J = NT - 1 - JREV;
+      if (16 * J < rE) {                                              // workgroup-uniform
+        if constexpr (TM::has_col(WAVE, J)) {
+          d4 s = d4{0.0, 0.0, 0.0, 0.0};
+          static_for<NT>([&](auto I) __attribute__((always_inline)) {
+            if constexpr (I > J && TM::wave(I, J) == WAVE) {
+              if (16 * I < rE) {
+                constexpr int S = TM::slot(I, J);
+                const double b = beta[16 * I + l15];
+                static_for<4>([&](auto j) __attribute__((always_inline)) { s[j()] = fma(acc[S][j()], b, s[j()]); });
+              }
+            }
+          });
+          static_for<4>([&](auto j) __attribute__((always_inline)) { s[j()] = row16_total(s[j()]); });
+          if (l15 == 0) {
+            static_for<4>([&](auto j) __attribute__((always_inline)) { part[WAVE * 16 + l4 + 4 * j] = s[j()]; });
+          }
+        }
+        __syncthreads();
+        if constexpr (WAVE == 0) {
+          constexpr int SD = TM::slot(J, J);
+          double pi = 0.0;
+          static_for<4>([&](auto j) __attribute__((always_inline)) {
+            const int k = l4 + 4 * j();
+            double v = tvec[16 * J + k];
+            static_for<W>([&](auto w) __attribute__((always_inline)) {
+              if constexpr (TM::has_col(w, J)) v -= part[w * 16 + k];
+            });
+            pi = fma(acc[SD][j()], v, pi);
+          });
+          pi += __shfl_xor(pi, 16, 64);
+          pi += __shfl_xor(pi, 32, 64);
+          if (l4 == 0) beta[16 * J + l15] = (16 * J + l15 < rE) ? pi : 0.0;
+        }
+        __syncthreads();
+      }
+    });
+    stamp();   // 5
+    stamp();   // 6
+
+    // ---- slack box: primal-dual active-set update --------------------------------
+    bool again = false;
+    if (P.convex) {
+      const double scale = -P.lam / P.lamb_sigma;
+      static_for<NE>([&](auto e) __attribute__((always_inline)) {
+        const int rho = tid + e * NTHR;
+        if (rho < r && (cK[e()] == K_WPRED || cK[e()] == K_WTERM)) {   // sigma[n*p:], controller.py:659
+          const double sh = scale * beta[rho];
+          const int ns = (sh > P.bound) ? 1 : (sh < -P.bound) ? -1 : 0;
+          if (ns != act[rho]) { act[rho] = ns; flags[1] = 1; }
+        }
+      });
+      __syncthreads();
+      again = (flags[1] != 0) && (flags[0] == 0);
+      if (again && iter >= P.max_iter) { again = false; status = 4; }
+    }
+    if (!again) break;
+  }
+  if (flags[0] != 0) status = 4;
+  const int lane = tid & 63;
+
+  // ---- outputs: z = t - lam*D*beta; cost = control cost + lam*beta'z + lamb_sigma*|sigma|^2 ----------------------
+  double partc = 0.0;
+  bool finite = true;
+  static_for<NE>([&](auto e) __attribute__((always_inline)) {
+    const int rho = tid + e * NTHR;
+    if (rho < r) {
+      const int s_act = act[rho];
+      const double b = beta[rho];
+      const double D = s_act ? cD1[e()] : cD0[e()];
+      const double t = cT[e()] + s_act * P.bound;
+      double z = t - P.lam * D * b;
+      if (P.dense_w) {                              // z = t - lam (W^-1 beta): one row of the dense matrix
+        const double* dr = P.dmat + (long long)rho * RP;
+        double sdb = 0.0;
+        for (int j = 0; j < r; ++j) sdb += dr[j] * beta[j];
+        z = t - P.lam * (D * b + sdb);
+      }
+      const double wq = P.tabd[3 * RP + rho];
+      const double tb = P.tabd[2 * RP + rho];
+      const int oidx = P.tabi[2 * RP + rho];
+      finite = finite && (fabs(b) < 1e300);
+      double contrib = P.lam * b * z;
+      const int kind = cK[e()];
+      if (P.dense_w && (kind == K_UFREE || kind == K_YFREE || kind == K_WPRED)) {
+        contrib -= P.lam * b * (z - tb);
+      } else
+      if (kind == K_UFREE || kind == K_YFREE) { const double dlt = z - tb; contrib += wq * dlt * dlt; }
+      else if (kind == K_WINT) { const double sg = z - cT[e()]; contrib += P.lamb_sigma * sg * sg; }
+      else if (kind == K_WTERM) { const double sg = z - tb; contrib += P.lamb_sigma * sg * sg; }
+      else if (kind == K_WPRED) {
+        const double sg = (s_act != 0) ? s_act * P.bound : -P.lam * b / P.lamb_sigma;
+        const double dlt = z - sg - tb;
+        contrib += wq * dlt * dlt + P.lamb_sigma * sg * sg;
+      }
+      partc += contrib;
+      if (oidx >= 0) u_opt[oidx] = z;               // ubar[n*m:], controller.py:799-805
+      if (beta_ws) beta_ws[rho] = b;
+      if (act_ws) act_ws[rho] = (signed char)s_act;
+    }
+  });
+  partc = wave_sum(partc);
+  const unsigned long long okmask = __ballot(finite);
+  if (lane == 0) { red[tid >> 6] = partc; red[16 + (tid >> 6)] = (okmask == ~0ull) ? 0.0 : 1.0; }
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0, bad = 0.0;
+    for (int w = 0; w < W; ++w) { tot += red[w]; bad += red[16 + w]; }
+    if (bad != 0.0 || !(fabs(tot) < 1e300)) status = 4;
+    *cost_out = tot;
+    *status_out = status;
+    if (iters_out) *iters_out = iter;
+    if (stamps) { stamps[14] = __builtin_amdgcn_s_memtime(); stamps[13] = __builtin_amdgcn_s_memrealtime(); }
+  }
+}
+
+template <int NT, int W>
+__global__ __launch_bounds__(64 * W, DDMPC_MIN_WAVES(NT, W)) void ddmpc_cold_solve_kernel2(
+    KParams P, const double* __restrict__ u_d, const double* __restrict__ y_d,
+    const double* __restrict__ u_past, const double* __restrict__ y_past, double* __restrict__ u_opt,
+    double* __restrict__ cost, int* __restrict__ status, int* __restrict__ iters,
+    double* __restrict__ beta_ws, signed char* __restrict__ act_ws, unsigned long long* __restrict__ stamps,
+    double* __restrict__ lfac, double* __restrict__ lfacT, const int* __restrict__ only) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const long long b = blockIdx.x;
+  if (only != nullptr && only[b] == 0) return;
+  const int tid = threadIdx.x;
+  constexpr int NTHR = 64 * W;
+  unsigned long long* st = stamps ? stamps + b * 16 : nullptr;
+  if (st && tid == 0) { st[0] = __builtin_amdgcn_s_memtime(); st[15] = __builtin_amdgcn_s_memrealtime(); }
+  double* xs = sm + Lds2<NT>::xs;
+  {
+    const double* ud = u_d + b * (long long)P.N * P.m;
+    const double* yd = y_d + b * (long long)P.N * P.p;
+    if (P.m == 2 && P.p == 2) {              // 16-byte loads, one time step per lane
+      const d2* u2 = reinterpret_cast<const d2*>(ud);
+      const d2* y2 = reinterpret_cast<const d2*>(yd);
+      d2* x2 = reinterpret_cast<d2*>(xs);
+      for (int t = tid; t < P.N; t += NTHR) {
+        const d2 uu = u2[t], yy = y2[t];
+        x2[2 * t] = uu;
+        x2[2 * t + 1] = yy;
+      }
+    } else {
+      const int nu = P.N * P.m, ny = P.N * P.p;
+      for (int i = tid; i < nu; i += NTHR) {
+        const int t = i / P.m, ch = i - t * P.m;
+        xs[t * P.nch + ch] = ud[i];
+      }
+      for (int i = tid; i < ny; i += NTHR) {
+        const int t = i / P.p, ch = i - t * P.p;
+        xs[t * P.nch + P.m + ch] = yd[i];
+      }
+    }
+    for (int i = P.N * P.nch + tid; i < P.xs_len; i += NTHR) xs[i] = 0.0;
+  }
+  const int n = P.npu / P.m;
+  const double* up = u_past + b * (long long)P.npu;
+  const double* yp = y_past + b * (long long)(n * P.p);
+  double* uo = u_opt + b * (long long)((P.Ln - n) * P.m);
+  double* bw = beta_ws ? beta_ws + b * (long long)P.rE : nullptr;
+  signed char* aw = act_ws ? act_ws + b * (long long)P.rE : nullptr;
+  int* it = iters ? iters + b : nullptr;
+  double* lf = lfac ? lfac + b * (long long)(NT * (NT + 1) / 2 * 256) : nullptr;
+  double* lft = lfacT ? lfacT + b * (long long)(NT * (NT + 1) / 2 * 256) : nullptr;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  static_for<W>([&](auto WV) {
+    if (wave == WV) wave_body2<NT, W, WV>(P, sm, up, yp, uo, cost + b, status + b, it, bw, aw, st, lf, lft);
+  });
+}
+
+}  // namespace ddmpc

@@ -4,6 +4,13 @@ import sys
 import numpy as np
 import pytest
 
+try:
+    # torch ships its own HIP runtime; when tests hand torch device tensors to the engine, torch's copy has to be the
+    # first one in the process (loading libddmpc.so first leaves torch with "No HIP GPUs are available")
+    import torch  # noqa: F401
+except Exception:           # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -108,12 +108,11 @@ def test_example_scripts_equal_reference_runs(gpu, loops, tmp_path):
         for key, tag in (("TEC_1-step", "tec"), ("TEC_n-step", "tec_nstep"), ("UCON_1-step", "ucon")):
             u_ref, y_ref = loops["rep_s%d_%s_u" % (inst, tag)], loops["rep_s%d_%s_y" % (inst, tag)]
             assert z[key + "_u"].shape[1:] == u_ref.shape == (597, 2)
-            if tag == "ucon":                       # UCON diverges (the paper's point): compare while the loop is still tame
-                k = int(np.argmax(np.max(np.abs(u_ref), axis=1) > 5.0)) or u_ref.shape[0]
-            else:
-                k = u_ref.shape[0]
-            assert np.max(np.abs(z[key + "_u"][inst, :k] - u_ref[:k])) / np.max(np.abs(u_ref[:k])) < 1e-6, (inst, tag)
-            assert np.max(np.abs(z[key + "_y"][inst, :k] - y_ref[:k])) < 1e-7, (inst, tag)
+            # UCON diverges (the paper's point; |u| reaches 1e3 and more): errors are measured against the size the
+            # trajectory has reached at that step
+            scale = np.maximum(1.0, np.maximum.accumulate(np.max(np.abs(np.hstack([u_ref, y_ref])), axis=1)))[:, None]
+            assert np.max(np.abs(z[key + "_u"][inst] - u_ref) / scale) < 1e-7, (inst, tag)
+            assert np.max(np.abs(z[key + "_y"][inst] - y_ref) / scale) < 1e-8, (inst, tag)
 
 
 # ------------------------------------------------------------------ cfg 3: one rank's shard of 262,144
@@ -228,8 +227,7 @@ def test_variables_after_a_rescued_nominal_solve(gpu):
     assert np.all(np.isnan(al))
     for b in range(B):
         ref = solve_nominal_exact(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
-        if "ybar" in ref:
-            assert np.max(np.abs(yb[b] - np.asarray(ref["ybar"]).ravel())) < 1e-7
+        assert np.max(np.abs(ub[b, n * m:] - ref["optimal_u"])) / np.max(np.abs(ref["optimal_u"])) < 1e-8
     # a noisy (full-rank) nominal batch right afterwards on the same handle: fast path, alpha is real again
     dn = harness.generate_batch(range(B))
     with _spec_engine(orc.spec_from_params(controller_type=0), 400, B) as eng:
