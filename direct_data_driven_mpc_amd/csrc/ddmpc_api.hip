@@ -417,6 +417,7 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   k.lamb_sigma = robust_ ? p.lamb_sigma : 1.0;
   k.bound = k.convex ? p.c * p.eps_max : 0.0;
   k.max_iter = p.max_iter > 0 ? p.max_iter : 50;
+  k.dev = getenv("DDMPC_DEV") ? atoi(getenv("DDMPC_DEV")) : 0;
   if (p.gram_mode == DDMPC_GRAM_STRUCTURED && k.nch != 4) {
     delete h;
     return fail(DDMPC_ERR_UNSUPPORTED, "DDMPC_GRAM_STRUCTURED needs m + p == 4 (got %d); use DDMPC_GRAM_AUTO", k.nch);

@@ -85,6 +85,23 @@ __device__ __forceinline__ double row16_total(double v) {
   return v;
 }
 
+// v_permlane16_swap on a pair of doubles: result[0] = rows [a.r0, b.r0, a.r2, b.r2], result[1] = rows [a.r1, b.r1, a.r3, b.r3]
+// (a.rN = the 16 lanes of DPP row N of a; probed on gfx950: tools/permlane_probe.hip).
+__device__ __forceinline__ d2 permlane16_swap_f64(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return d2{__hiloint2double((int)hi[0], (int)lo[0]), __hiloint2double((int)hi[1], (int)lo[1])};
+}
+
+// 1/sqrt(x) for the pivots of the in-tile factorisation: hardware seed (v_rsq_f64, ~2^-26) + ONE Newton step
+// y0 (1 + e/2), e = 1 - x y0^2: relative error 3/8 e^2 ~ 1e-16, two dependent operations shorter than the third-order
+// rsq_nr of the first kernel; the pivots sit on the workgroup's critical path.
+__device__ __forceinline__ double rsq_n2(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y0, y0, 1.0);
+  return fma(0.5 * y0, e, y0);
+}
+
 // LDS carve-up (doubles) of the second kernel.
 template <int NT>
 struct Lds2 {
@@ -166,6 +183,9 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
   });
   if (tid0 < 8) flags[tid0] = 0;
 
+  // the panel wave's dependency chain (in-tile factorisation) is the critical path of the workgroup: its instructions
+  // win the SIMD's issue arbitration against the MFMA waves of the co-resident workgroups
+  // (measured: raising the panel wave's priority with s_setprio costs 3 %: it starves the MFMA waves of the co-resident workgroups)
   int iter = 0;
   int status = 0;
   int tid = tid0;
@@ -361,135 +381,211 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
     }
     __syncthreads();      // every wave has read tvec (targets) for its rhs entries; LT / PT2 / PB are free
 
-    // ---- blocked Cholesky, 16-wide panels --------------------------------------------------------------------
+    // ---- blocked Cholesky, 16-wide panels, software-pipelined over the tile columns --------------------------------
+    // Step Jb (M_Jb = L_JJ^-1 of tile column Jb is in LT):
+    //   (T1) the owner of tile (Jb+1, Jb) solves it (4 MFMAs) and dumps it to PB            -- barrier A1
+    //   panel wave: updates diagonal tile Jb+1 from that dump and starts factoring it (sub-step 0)
+    //   other waves: (T2) solve + dump their other tiles of tile row Jb                       -- barrier A2
+    //   other waves: (U) trailing update of their tiles; panel wave: sub-steps 1..3 of the factorisation, with the
+    //   trailing updates of the diagonal tiles Jb+2.. slipped into its instruction stream      -- barrier B: M_{Jb+1} in LT
+    // so the factorisation chain of the next diagonal tile runs beside the TRSM / trailing update of the current one.
+    //
+    // In-tile factorisation (panel wave, no workgroup barrier inside except A2): four 4-wide sub-steps.  Lane x < 16 owns
+    // tile row x, lane 16 + x' row x' of a (negated) identity block that rides along: the same substitution that yields
+    // the rows of L_JJ yields the columns of M = L_JJ^-1.  Every lane factors the 4x4 pivot block redundantly
+    // (v_rsq_f64 + one third-order correction per pivot), substitutes its row, the rows go to LT (k-major); the rank-4
+    // update inside the two tiles is one MFMA each, and the next panel's columns go back out to PT2.  A non-positive
+    // pivot yields NaN, which reaches beta and is reported through the finite check of the output stage.  Rows above /
+    // inside the pivot group carry don't-care values in LT (they only touch finished entries); the export masks them.
+    // `pend(h)`, h = 0..11: hooks at which the caller slips independent MFMAs (trailing updates of later diagonal tiles)
+    // into the dependency chain of the sub-step; pinned with sched_barrier so that they run beside the chain's VALU
+    // work and LDS waits instead of in front of it.
+    auto substep = [&](d4& Ad, d4& Et, auto QQ, int nq, auto&& pend) __attribute__((always_inline)) {
+      constexpr int q = QQ;
+      constexpr int c0 = 4 * q;
+#define DDMPC_HOOK(h) do { __builtin_amdgcn_sched_barrier(0); pend(std::integral_constant<int, h>{}); __builtin_amdgcn_sched_barrier(0); } while (0)
+      const int x = lane & 31;                                      // lanes 32..63 mirror lanes 0..31
+      const double* Pd = PT2 + c0 * 4;                              // rows c0..c0+3 of the tile, 4 panel entries each
+      const double p00 = -Pd[0];
+      const double p10 = -Pd[4], p11 = -Pd[5];
+      const double p20 = -Pd[8], p21 = -Pd[9], p22 = -Pd[10];
+      const double p30 = -Pd[12], p31 = -Pd[13], p32 = -Pd[14], p33 = -Pd[15];
+      const double r0 = PT2[x * 4 + 0], r1 = PT2[x * 4 + 1], r2 = PT2[x * 4 + 2], r3 = PT2[x * 4 + 3];
+      DDMPC_HOOK(0);
+      const double i0 = rsq_n2(p00);
+      DDMPC_HOOK(1);
+      const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
+      const double i1 = rsq_n2(p11 - l10 * l10);
+      DDMPC_HOOK(2);
+      const double l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
+      const double i2 = rsq_n2(p22 - l20 * l20 - l21 * l21);
+      DDMPC_HOOK(3);
+      const double l32 = (p32 - l30 * l20 - l31 * l21) * i2;
+      const double i3 = rsq_n2(p33 - l30 * l30 - l31 * l31 - l32 * l32);
+      DDMPC_HOOK(4);
+      const double x0 = -r0 * i0;
+      const double x1 = -(r1 + x0 * l10) * i1;
+      DDMPC_HOOK(5);
+      const double x2 = -(r2 + x0 * l20 + x1 * l21) * i2;
+      const double x3 = -(r3 + x0 * l30 + x1 * l31 + x2 * l32) * i3;
+      DDMPC_HOOK(6);
+      if (lane < 32) {                                              // kept for M / L_JJ / y; not on the chain
+        LT[(c0 + 0) * LRS + x] = x0; LT[(c0 + 1) * LRS + x] = x1;
+        LT[(c0 + 2) * LRS + x] = x2; LT[(c0 + 3) * LRS + x] = x3;
+      }
+      // MFMA operands without an LDS round trip.  Lane rows hold [tile rows, identity rows, tile rows, identity rows]
+      // (x = lane & 31); v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second:
+      //   swap(x0, x1) -> [x0.A x1.A x0.A x1.A], [x0.E x1.E x0.E x1.E];  swap(x2, x3) likewise,
+      // so that operand row kk = x_kk of the tile rows (opA) / of the identity rows (opE) is one select away.
+      const d2 s01a = permlane16_swap_f64(x0, x1), s23a = permlane16_swap_f64(x2, x3);
+      const bool lowhalf = lane < 32;
+      const double opA = lowhalf ? s01a[0] : s23a[0];
+      const double opE = lowhalf ? s01a[1] : s23a[1];
+      DDMPC_HOOK(7);
+      Ad = __builtin_amdgcn_mfma_f64_16x16x4f64(opA, opA, Ad, 0, 0, 0);
+      Et = __builtin_amdgcn_mfma_f64_16x16x4f64(opE, opA, Et, 0, 0, 0);
+      DDMPC_HOOK(8);
+      DDMPC_HOOK(9);
+      DDMPC_HOOK(10);
+      DDMPC_HOOK(11);
+      if constexpr (q < 3) {
+        if (q + 1 < nq && lo == q + 1) {
+          static_for<4>([&](auto j) __attribute__((always_inline)) {
+            PT2[(l4 + 4 * j) * 4 + l3] = Ad[j()];
+            PT2[(16 + l4 + 4 * j) * 4 + l3] = Et[j()];
+          });
+        }
+      }
+#undef DDMPC_HOOK
+    };
+    auto no_pend = [](auto) __attribute__((always_inline)) {};
+    auto factor_begin = [&](const d4& Ad, d4& Et) __attribute__((always_inline)) {
+      static_for<4>([&](auto j) __attribute__((always_inline)) { Et[j()] = (l4 + 4 * j() == l15) ? -1.0 : 0.0; });
+      if (lo == 0) {
+        static_for<4>([&](auto j) __attribute__((always_inline)) {
+          PT2[(l4 + 4 * j) * 4 + l3] = Ad[j()];
+          PT2[(16 + l4 + 4 * j) * 4 + l3] = Et[j()];
+        });
+      }
+    };
+    // after the last sub-step: M into the diagonal tile's registers, y of the last tile column, optional export
+    auto factor_end = [&](auto JT, int nq) __attribute__((always_inline)) {
+      constexpr int Jt = JT;
+      constexpr int SD = TM::slot(Jt, Jt);
+      static_for<4>([&](auto j) __attribute__((always_inline)) {
+        const int k = l4 + 4 * j();
+        const double mv = LT[k * LRS + 16 + l15];
+        acc[SD][j()] = (k < 4 * nq) ? mv : 0.0;                     // register j of lane (l4, l15) = M[l4 + 4j][l15]
+      });
+      if (Jt == IR) {                                               // y of the last tile column = the substituted rhs row
+        if (lane < 4 * nq) tvec[16 * Jt + lane] = LT[lane * LRS + rr];
+      }
+      if (lfac != nullptr) {                                        // ddmpc_prepare: L_JJ row-major and its transpose
+        static_for<4>([&](auto e) __attribute__((always_inline)) {
+          const int idx = lane + 64 * e(), xr = idx >> 4, kc = idx & 15;
+          double v = (kc <= xr && kc < 4 * nq) ? LT[kc * LRS + xr] : 0.0;
+          if (xr == kc && kc >= 4 * nq) v = 1.0;
+          lfac[(Jt * (Jt + 1) / 2 + Jt) * 256 + idx] = v;
+          lfacT[(Jt * (Jt + 1) / 2 + Jt) * 256 + kc * 16 + xr] = v;
+        });
+      }
+    };
+    // prologue: the panel wave factors diagonal tile 0 on its own
+    {
+      const int nq0 = NS < 4 ? NS : 4;
+      const long long t0 = now();
+      if constexpr (WAVE == 0) {
+        d4 Ad = acc[TM::slot(0, 0)];
+        d4 Et;
+        factor_begin(Ad, Et);
+        static_for<4>([&](auto q) __attribute__((always_inline)) { if (q() < nq0) substep(Ad, Et, q, nq0, no_pend); });
+        factor_end(std::integral_constant<int, 0>{}, nq0);
+      }
+      const long long t1 = now();
+      __syncthreads();                                              // (B) M_0 is in LT
+      tphF += t1 - t0; tphB += now() - t1;
+    }
     static_for<NT>([&](auto JB) __attribute__((always_inline)) {
       constexpr int Jb = JB;
-      const int nq = (NS - 4 * Jb) < 4 ? (NS - 4 * Jb) : 4;         // pivot groups in this tile column (<= 0: none)
-      if (nq > 0) {                                                   // workgroup-uniform
-        const bool more = 16 * (Jb + 1) < rE + 1;                     // live columns to the right of this panel
+      const int nqc = (NS - 4 * Jb) < 4 ? (NS - 4 * Jb) : 4;       // pivot groups of this tile column (<= 0: none)
+      if (nqc > 0) {                                                // workgroup-uniform
+        const bool more = 16 * (Jb + 1) < rE + 1;                   // live columns to the right of this panel
+        const int nqn = (NS - 4 * (Jb + 1)) < 4 ? (NS - 4 * (Jb + 1)) : 4;   // pivot groups of the next tile column
         const long long t0 = now();
-        // (F) panel wave: factor the diagonal tile, L_JJ and M = L_JJ^-1 -> LT
-        if constexpr (WAVE == 0) {
-          constexpr int SD = TM::slot(Jb, Jb);
-          d4 Ad = acc[SD];
-          d4 Et;
-          static_for<4>([&](auto j) __attribute__((always_inline)) { Et[j()] = (l4 + 4 * j() == l15) ? -1.0 : 0.0; });
-          const int x = lane & 31;                                    // lanes 32..63 mirror lanes 0..31 (reads only)
-          if (lo == 0) {
-            static_for<4>([&](auto j) __attribute__((always_inline)) {
-              PT2[(l4 + 4 * j) * 4 + l3] = Ad[j()];
-              PT2[(16 + l4 + 4 * j) * 4 + l3] = Et[j()];
-            });
+        // M operand of the triangular solves: read before A1, the panel wave overwrites LT after it
+        double am[4];
+        static_for<4>([&](auto ks) __attribute__((always_inline)) { am[ks()] = -LT[l15 * LRS + 16 + 4 * ks() + l4]; });
+        auto trsm_tile = [&](auto II) __attribute__((always_inline)) {
+          constexpr int I = II;
+          if (16 * I < rE + 1) {
+            constexpr int S = TM::slot(I, Jb);
+            const d4 T = acc[S];
+            d4 dd = d4{0.0, 0.0, 0.0, 0.0};
+            dd = __builtin_amdgcn_mfma_f64_16x16x4f64(am[0], T[0], dd, 0, 0, 0);
+            dd = __builtin_amdgcn_mfma_f64_16x16x4f64(am[1], T[1], dd, 0, 0, 0);
+            dd = __builtin_amdgcn_mfma_f64_16x16x4f64(am[2], T[2], dd, 0, 0, 0);
+            dd = __builtin_amdgcn_mfma_f64_16x16x4f64(am[3], T[3], dd, 0, 0, 0);
+            acc[S] = dd;
+            static_for<4>([&](auto j) __attribute__((always_inline)) { PB[(l4 + 4 * j) * RSB + 16 * I + l15] = dd[j()]; });
           }
-          bool okall = true;
-#pragma nounroll
-          for (int q = 0; q < nq; ++q) {
-            const int c0 = 4 * q;
-            const double* Pd = PT2 + c0 * 4;                          // rows c0..c0+3 of the tile, 4 panel entries each
-            const double p00 = -Pd[0];
-            const double p10 = -Pd[4], p11 = -Pd[5];
-            const double p20 = -Pd[8], p21 = -Pd[9], p22 = -Pd[10];
-            const double p30 = -Pd[12], p31 = -Pd[13], p32 = -Pd[14], p33 = -Pd[15];
-            const double r0 = PT2[x * 4 + 0], r1 = PT2[x * 4 + 1], r2 = PT2[x * 4 + 2], r3 = PT2[x * 4 + 3];
-            const double d0 = p00;
-            const double i0 = rsq_nr(d0);
-            const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
-            const double d1 = p11 - l10 * l10;
-            const double i1 = rsq_nr(d1);
-            const double l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
-            const double d2v = p22 - l20 * l20 - l21 * l21;
-            const double i2 = rsq_nr(d2v);
-            const double l32 = (p32 - l30 * l20 - l31 * l21) * i2;
-            const double d3 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
-            const double i3 = rsq_nr(d3);
-            okall = okall && (d0 > 0.0) && (d1 > 0.0) && (d2v > 0.0) && (d3 > 0.0) &&
-                    (i0 < 1e150) && (i1 < 1e150) && (i2 < 1e150) && (i3 < 1e150);
-            // forward substitution of this lane's row (the panel holds negated entries).  Tile rows above the pivot
-            // group are finished (zero here); inside the group the strictly upper part is zero; the identity rows
-            // (x >= 16) yield the columns of M.
-            double x0 = -r0 * i0;
-            double x1 = -(r1 + x0 * l10) * i1;
-            double x2 = -(r2 + x0 * l20 + x1 * l21) * i2;
-            double x3 = -(r3 + x0 * l30 + x1 * l31 + x2 * l32) * i3;
-            const int ii = (x < 16) ? (x - c0) : 4;
-            x0 = (ii < 0) ? 0.0 : x0;
-            x1 = (ii < 1) ? 0.0 : x1;
-            x2 = (ii < 2) ? 0.0 : x2;
-            x3 = (ii < 3) ? 0.0 : x3;
-            if (lane < 32) {
-              LT[(c0 + 0) * LRS + x] = x0; LT[(c0 + 1) * LRS + x] = x1;
-              LT[(c0 + 2) * LRS + x] = x2; LT[(c0 + 3) * LRS + x] = x3;
-            }
-            // rank-4 update inside the tile (negated matrix: plain accumulate) and the next panel's columns
-            const double opA = LT[(c0 + l4) * LRS + l15];
-            const double opE = LT[(c0 + l4) * LRS + 16 + l15];
-            Ad = __builtin_amdgcn_mfma_f64_16x16x4f64(opA, opA, Ad, 0, 0, 0);
-            Et = __builtin_amdgcn_mfma_f64_16x16x4f64(opE, opA, Et, 0, 0, 0);
-            if (q + 1 < nq && lo == q + 1) {
-              static_for<4>([&](auto j) __attribute__((always_inline)) {
-                PT2[(l4 + 4 * j) * 4 + l3] = Ad[j()];
-                PT2[(16 + l4 + 4 * j) * 4 + l3] = Et[j()];
-              });
-            }
-          }
-          if (lane == 0 && !okall) flags[0] = 1;
-          // M (lower triangular) replaces the diagonal tile: register j of lane (l4, l15) = M[l4 + 4j][l15]
-          static_for<4>([&](auto j) __attribute__((always_inline)) {
-            const int k = l4 + 4 * j();
-            const double mv = LT[k * LRS + 16 + l15];
-            acc[SD][j()] = (k < 4 * nq) ? mv : 0.0;
-          });
-          if (Jb == IR) {                                             // y of the last tile column = the substituted rhs row
-            if (lane < 4 * nq) tvec[16 * Jb + lane] = LT[lane * LRS + rr];
-          }
-          if (lfac != nullptr) {                                      // ddmpc_prepare: L_JJ row-major and its transpose
-            static_for<4>([&](auto e) __attribute__((always_inline)) {
-              const int idx = lane + 64 * e(), xr = idx >> 4, kc = idx & 15;
-              double v = (kc <= xr && kc < 4 * nq) ? LT[kc * LRS + xr] : 0.0;
-              if (xr == kc && kc >= 4 * nq) v = 1.0;
-              lfac[(Jb * (Jb + 1) / 2 + Jb) * 256 + idx] = v;
-              lfacT[(Jb * (Jb + 1) / 2 + Jb) * 256 + kc * 16 + xr] = v;
-            });
-          }
+        };
+        // (T1) the tile the next diagonal tile waits for
+        if constexpr (Jb + 1 < NT) {
+          if constexpr (TM::wave(Jb + 1, Jb) == WAVE) { if (more) trsm_tile(std::integral_constant<int, Jb + 1>{}); }
         }
         const long long t1 = now();
-        __syncthreads();                                              // (B) M is in LT
+        __syncthreads();                                            // (A1)
         const long long t2 = now();
+        d4 Ad = d4{0.0, 0.0, 0.0, 0.0}, Et = d4{0.0, 0.0, 0.0, 0.0};
+        if constexpr (WAVE == 0 && Jb + 1 < NT) {
+          if (nqn > 0) {                                            // next diagonal tile: trailing update, first sub-step
+            constexpr int S = TM::slot(Jb + 1, Jb + 1);
+            Ad = acc[S];
+            const long long tu0 = now();
+            static_for<4>([&](auto ks) __attribute__((always_inline)) {
+              const double o = PB[(4 * ks() + l4) * RSB + 16 * (Jb + 1) + l15];
+              Ad = __builtin_amdgcn_mfma_f64_16x16x4f64(o, o, Ad, 0, 0, 0);
+            });
+            tphU += now() - tu0;
+            factor_begin(Ad, Et);
+            substep(Ad, Et, std::integral_constant<int, 0>{}, nqn, no_pend);
+          }
+        }
+        // (T2) the other tiles of tile row Jb
         if (more) {
-          // (T) U(Jb, I) = M * K(Jb, I) for the tiles right of the diagonal: 4 MFMAs per tile, then the tile goes to PB
-          double am[4];
-          static_for<4>([&](auto ks) __attribute__((always_inline)) { am[ks()] = -LT[l15 * LRS + 16 + 4 * ks() + l4]; });
           static_for<NT>([&](auto I) __attribute__((always_inline)) {
-            if constexpr (I > Jb && TM::wave(I, Jb) == WAVE) {
-              if (16 * I < rE + 1) {
-                constexpr int S = TM::slot(I, Jb);
-                const d4 T = acc[S];
-                d4 dd = d4{0.0, 0.0, 0.0, 0.0};
-                dd = __builtin_amdgcn_mfma_f64_16x16x4f64(am[0], T[0], dd, 0, 0, 0);
-                dd = __builtin_amdgcn_mfma_f64_16x16x4f64(am[1], T[1], dd, 0, 0, 0);
-                dd = __builtin_amdgcn_mfma_f64_16x16x4f64(am[2], T[2], dd, 0, 0, 0);
-                dd = __builtin_amdgcn_mfma_f64_16x16x4f64(am[3], T[3], dd, 0, 0, 0);
-                acc[S] = dd;
-                static_for<4>([&](auto j) __attribute__((always_inline)) {
-                  PB[(l4 + 4 * j) * RSB + 16 * I + l15] = dd[j()];
-                });
-              }
-            }
+            if constexpr (I > Jb + 1 && TM::wave(I, Jb) == WAVE) trsm_tile(I);
           });
         }
         const long long t3 = now();
-        __syncthreads();                                              // (A) the panel is in PB
+        __syncthreads();                                            // (A2) the whole panel is in PB
         const long long t4 = now();
+        if constexpr (WAVE == 0 && Jb + 1 < NT) {
+          // sub-steps 1..3 of the next diagonal tile; the trailing updates of the diagonal tiles Jb+2.. (operands from
+          // PB, which stays valid until barrier B) are dealt over the three sub-steps
+          static_for<3>([&](auto QM) __attribute__((always_inline)) {
+            constexpr int q = QM + 1;
+            // diagonal tiles Jb+2+QM, +3, +6, ...: 4 MFMAs each, issued k-step-major (consecutive MFMAs hit different tiles)
+            constexpr int first = Jb + 2 + QM;
+            constexpr int ntl = first < NT ? (NT - 1 - first) / 3 + 1 : 0;
+            auto pend = [&](auto H) __attribute__((always_inline)) {
+              constexpr int h0 = H;
+              static_for<(4 * ntl + 11) / 12>([&](auto R) __attribute__((always_inline)) {   // more than 12 pending: several per hook
+                constexpr int h = h0 + 12 * R;
+                if constexpr (h < 4 * ntl) {
+                  constexpr int J2 = first + 3 * (h % ntl), ks = h / ntl;
+                  constexpr int S2 = TM::slot(J2, J2);
+                  const double o = PB[(4 * ks + l4) * RSB + 16 * J2 + l15];
+                  acc[S2] = __builtin_amdgcn_mfma_f64_16x16x4f64(o, o, acc[S2], 0, 0, 0);
+                }
+              });
+            };
+            if (q < nqn) substep(Ad, Et, std::integral_constant<int, q>{}, nqn, pend);
+          });
+          if (nqn > 0) factor_end(std::integral_constant<int, Jb + 1>{}, nqn);
+        }
+        // (U) trailing update K(J, I) += U(Jb, J)' U(Jb, I) (negated matrix) of the off-diagonal tiles, 4 k-steps of 4
         if (more) {
-          // (U) trailing update K(J, I) += U(Jb, J)' U(Jb, I) (negated matrix), 4 k-steps of 4; the panel wave does
-          //     the next diagonal tile first
-          if constexpr (WAVE == 0 && Jb + 1 < NT) {
-            constexpr int S = TM::slot(Jb + 1, Jb + 1);
-            static_for<4>([&](auto ks) __attribute__((always_inline)) {
-              const double o = PB[(4 * ks() + l4) * RSB + 16 * (Jb + 1) + l15];
-              acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(o, o, acc[S], 0, 0, 0);
-            });
-          }
           static_for<4>([&](auto ks) __attribute__((always_inline)) {
             double op[NT];
             static_for<NT>([&](auto X) __attribute__((always_inline)) {
@@ -497,7 +593,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
             });
             static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
               constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
-              if constexpr (J > Jb && !(WAVE == 0 && I == Jb + 1 && J == Jb + 1)) {
+              if constexpr (J > Jb && I > J) {
                 if (16 * I < rE + 1) {
                   constexpr int S = TM::slot(I, J);
                   acc[S] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[J], op[I], acc[S], 0, 0, 0);
@@ -507,7 +603,9 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
           });
         }
         const long long t5 = now();
-        tphF += t1 - t0; tphB += t2 - t1; tphT += t3 - t2; tphA += t4 - t3; tphU += t5 - t4;
+        __syncthreads();                                            // (B) M_{Jb+1} is in LT
+        const long long t6 = now();
+        tphT += t1 - t0; tphA += (t2 - t1) + (t4 - t3); tphF += (t3 - t2) + (t5 - t4); tphB += t6 - t5;   // F includes U (wave 0)
       }
     });
     if (timing && threadIdx.x == 0) { stamps[7] = tphF; stamps[8] = tphB; stamps[9] = tphT; stamps[10] = tphA; stamps[11] = tphU; }
@@ -574,8 +672,13 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
             });
             pi = fma(acc[SD][j()], v, pi);
           });
-          pi += __shfl_xor(pi, 16, 64);
-          pi += __shfl_xor(pi, 32, 64);
+          {   // sum over the four lane rows without LDS: swap(a, a) pairs rows (0,1) and (2,3), then the halves
+            const d2 s1 = permlane16_swap_f64(pi, pi);
+            pi = s1[0] + s1[1];
+            const auto lo2 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(pi), (unsigned)__double2loint(pi), false, false);
+            const auto hi2 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(pi), (unsigned)__double2hiint(pi), false, false);
+            pi = __hiloint2double((int)hi2[0], (int)lo2[0]) + __hiloint2double((int)hi2[1], (int)lo2[1]);
+          }
           if (l4 == 0) beta[16 * J + l15] = (16 * J + l15 < rE) ? pi : 0.0;
         }
         __syncthreads();

@@ -63,6 +63,7 @@ struct KParams {
   double bound;     // c * eps_max
   const double* tabd;
   const int* tabi;
+  int dev;              // development switches for in-process A/B measurements (env DDMPC_DEV at create); 0 in production
   int dense_w;          // 1: dense weighting matrices -> lam * W^-1 is the full [RP][RP] matrix `dmat`
   const double* dmat;   //    (shared by the batch, zero outside the weighted components), tabd D0 = D1 = 0
 };

@@ -35,7 +35,7 @@ def parity(tag, B, N=400, **kw):
             uw, cw, sw, _ = eng.step(up, yp)
             print("    warm step vs cold: %.2e" % (np.max(np.abs(uw - u)) / np.max(np.abs(u))))
 
-def timing(B=4096, slack=0):
+def timing(B=4096, slack=0, stamps=True):
     cfg = controller_params(dict(slack_var_constraint_type=slack))
     spec = orc.spec_from_params(slack_var_constraint_type=slack)
     d = generate_batch(range(B))
@@ -49,10 +49,12 @@ def timing(B=4096, slack=0):
         for _ in range(5): eng.solve(up, yp, *out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(30): eng.solve(up, yp, *out)
+        for _ in range(100): eng.solve(up, yp, *out)
         e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 30
+        ms = e0.elapsed_time(e1) / 100
         print("timing slack=%d B=%d: %.1f us per launch, %.3e solves/s, status ok %s" % (slack, B, ms * 1e3, B / ms * 1e3, bool((out[2] == 0).all())), flush=True)
+        if not stamps:
+            return
         eng.debug_stamps(True)
         eng.solve(up, yp, *out)
         st = eng.debug_stamps(False, fetch=True).astype(np.int64)
@@ -61,10 +63,27 @@ def timing(B=4096, slack=0):
         for i, nm in enumerate(names[:5]):
             print("   %-16s median %8.0f cycles" % (nm, np.median(dt[:, i])))
         print("   total %8.0f cycles" % np.median(st[:, 14] - st[:, 0]))
-        for i, nm in enumerate(["F factor (wave 0)", "wait B", "T trsm", "wait A", "U update"]):
-            print("   chol %-18s median %8.0f cycles (sum over steps, wave 0)" % (nm, np.median(st[:, 7 + i])))
+        for i, nm in enumerate(["F factor (wave 0, incl. U)", "wait B", "T trsm", "wait A1+A2", "U diag updates (in F)"]):
+            print("   chol %-30s median %8.0f cycles (sum over steps, wave 0)" % (nm, np.median(st[:, 7 + i])))
 
 if __name__ == "__main__":
+    import os
+    if len(sys.argv) > 1 and sys.argv[1] == "ab":          # in-process A/B of development switches (same box, same clocks)
+        for rep in range(3):
+            for dev in sys.argv[2:]:
+                os.environ["DDMPC_DEV"] = dev
+                print("DDMPC_DEV=%s" % dev, end="  ")
+                timing(4096, 0, stamps=False)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "fine":        # sub-step internals (dev bit 1): slots = F: mfma+extract, B: factor, T: reads, A: subst, U: LT write+permlane
+        os.environ["DDMPC_DEV"] = "2"
+        for B in (256, 4096):
+            timing(B, 0)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "occ":         # phase stamps at 1, 2 and 3 workgroups per CU
+        for B in (256, 512, 768, 4096):
+            timing(B, 0)
+        sys.exit(0)
     parity("robust/none", 8)
     parity("robust/convex", 8, slack_var_constraint_type=1)
     parity("ucon", 4, tec=False)
