@@ -22,6 +22,8 @@ MEM_HOST, MEM_DEVICE = 0, 1
 GRAM_AUTO, GRAM_DENSE, GRAM_STRUCTURED = 0, 1, 2
 OPT_CLOSED_LOOP_PATH = 1
 OPT_CLOSED_LOOP_GRAPH = 2
+OPT_REFINE, OPT_REFINE_MAX, OPT_REFINE_COND_LOG10 = 3, 4, 5
+REFINE_OFF, REFINE_AUTO, REFINE_ALWAYS = 0, 1, 2
 PATH_AUTO, PATH_COLD, PATH_WARM = 0, 1, 2
 SOL_ALPHA, SOL_UBAR, SOL_YBAR, SOL_SIGMA = 0, 1, 2, 3
 

@@ -94,13 +94,15 @@ def build(force: bool = False, jobs: int = 0, verbose: bool = True) -> str:
     cmd = [hipcc] + COMMON_FLAGS + api_flags + ["-c", os.path.join(CSRC, "ddmpc_api.hip"), "-o", api_obj]
     tasks.append((cmd, api_obj, _fingerprint(cmd, API_DEPS, [header])))
     for nt, w in instances():
-        for gen in ((2,) if SKIP_V1 else (2, 1)):
-            obj = os.path.join(OBJ_DIR, "ddmpc_inst%s_%d_%d.o" % ("" if gen == 1 else "2", nt, w))
-            cmd = [hipcc] + COMMON_FLAGS + ["-DDDMPC_INST_NT=%d" % nt, "-DDDMPC_INST_W=%d" % w] + \
-                  (["-DDDMPC_INST_V1"] if gen == 1 else []) + ["-c", os.path.join(CSRC, "ddmpc_inst.hip"), "-o", obj]
+        # 2: the 16-wide-panel kernel, "2r": the same with the iterative-refinement loop compiled in, 1: first generation
+        for gen in (("2", "2r") if SKIP_V1 else ("2", "2r", "1")):
+            obj = os.path.join(OBJ_DIR, "ddmpc_inst%s_%d_%d.o" % ("" if gen == "1" else gen, nt, w))
+            extra = {"1": ["-DDDMPC_INST_V1"], "2": [], "2r": ["-DDDMPC_INST_REF=true"]}[gen]
+            cmd = [hipcc] + COMMON_FLAGS + ["-DDDMPC_INST_NT=%d" % nt, "-DDDMPC_INST_W=%d" % w] + extra + \
+                  ["-c", os.path.join(CSRC, "ddmpc_inst.hip"), "-o", obj]
             tasks.append((cmd, obj, _fingerprint(cmd, INST_DEPS)))
     todo = [t for t in tasks if force or not _is_current(t[1], t[2])]
-    todo.sort(key=lambda t: -int(re.search(r"ddmpc_inst2?_(\d+)_", t[1]).group(1)) if "ddmpc_inst" in t[1] else 0)  # longest first
+    todo.sort(key=lambda t: -int(re.search(r"ddmpc_inst2?r?_(\d+)_", t[1]).group(1)) if "ddmpc_inst" in t[1] else 0)  # longest first
     if todo:
         jobs = jobs or min(len(todo), max(1, (os.cpu_count() or 2) - 1), 8)
         if verbose:

@@ -26,10 +26,13 @@ namespace ddmpc {
 #include "ddmpc_instances.inc"
 #undef DDMPC_INSTANCE
 #endif
-#define DDMPC_INSTANCE(NT, W)                                                                        \
-  extern template __global__ void ddmpc_cold_solve_kernel2<NT, W>(                                   \
-      KParams, const double*, const double*, const double*, const double*, double*, double*, int*,  \
-      int*, double*, signed char*, unsigned long long*, double*, double*, const int*);
+#define DDMPC_INSTANCE(NT, W)                                                                              \
+  extern template __global__ void ddmpc_cold_solve_kernel2<NT, W, false>(                                  \
+      KParams, const double*, const double*, const double*, const double*, double*, double*, int*,        \
+      int*, double*, signed char*, unsigned long long*, double*, double*, int*, const int*, long long, int*);   \
+  extern template __global__ void ddmpc_cold_solve_kernel2<NT, W, true>(                                   \
+      KParams, const double*, const double*, const double*, const double*, double*, double*, int*,        \
+      int*, double*, signed char*, unsigned long long*, double*, double*, int*, const int*, long long, int*);
 #include "ddmpc_instances.inc"
 #undef DDMPC_INSTANCE
 }  // namespace ddmpc
@@ -98,7 +101,7 @@ typedef void (*cold_kernel_t)(KParams, const double*, const double*, const doubl
                               double*, int*, int*, double*, signed char*, unsigned long long*, double*, const int*);
 
 typedef void (*cold_kernel2_t)(KParams, const double*, const double*, const double*, const double*, double*,
-                               double*, int*, int*, double*, signed char*, unsigned long long*, double*, double*, const int*);
+                               double*, int*, int*, double*, signed char*, unsigned long long*, double*, double*, int*, const int*, long long, int*);
 
 struct KernelChoice {
   int NT, W;
@@ -106,6 +109,7 @@ struct KernelChoice {
   const char* name;
   cold_kernel2_t fn2;        // 16-wide-panel kernel (ddmpc_cold2.hpp), the default
   const char* name2;
+  cold_kernel2_t fn2r;       // the same with the iterative-refinement loop compiled in
 };
 
 // Instantiated (tile rows, waves) pairs.  A problem uses the smallest NT that
@@ -117,7 +121,7 @@ struct KernelChoice {
 #endif
 const KernelChoice kKernels[] = {
 #define DDMPC_INSTANCE(NT, W) \
-  {NT, W, DDMPC_V1_FN(NT, W), "ddmpc_cold_solve_kernel_v1<" #NT "," #W ">", &ddmpc_cold_solve_kernel2<NT, W>, "ddmpc_cold_solve_kernel<" #NT "," #W ">"},
+  {NT, W, DDMPC_V1_FN(NT, W), "ddmpc_cold_solve_kernel_v1<" #NT "," #W ">", &ddmpc_cold_solve_kernel2<NT, W, false>, "ddmpc_cold_solve_kernel<" #NT "," #W ">", &ddmpc_cold_solve_kernel2<NT, W, true>},
 #include "ddmpc_instances.inc"
 #undef DDMPC_INSTANCE
 };
@@ -158,8 +162,10 @@ struct ddmpc_handle {
   DevBuf d_lfac, d_lfacT, d_gain, d_prep_status, d_zero, d_need;
   // host-pointer solves: one packed device buffer and its pinned host mirror (two copies per solve instead of six)
   DevBuf d_io, d_rr, d_alpha;
+  DevBuf d_rflag;                          // AUTO refinement: per-instance "refine me" flags of the plain cold kernel
   DevBuf d_zws, d_resc;                    // NOMINAL rescue kernel: z per component and a per-instance "rescued" flag (ddmpc_get_solution)
   bool rescue_ran = false;
+  int epoch = 0;                           // cold launches so far (KParams::epoch)
   bool v2 = true;                          // 16-wide-panel cold kernel (default); false: first-generation kernel (DDMPC_KERNEL=1)
   bool ws_stale = false;                   // the last solve was a cold solve that skipped the beta / active-set workspace                 // the last solve launched the rescue kernel (its flags are current)
   HostBuf h_io;
@@ -418,6 +424,9 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   k.bound = k.convex ? p.c * p.eps_max : 0.0;
   k.max_iter = p.max_iter > 0 ? p.max_iter : 50;
   k.dev = getenv("DDMPC_DEV") ? atoi(getenv("DDMPC_DEV")) : 0;
+  k.refine = getenv("DDMPC_REFINE") ? atoi(getenv("DDMPC_REFINE")) : DDMPC_REFINE_AUTO;   // env: development knob
+  k.refine_max = 3;
+  k.refine_cond = std::pow(10.0, 6.3);   // 2e6:     // four-tank benchmark data: 1.0e6..1.3e6 with errors ~1e-12 (not refined); see DESIGN.md section 9
   if (p.gram_mode == DDMPC_GRAM_STRUCTURED && k.nch != 4) {
     delete h;
     return fail(DDMPC_ERR_UNSUPPORTED, "DDMPC_GRAM_STRUCTURED needs m + p == 4 (got %d); use DDMPC_GRAM_AUTO", k.nch);
@@ -440,8 +449,8 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
         if (cand.NT == kc->NT && cand.W == want) { kc = &cand; break; }
     }
   }
-  static const KernelChoice kLargeNominal = {0, 4, nullptr, "ddmpc_nominal_rr_kernel", nullptr, "ddmpc_nominal_rr_kernel"};
-  static const KernelChoice kLargeSolve = {0, 4, nullptr, "ddmpc_large_solve_kernel", nullptr, "ddmpc_large_solve_kernel"};
+  static const KernelChoice kLargeNominal = {0, 4, nullptr, "ddmpc_nominal_rr_kernel", nullptr, "ddmpc_nominal_rr_kernel", nullptr};
+  static const KernelChoice kLargeSolve = {0, 4, nullptr, "ddmpc_large_solve_kernel", nullptr, "ddmpc_large_solve_kernel", nullptr};
   if (!kc) {
     // No register-resident kernel holds this many rows.  With scalar/diagonal weights the problem is served by the
     // global-workspace kernels (plain VALU code): ROBUST controllers by
@@ -507,6 +516,8 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   if (h->lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(h->v2 ? reinterpret_cast<const void*>(h->kc.fn2) : reinterpret_cast<const void*>(h->kc.fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+    if (e == hipSuccess && h->v2)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(h->kc.fn2r), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
     if (e != hipSuccess) { ddmpc_destroy(h); return fail(DDMPC_ERR_HIP, "hipFuncSetAttribute(LDS=%zu) failed: %s", h->lds_bytes, hipGetErrorString(e)); }
   }
   int rc = upload_params(h);
@@ -522,7 +533,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_rflag};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -632,10 +643,36 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
   signed char* aws = want_ws ? (signed char*)h->d_act.p : nullptr;
   unsigned long long* stp = h->stamps_on ? (unsigned long long*)h->d_stamps.p : (unsigned long long*)nullptr;
   dim3 grid((unsigned)h->batch), block(64 * h->kc.W);
-  if (h->v2)
-    hipLaunchKernelGGL(h->kc.fn2, grid, block, h->lds_bytes, h->stream, kp_override ? *kp_override : h->kp, h->ud, h->yd,
-                       up, yp, uo, cost, (int*)status, (int*)iters, bws, aws, stp, lfac, lfacT, only);
-  else
+  if (h->v2) {
+    // Refinement (DDMPC_OPT_REFINE).  OFF / factor export / nominal scheme (z = t does not depend on beta): plain kernel.
+    // ALWAYS: the kernel variant with the refinement loop.  AUTO: plain kernel, which flags the instances whose pivots
+    // bound cond(K) from below by more than the threshold; those alone are solved again by the refining variant.
+    KParams kq = kp_override ? *kp_override : h->kp;
+    int mode = (lfac != nullptr || kq.lam == 0.0) ? DDMPC_REFINE_OFF : kq.refine;
+    if (mode == DDMPC_REFINE_ALWAYS) {
+      hipLaunchKernelGGL(h->kc.fn2r, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
+                         (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, only, 0LL, (int*)nullptr);
+    } else if (mode == DDMPC_REFINE_AUTO) {
+      // flags [batch] + one counter behind them (number of flagged instances of this launch; the refinement pass leaves at
+      // once when it is zero)
+      const bool fresh = h->d_rflag.bytes < ((size_t)h->batch + 1) * sizeof(int);
+      if ((rc = h->d_rflag.ensure(((size_t)h->batch + 1) * sizeof(int)))) return rc;
+      if (fresh) HIP_TRY(hipMemsetAsync(h->d_rflag.p, 0, ((size_t)h->batch + 1) * sizeof(int), h->stream));
+      int* rcount = (int*)h->d_rflag.p + h->batch;
+      if (only) HIP_TRY(hipMemsetAsync(h->d_rflag.p, 0, (size_t)h->batch * sizeof(int), h->stream));   // filtered-out instances: no flag
+      kq.epoch = ++h->epoch;
+      hipLaunchKernelGGL(h->kc.fn2, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
+                         (int*)iters, bws, aws, stp, lfac, lfacT, (int*)h->d_rflag.p, only, 0LL, rcount);
+      HIP_TRY(hipGetLastError());
+      kq.refine = DDMPC_REFINE_ALWAYS;
+      const unsigned pg = (unsigned)(h->batch < 768 ? h->batch : 768);       // persistent grid, 3 workgroups per CU
+      hipLaunchKernelGGL(h->kc.fn2r, dim3(pg), block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
+                         (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, (const int*)h->d_rflag.p, (long long)h->batch, rcount);
+    } else {
+      hipLaunchKernelGGL(h->kc.fn2, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
+                         (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, only, 0LL, (int*)nullptr);
+    }
+  } else
     hipLaunchKernelGGL(h->kc.fn, grid, block, h->lds_bytes, h->stream, kp_override ? *kp_override : h->kp, h->ud, h->yd,
                        up, yp, uo, cost, (int*)status, (int*)iters, bws, aws, stp, lfac, only);
   HIP_TRY(hipGetLastError());
@@ -820,6 +857,19 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
   const size_t nchunks = B >= 2048 ? 8 : (B >= 256 ? 4 : 1);
   hipEvent_t ev[8];
   for (size_t k = 0; k < nchunks; ++k) HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+  // refinement (see launch_cold): ALWAYS -> the refining kernel variant per chunk; AUTO -> the chunks flag the instances
+  // that need it and one filtered launch of the refining variant follows the last chunk
+  const bool refinable = h->v2 && h->kp.lam != 0.0;
+  const bool always = refinable && h->kp.refine == DDMPC_REFINE_ALWAYS;
+  int* rflag = nullptr;
+  if (refinable && h->kp.refine == DDMPC_REFINE_AUTO) {
+    const bool fresh = h->d_rflag.bytes < (B + 1) * sizeof(int);
+    if ((rc = h->d_rflag.ensure((B + 1) * sizeof(int)))) return rc;
+    rflag = (int*)h->d_rflag.p;
+    if (fresh) HIP_TRY(hipMemsetAsync(rflag, 0, (B + 1) * sizeof(int), h->stream));
+  }
+  KParams kchunk = h->kp;
+  kchunk.epoch = ++h->epoch;
   int rcl = DDMPC_OK;
   for (size_t k = 0; k < nchunks && rcl == DDMPC_OK; ++k) {
     const size_t b0 = B * k / nchunks, b1 = B * (k + 1) / nchunks, nb = b1 - b0;
@@ -830,11 +880,11 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
       break;
     }
     if (h->v2)
-      hipLaunchKernelGGL(h->kc.fn2, dim3((unsigned)nb), dim3(64 * h->kc.W), h->lds_bytes, h->stream, h->kp,
+      hipLaunchKernelGGL(always ? h->kc.fn2r : h->kc.fn2, dim3((unsigned)nb), dim3(64 * h->kc.W), h->lds_bytes, h->stream, kchunk,
                          (const double*)(dud + b0 * su), (const double*)(dyd + b0 * sy), (const double*)(dup + b0 * sup),
                          (const double*)(dyp + b0 * syp), duo + b0 * suo, dco + b0, (int*)(dst + b0), (int*)(dit + b0),
                          (double*)nullptr, (signed char*)nullptr, (unsigned long long*)nullptr, (double*)nullptr,
-                         (double*)nullptr, (const int*)nullptr);
+                         (double*)nullptr, rflag ? rflag + b0 : (int*)nullptr, (const int*)nullptr, 0LL, rflag ? rflag + B : (int*)nullptr);
     else
       hipLaunchKernelGGL(h->kc.fn, dim3((unsigned)nb), dim3(64 * h->kc.W), h->lds_bytes, h->stream, h->kp,
                          (const double*)(dud + b0 * su), (const double*)(dyd + b0 * sy), (const double*)(dup + b0 * sup),
@@ -842,6 +892,15 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
                          (double*)nullptr, (signed char*)nullptr, (unsigned long long*)nullptr, (double*)nullptr,
                          (const int*)nullptr);
     if (hipGetLastError() != hipSuccess) rcl = fail(DDMPC_ERR_HIP, "ddmpc_solve_from_host: launch of chunk %zu failed", k);
+  }
+  if (rcl == DDMPC_OK && rflag) {
+    KParams kq = kchunk;
+    kq.refine = DDMPC_REFINE_ALWAYS;
+    hipLaunchKernelGGL(h->kc.fn2r, dim3((unsigned)(B < 768 ? B : 768)), dim3(64 * h->kc.W), h->lds_bytes, h->stream, kq,
+                       (const double*)dud, (const double*)dyd, (const double*)dup, (const double*)dyp, duo, dco, (int*)dst, (int*)dit,
+                       (double*)nullptr, (signed char*)nullptr, (unsigned long long*)nullptr, (double*)nullptr, (double*)nullptr,
+                       (int*)nullptr, (const int*)rflag, (long long)B, rflag + B);
+    if (hipGetLastError() != hipSuccess) rcl = fail(DDMPC_ERR_HIP, "ddmpc_solve_from_host: launch of the refinement pass failed");
   }
   if (rcl == DDMPC_OK) {            // NOMINAL on exact data: same rank-revealing rescue as ddmpc_solve (all chunks are uploaded
     h->ud = dud; h->yd = dyd;       // and solved by now in stream order)
@@ -955,6 +1014,20 @@ int ddmpc_set_option(ddmpc_handle* h, int option, int value) {
       return DDMPC_OK;
     case DDMPC_OPT_CLOSED_LOOP_GRAPH:
       h->closed_loop_graph = value != 0;
+      return DDMPC_OK;
+    case DDMPC_OPT_REFINE:
+      if (value != DDMPC_REFINE_OFF && value != DDMPC_REFINE_AUTO && value != DDMPC_REFINE_ALWAYS)
+        return fail(DDMPC_ERR_INVALID, "refinement mode must be DDMPC_REFINE_OFF, _AUTO or _ALWAYS");
+      h->kp.refine = value;
+      h->prepared = false;              // the affine law is formed from a refined solve of the offset column
+      return DDMPC_OK;
+    case DDMPC_OPT_REFINE_MAX:
+      if (value < 1 || value > 10) return fail(DDMPC_ERR_INVALID, "refinement passes must be within [1, 10]");
+      h->kp.refine_max = value;
+      return DDMPC_OK;
+    case DDMPC_OPT_REFINE_COND_LOG10:
+      if (value < 0 || value > 3000) return fail(DDMPC_ERR_INVALID, "refinement threshold (tenths of a decade) must be within [0, 3000]");
+      h->kp.refine_cond = std::pow(10.0, 0.1 * (double)value);
       return DDMPC_OK;
     default: return fail(DDMPC_ERR_INVALID, "unknown option %d", option);
   }
@@ -1200,6 +1273,11 @@ int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps
   if (!warm) {
     if ((rc = h->d_beta.ensure(B * h->kp.rE * sizeof(double))) || (rc = h->d_act.ensure(B * h->kp.rE))) return rc;
     if (warm_box && (rc = h->d_need.ensure(B * sizeof(int)))) return rc;
+    if (h->v2 && !h->large) {       // AUTO refinement flags of launch_cold: sized (and cleared once) before a capture starts
+      const bool fresh = h->d_rflag.bytes < (B + 1) * sizeof(int);
+      if ((rc = h->d_rflag.ensure((B + 1) * sizeof(int)))) return rc;
+      if (fresh) HIP_TRY(hipMemsetAsync(h->d_rflag.p, 0, (B + 1) * sizeof(int), h->stream));
+    }
   }
   if (use_graph && hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
     (void)hipGetLastError();                          // e.g. a caller-provided legacy stream: launch the steps directly

@@ -49,6 +49,11 @@ struct TileMap2 {
   static constexpr int MAXS = tab.maxs;
   static constexpr int wave(int I, int J) { return tab.wave[I - J]; }
   static constexpr int slot(int I, int J) { return tab.base[I - J] + J; }
+  // does wave w own a tile (J, K) with K < J in tile row J?
+  static constexpr bool has_row(int w, int J) {
+    for (int K = 0; K < J; ++K) if (wave(J, K) == w) return true;
+    return false;
+  }
   // does wave w own a tile (I, J) with I > J in tile column J?
   static constexpr bool has_col(int w, int J) {
     for (int I = J + 1; I < NT; ++I) if (wave(I, J) == w) return true;
@@ -102,6 +107,16 @@ __device__ __forceinline__ double rsq_n2(double x) {
   return fma(0.5 * y0, e, y0);
 }
 
+// Sum of one value per lane over the four 16-lane rows of the wave (every lane receives the total), without LDS:
+// swap(a, a) pairs rows (0,1) and (2,3), then the two halves.
+__device__ __forceinline__ double rows4_total(double v) {
+  const d2 s1 = permlane16_swap_f64(v, v);
+  v = s1[0] + s1[1];
+  const auto lo2 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+  const auto hi2 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+  return __hiloint2double((int)hi2[0], (int)lo2[0]) + __hiloint2double((int)hi2[1], (int)lo2[1]);
+}
+
 // LDS carve-up (doubles) of the second kernel.
 template <int NT>
 struct Lds2 {
@@ -109,7 +124,11 @@ struct Lds2 {
   static constexpr int dvec = 0;
   static constexpr int tvec = dvec + RP;
   static constexpr int beta = tvec + RP;
-  static constexpr int part = beta + RP;               // back substitution: [8 waves][16] partial sums
+  static constexpr int cd0 = beta + RP;                // per-component constants of this instance (kept out of the registers):
+  static constexpr int cd1 = cd0 + RP;                 //   D (inactive / bound active), target (past window folded in),
+  static constexpr int ct0 = cd1 + RP;                 //   kind (ints, RP/2 doubles)
+  static constexpr int ckk = ct0 + RP;
+  static constexpr int part = ckk + (RP + 1) / 2;      // back substitution: [8 waves][16] partial sums
   static constexpr int red = part + 128;               // 32
   static constexpr int ints = red + 32;                // int act[RP], int flags[8]
   static constexpr int pt2 = (ints + (RP + 8 + 1) / 2 + 2) & ~1;   // in-tile panel, row-major: [32 rows][4]
@@ -122,14 +141,19 @@ struct Lds2 {
   __host__ __device__ static constexpr int total(int xs_len) { return (xs + xs_len + 1) & ~1; }
 };
 
-template <int NT, int W, int WAVE>
+// REF: compile the iterative-refinement loop in.  The plain variant (REF = false) is the fast one; when asked to
+// (refine_flag != nullptr) it records whether its pivots call for refinement, and the API re-solves exactly those
+// instances with the REF variant (DDMPC_REFINE_AUTO).  Keeping the loop out of the plain variant keeps its register
+// allocation free of spills on the factorisation's critical path.
+template <int NT, int W, int WAVE, bool REF>
 __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict__ sm,
                                            const double* __restrict__ up, const double* __restrict__ yp,
                                            double* __restrict__ u_opt, double* __restrict__ cost_out,
                                            int* __restrict__ status_out, int* __restrict__ iters_out,
                                            double* __restrict__ beta_ws, signed char* __restrict__ act_ws,
                                            unsigned long long* __restrict__ stamps, double* __restrict__ lfac,
-                                           double* __restrict__ lfacT) {
+                                           double* __restrict__ lfacT, int* __restrict__ refine_flag,
+                                           int* __restrict__ refine_count) {
   using TM = TileMap2<NT, W>;
   using WT = WaveTiles2<NT, W, WAVE>;
   using LD = Lds2<NT>;
@@ -166,18 +190,20 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
   d4 acc[TM::MAXS];
 
   constexpr int NE = (RP + NTHR - 1) / NTHR;
-  double cD0[NE], cD1[NE], cT[NE];
-  int cK[NE];
+  double* cD0 = sm + LD::cd0;
+  double* cD1 = sm + LD::cd1;
+  double* cT = sm + LD::ct0;
+  int* cK = reinterpret_cast<int*>(sm + LD::ckk);
   static_for<NE>([&](auto e) __attribute__((always_inline)) {
     const int rho = tid0 + e * NTHR;
-    cD0[e()] = 0.0; cD1[e()] = 0.0; cT[e()] = 0.0; cK[e()] = K_PAD;
     if (rho < RP) {
-      cD0[e()] = P.tabd[0 * RP + rho];
-      cD1[e()] = P.tabd[1 * RP + rho];
-      cT[e()] = P.tabd[2 * RP + rho];
-      cK[e()] = P.tabi[0 * RP + rho];
+      double tt = P.tabd[2 * RP + rho];
       const int pidx = P.tabi[1 * RP + rho];
-      if (pidx >= 0) cT[e()] = (pidx < P.npu) ? up[pidx] : yp[pidx - P.npu];
+      if (pidx >= 0) tt = (pidx < P.npu) ? up[pidx] : yp[pidx - P.npu];
+      cD0[rho] = P.tabd[0 * RP + rho];
+      cD1[rho] = P.tabd[1 * RP + rho];
+      cT[rho] = tt;
+      cK[rho] = P.tabi[0 * RP + rho];
       act[rho] = 0;
     }
   });
@@ -189,6 +215,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
   int iter = 0;
   int status = 0;
   int tid = tid0;
+  double imax = 0.0, kmax = 0.0;     // panel wave: largest 1/sqrt(pivot) and largest diagonal entry of K
   long long tphF = 0, tphB = 0, tphT = 0, tphA = 0, tphU = 0;
   const bool timing = (stamps != nullptr) && (WAVE == 0);
   auto now = [&]() __attribute__((always_inline)) -> long long { return timing ? (long long)__builtin_amdgcn_s_memtime() : 0; };
@@ -201,8 +228,8 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
       const int rho = tid + e * NTHR;
       if (rho < RP) {
         const int s_act = act[rho];
-        dvec[rho] = s_act ? cD1[e()] : cD0[e()];
-        tvec[rho] = cT[e()] + s_act * P.bound;
+        dvec[rho] = s_act ? cD1[rho] : cD0[rho];
+        tvec[rho] = cT[rho] + s_act * P.bound;
         beta[rho] = 0.0;
       }
     });
@@ -251,17 +278,32 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
           const double* pA = xs + 4 * (kq + blk) + ij + 16 * (WAVE * MAXG);      // A[i][k] = x_i[t0 + k + 4g + blk]
           const int cfull = c & ~3;
           int t0 = 0;
-          for (; t0 + 16 <= cfull; t0 += 16) {
-            double bv[4], av[MAXG + 3];
+          // 4 k-steps per trip, software-pipelined over two operand sets: the loads of trip i+1 are in flight while the
+          // MFMAs of trip i issue (the phase is bound by LDS latency, not by the matrix pipe)
+          auto ld = [&](double (&bv)[4], double (&av)[MAXG + 3]) __attribute__((always_inline)) {
             static_for<4>([&](auto u) __attribute__((always_inline)) { bv[u()] = pB[16 * u]; });
             static_for<MAXG + 3>([&](auto q) __attribute__((always_inline)) { av[q()] = pA[16 * q]; });
+            pA += 64; pB += 64;
+          };
+          auto mm = [&](const double (&bv)[4], const double (&av)[MAXG + 3]) __attribute__((always_inline)) {
             static_for<4>([&](auto u) __attribute__((always_inline)) {
               static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
                 cacc[gi()] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[gi() + u()], bv[u()], cacc[gi()], 0, 0, 0);
               });
             });
-            pA += 64; pB += 64;
+          };
+          const int ntrip = cfull >> 4;
+          double bv0[4], av0[MAXG + 3], bv1[4], av1[MAXG + 3];
+          if (ntrip > 0) ld(bv0, av0);
+          int it = 0;
+          for (; it + 2 <= ntrip; it += 2) {
+            ld(bv1, av1);
+            mm(bv0, av0);
+            if (it + 2 < ntrip) ld(bv0, av0);
+            mm(bv1, av1);
           }
+          if (it < ntrip) mm(bv0, av0);
+          t0 = 16 * ntrip;
           for (; t0 < cfull; t0 += 4) {
             const double bv = pB[0];
             static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
@@ -357,7 +399,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
       if constexpr (I == J) {
         static_for<4>([&](auto j) __attribute__((always_inline)) {
           const int gr = 16 * J + l4 + 4 * j;
-          if (gr == gc && gr < r) v[j()] -= P.lam * dvec[gr];
+          if (gr == gc && gr < r) { v[j()] -= P.lam * dvec[gr]; kmax = fmax(kmax, -v[j()]); }
         });
       }
       if (16 * I + 15 >= r) {                             // wave-uniform: tile columns that touch the padding / rhs column
@@ -379,6 +421,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         static_for<4>([&](auto j) __attribute__((always_inline)) { acc[S][j()] -= P.lam * dm[4 * j() * RP]; });
       });
     }
+    imax = 0.0;
     __syncthreads();      // every wave has read tvec (targets) for its rhs entries; LT / PT2 / PB are free
 
     // ---- blocked Cholesky, 16-wide panels, software-pipelined over the tile columns --------------------------------
@@ -403,7 +446,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
     auto substep = [&](d4& Ad, d4& Et, auto QQ, int nq, auto&& pend) __attribute__((always_inline)) {
       constexpr int q = QQ;
       constexpr int c0 = 4 * q;
-#define DDMPC_HOOK(h) do { __builtin_amdgcn_sched_barrier(0); pend(std::integral_constant<int, h>{}); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define DDMPC_HOOK(h) do { pend(std::integral_constant<int, h>{}); } while (0)
       const int x = lane & 31;                                      // lanes 32..63 mirror lanes 0..31
       const double* Pd = PT2 + c0 * 4;                              // rows c0..c0+3 of the tile, 4 panel entries each
       const double p00 = -Pd[0];
@@ -476,6 +519,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         const int k = l4 + 4 * j();
         const double mv = LT[k * LRS + 16 + l15];
         acc[SD][j()] = (k < 4 * nq) ? mv : 0.0;                     // register j of lane (l4, l15) = M[l4 + 4j][l15]
+        if (k == l15 && k < 4 * nq) imax = fmax(imax, mv);          // diag M = 1/sqrt(pivot): conditioning estimate (refinement trigger)
       });
       if (Jt == IR) {                                               // y of the last tile column = the substituted rhs row
         if (lane < 4 * nq) tvec[16 * Jt + lane] = LT[lane * LRS + rr];
@@ -637,53 +681,191 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
       }
     });
     __syncthreads();
-    // ---- back substitution U beta = y, one tile column per round, right to left:
-    //   (1) every wave: s[k] = sum over its tiles (I > J) of U(J,I)[k][.] beta_I  (4 multiply-adds per tile, then one
+    // ---- back substitution U x = y (y in tvec), one tile column per round, right to left:
+    //   (1) every wave: s[k] = sum over its tiles (I > J) of U(J,I)[k][.] x_I  (4 multiply-adds per tile, then one
     //       16-lane reduction per register) -> part[wave][k]
-    //   (2) panel wave: beta_J = M_J' (y_J - sum of the parts)
-    static_for<NT>([&](auto JREV) __attribute__((always_inline)) {
-      constexpr int J = NT - 1 - JREV;
-      if (16 * J < rE) {                                              // workgroup-uniform
-        if constexpr (TM::has_col(WAVE, J)) {
-          d4 s = d4{0.0, 0.0, 0.0, 0.0};
-          static_for<NT>([&](auto I) __attribute__((always_inline)) {
-            if constexpr (I > J && TM::wave(I, J) == WAVE) {
-              if (16 * I < rE) {
-                constexpr int S = TM::slot(I, J);
-                const double b = beta[16 * I + l15];
-                static_for<4>([&](auto j) __attribute__((always_inline)) { s[j()] = fma(acc[S][j()], b, s[j()]); });
+    //   (2) panel wave: x_J = M_J' (y_J - sum of the parts)
+    auto back_substitute = [&](double* __restrict__ out) __attribute__((always_inline)) {
+      static_for<NT>([&](auto JREV) __attribute__((always_inline)) {
+        constexpr int J = NT - 1 - JREV;
+        if (16 * J < rE) {                                              // workgroup-uniform
+          if constexpr (TM::has_col(WAVE, J)) {
+            d4 s = d4{0.0, 0.0, 0.0, 0.0};
+            static_for<NT>([&](auto I) __attribute__((always_inline)) {
+              if constexpr (I > J && TM::wave(I, J) == WAVE) {
+                if (16 * I < rE) {
+                  constexpr int S = TM::slot(I, J);
+                  const double b = out[16 * I + l15];
+                  static_for<4>([&](auto j) __attribute__((always_inline)) { s[j()] = fma(acc[S][j()], b, s[j()]); });
+                }
               }
+            });
+            static_for<4>([&](auto j) __attribute__((always_inline)) { s[j()] = row16_total(s[j()]); });
+            if (l15 == 0) {
+              static_for<4>([&](auto j) __attribute__((always_inline)) { part[WAVE * 16 + l4 + 4 * j] = s[j()]; });
+            }
+          }
+          __syncthreads();
+          if constexpr (WAVE == 0) {
+            constexpr int SD = TM::slot(J, J);
+            double pi = 0.0;
+            static_for<4>([&](auto j) __attribute__((always_inline)) {
+              const int k = l4 + 4 * j();
+              double v = tvec[16 * J + k];
+              static_for<W>([&](auto w) __attribute__((always_inline)) {
+                if constexpr (TM::has_col(w, J)) v -= part[w * 16 + k];
+              });
+              pi = fma(acc[SD][j()], v, pi);
+            });
+            pi = rows4_total(pi);
+            if (l4 == 0) out[16 * J + l15] = (16 * J + l15 < rE) ? pi : 0.0;
+          }
+          __syncthreads();
+        }
+      });
+    };
+    // ---- forward substitution U' y = rho in place in tvec (refinement only; the first right-hand side rides along
+    //      with the factorisation), left to right:
+    //   (1) every wave: s[i] = sum over its tiles (J, K), K < J, of U(K,J)[.][i]' y_K  (4 multiply-adds per tile, one
+    //       reduction over the four lane rows) -> part[wave][i]
+    //   (2) panel wave: y_J = M_J (rho_J - sum of the parts)
+    auto forward_substitute = [&]() __attribute__((always_inline)) {
+      static_for<NT>([&](auto JJ) __attribute__((always_inline)) {
+        constexpr int J = JJ;
+        if (16 * J < rE) {
+          if constexpr (TM::has_row(WAVE, J)) {
+            double s = 0.0;
+            static_for<J>([&](auto K) __attribute__((always_inline)) {
+              if constexpr (TM::wave(J, K) == WAVE) {
+                constexpr int S = TM::slot(J, K);
+                static_for<4>([&](auto j) __attribute__((always_inline)) {
+                  s = fma(acc[S][j()], tvec[16 * K + l4 + 4 * j()], s);
+                });
+              }
+            });
+            s = rows4_total(s);
+            if (l4 == 0) part[WAVE * 16 + l15] = s;
+          }
+          __syncthreads();
+          if constexpr (WAVE == 0) {
+            constexpr int SD = TM::slot(J, J);
+            double v = tvec[16 * J + l15];
+            static_for<W>([&](auto w) __attribute__((always_inline)) {
+              if constexpr (TM::has_row(w, J)) v -= part[w * 16 + l15];
+            });
+            v = (16 * J + l15 < rE) ? v : 0.0;                        // rhs / padding columns of the last tile carry no unknown
+            d4 q;
+            static_for<4>([&](auto j) __attribute__((always_inline)) { q[j()] = row16_total(acc[SD][j()] * v); });
+            if (l15 == 0) {
+              static_for<4>([&](auto j) __attribute__((always_inline)) { tvec[16 * J + l4 + 4 * j] = q[j()]; });
+            }
+          }
+          __syncthreads();
+        }
+      });
+    };
+    if constexpr (WAVE == 0) {       // conditioning estimate for the refinement trigger: visible after the sweep's barriers
+      if ((REF && P.refine != 0) || refine_flag != nullptr) {
+        double km = kmax, im = imax;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { km = fmax(km, __shfl_xor(km, off, 64)); im = fmax(im, __shfl_xor(im, off, 64)); }
+        const double est = km * im * im;                              // max K_kk * max 1/d_k <= cond(K)
+        if (lane == 0) {
+          red[30] = est;
+          if (refine_flag != nullptr) {
+            // epoch stamps instead of counts: nothing has to be cleared between launches (P.epoch grows by one per launch)
+            const int f = (P.lam != 0.0 && !(est <= P.refine_cond)) ? P.epoch : 0;
+            *refine_flag = f;
+            if (f && refine_count != nullptr) atomicMax(refine_count, P.epoch);
+          }
+          if (stamps != nullptr) stamps[12] = (unsigned long long)__double_as_longlong(est);      // diagnostics
+        }
+      }
+    }
+    back_substitute(beta);
+
+    // ---- iterative refinement: residual with EXACT products with the implicit Hankel matrix,
+    //        rho = t - ( H (H' beta) + lam D beta ),
+    //      solved against the factor at hand.  The Gram route squares cond(H); the residual is evaluated through H
+    //      itself (two products from the trajectory in LDS), so the corrected beta is accurate to cond(H)-level like a
+    //      full-space solve.  Auto mode: only when the pivots say the system is ill-conditioned.
+    if constexpr (REF) {
+    if (P.refine != 0 && P.lam != 0.0) {      // nominal scheme: z = t does not depend on beta, nothing to refine
+      const double cond_lb = red[30];
+      bool go = (P.refine >= 2) || !(cond_lb <= P.refine_cond);       // NaN (failed pivot): falls through harmlessly
+      double prev = 1e300;
+      for (int pass = 0; go && pass < P.refine_max; ++pass) {
+        // alpha = H' beta in chunks that fit the (now free) panel buffer, z += H[:, chunk] alpha[chunk]
+        const int c = P.c;
+        constexpr int CH = 16 * RSB;
+        double zacc[NE];
+        static_for<NE>([&](auto e) __attribute__((always_inline)) { zacc[e()] = 0.0; });
+        for (int i0 = 0; i0 < c; i0 += CH) {
+          const int nc = (c - i0) < CH ? (c - i0) : CH;
+          for (int i = tid; i < nc; i += NTHR) {
+            const double* xp = xs + (long long)(i0 + i) * nch;
+            double s = 0.0;
+            for (int rho = 0; rho < r; ++rho) s = fma(xp[rho], beta[rho], s);
+            PB[i] = s;
+          }
+          __syncthreads();
+          static_for<NE>([&](auto e) __attribute__((always_inline)) {
+            const int rho = tid + e * NTHR;
+            if (rho < r) {
+              const double* xq = xs + (long long)i0 * nch + rho;
+              double s = zacc[e()];
+              for (int ii = 0; ii < nc; ++ii) s = fma(xq[(long long)ii * nch], PB[ii], s);
+              zacc[e()] = s;
             }
           });
-          static_for<4>([&](auto j) __attribute__((always_inline)) { s[j()] = row16_total(s[j()]); });
-          if (l15 == 0) {
-            static_for<4>([&](auto j) __attribute__((always_inline)) { part[WAVE * 16 + l4 + 4 * j] = s[j()]; });
-          }
+          __syncthreads();
         }
+        static_for<NE>([&](auto e) __attribute__((always_inline)) {
+          const int rho = tid + e * NTHR;
+          if (rho < RP) {
+            double rv = 0.0;
+            if (rho < r) {
+              const int s_act = act[rho];
+              const double D = s_act ? cD1[rho] : cD0[rho];
+              const double t = cT[rho] + s_act * P.bound;
+              double db = D * beta[rho];
+              if (P.dense_w) {
+                const double* dr = P.dmat + (long long)rho * RP;
+                for (int j = 0; j < r; ++j) db = fma(dr[j], beta[j], db);
+              }
+              rv = t - zacc[e()] - P.lam * db;
+            }
+            tvec[rho] = rv;
+          }
+        });
         __syncthreads();
-        if constexpr (WAVE == 0) {
-          constexpr int SD = TM::slot(J, J);
-          double pi = 0.0;
-          static_for<4>([&](auto j) __attribute__((always_inline)) {
-            const int k = l4 + 4 * j();
-            double v = tvec[16 * J + k];
-            static_for<W>([&](auto w) __attribute__((always_inline)) {
-              if constexpr (TM::has_col(w, J)) v -= part[w * 16 + k];
-            });
-            pi = fma(acc[SD][j()], v, pi);
-          });
-          {   // sum over the four lane rows without LDS: swap(a, a) pairs rows (0,1) and (2,3), then the halves
-            const d2 s1 = permlane16_swap_f64(pi, pi);
-            pi = s1[0] + s1[1];
-            const auto lo2 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(pi), (unsigned)__double2loint(pi), false, false);
-            const auto hi2 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(pi), (unsigned)__double2hiint(pi), false, false);
-            pi = __hiloint2double((int)hi2[0], (int)lo2[0]) + __hiloint2double((int)hi2[1], (int)lo2[1]);
+        forward_substitute();
+        back_substitute(dvec);                                        // delta (dvec is free: D lives in registers)
+        double dmx = 0.0, bmx = 0.0;
+        static_for<NE>([&](auto e) __attribute__((always_inline)) {
+          const int rho = tid + e * NTHR;
+          if (rho < r) {
+            const double dl = dvec[rho];
+            const double bn = beta[rho] + dl;
+            beta[rho] = bn;
+            dmx = fmax(dmx, fabs(dl)); bmx = fmax(bmx, fabs(bn));
           }
-          if (l4 == 0) beta[16 * J + l15] = (16 * J + l15 < rE) ? pi : 0.0;
-        }
+        });
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { dmx = fmax(dmx, __shfl_xor(dmx, off, 64)); bmx = fmax(bmx, __shfl_xor(bmx, off, 64)); }
+        __syncthreads();
+        if (lane == 0) { red[tid >> 6] = dmx; red[8 + (tid >> 6)] = bmx; }
+        __syncthreads();
+        double dall = 0.0, ball = 0.0;
+        for (int w = 0; w < W; ++w) { dall = fmax(dall, red[w]); ball = fmax(ball, red[8 + w]); }
+        const double rel = dall / fmax(ball, 1e-300);
+        // stop when the correction is at rounding level, or no longer shrinking (or not finite)
+        go = (rel > 1e-13) && (rel < 0.25 * prev);
+        prev = rel;
         __syncthreads();
       }
-    });
+    }
+    }  // REF
     stamp();   // 5
     stamp();   // 6
 
@@ -693,7 +875,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
       const double scale = -P.lam / P.lamb_sigma;
       static_for<NE>([&](auto e) __attribute__((always_inline)) {
         const int rho = tid + e * NTHR;
-        if (rho < r && (cK[e()] == K_WPRED || cK[e()] == K_WTERM)) {   // sigma[n*p:], controller.py:659
+        if (rho < r && (cK[rho] == K_WPRED || cK[rho] == K_WTERM)) {   // sigma[n*p:], controller.py:659
           const double sh = scale * beta[rho];
           const int ns = (sh > P.bound) ? 1 : (sh < -P.bound) ? -1 : 0;
           if (ns != act[rho]) { act[rho] = ns; flags[1] = 1; }
@@ -716,8 +898,8 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
     if (rho < r) {
       const int s_act = act[rho];
       const double b = beta[rho];
-      const double D = s_act ? cD1[e()] : cD0[e()];
-      const double t = cT[e()] + s_act * P.bound;
+      const double D = s_act ? cD1[rho] : cD0[rho];
+      const double t = cT[rho] + s_act * P.bound;
       double z = t - P.lam * D * b;
       if (P.dense_w) {                              // z = t - lam (W^-1 beta): one row of the dense matrix
         const double* dr = P.dmat + (long long)rho * RP;
@@ -730,12 +912,12 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
       const int oidx = P.tabi[2 * RP + rho];
       finite = finite && (fabs(b) < 1e300);
       double contrib = P.lam * b * z;
-      const int kind = cK[e()];
+      const int kind = cK[rho];
       if (P.dense_w && (kind == K_UFREE || kind == K_YFREE || kind == K_WPRED)) {
         contrib -= P.lam * b * (z - tb);
       } else
       if (kind == K_UFREE || kind == K_YFREE) { const double dlt = z - tb; contrib += wq * dlt * dlt; }
-      else if (kind == K_WINT) { const double sg = z - cT[e()]; contrib += P.lamb_sigma * sg * sg; }
+      else if (kind == K_WINT) { const double sg = z - cT[rho]; contrib += P.lamb_sigma * sg * sg; }
       else if (kind == K_WTERM) { const double sg = z - tb; contrib += P.lamb_sigma * sg * sg; }
       else if (kind == K_WPRED) {
         const double sg = (s_act != 0) ? s_act * P.bound : -P.lam * b / P.lamb_sigma;
@@ -763,18 +945,29 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
   }
 }
 
-template <int NT, int W>
+// Grid: the plain variant runs one workgroup per instance (grid = batch).  The refining variant may also be launched as a
+// short persistent grid (nbatch > 0: workgroup g takes instances g, g + gridDim.x, ... and skips the ones `only` filters
+// out): the AUTO refinement pass usually finds few or no flagged instances, and 768 workgroups scanning flags cost less
+// than a batch-sized grid of workgroups that exit at once.
+template <int NT, int W, bool REF>
 __global__ __launch_bounds__(64 * W, DDMPC_MIN_WAVES(NT, W)) void ddmpc_cold_solve_kernel2(
     KParams P, const double* __restrict__ u_d, const double* __restrict__ y_d,
     const double* __restrict__ u_past, const double* __restrict__ y_past, double* __restrict__ u_opt,
     double* __restrict__ cost, int* __restrict__ status, int* __restrict__ iters,
     double* __restrict__ beta_ws, signed char* __restrict__ act_ws, unsigned long long* __restrict__ stamps,
-    double* __restrict__ lfac, double* __restrict__ lfacT, const int* __restrict__ only) {
+    double* __restrict__ lfac, double* __restrict__ lfacT, int* __restrict__ refine_flag,
+    const int* __restrict__ only, long long nbatch, int* __restrict__ refine_count) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const long long b = blockIdx.x;
-  if (only != nullptr && only[b] == 0) return;
   const int tid = threadIdx.x;
   constexpr int NTHR = 64 * W;
+  if constexpr (REF) {
+    // persistent refinement pass: nothing flagged by the plain kernel (the usual case) -> one load and out
+    if (nbatch > 0 && refine_count != nullptr && *refine_count != P.epoch) return;
+  }
+  const long long bend = (REF && nbatch > 0) ? nbatch : (long long)blockIdx.x + 1;
+  const long long bstep = (REF && nbatch > 0) ? (long long)gridDim.x : 1;
+  for (long long b = blockIdx.x; b < bend; b += bstep) {
+  if (only != nullptr && only[b] == 0) continue;
   unsigned long long* st = stamps ? stamps + b * 16 : nullptr;
   if (st && tid == 0) { st[0] = __builtin_amdgcn_s_memtime(); st[15] = __builtin_amdgcn_s_memrealtime(); }
   double* xs = sm + Lds2<NT>::xs;
@@ -814,8 +1007,12 @@ __global__ __launch_bounds__(64 * W, DDMPC_MIN_WAVES(NT, W)) void ddmpc_cold_sol
   double* lft = lfacT ? lfacT + b * (long long)(NT * (NT + 1) / 2 * 256) : nullptr;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   static_for<W>([&](auto WV) {
-    if (wave == WV) wave_body2<NT, W, WV>(P, sm, up, yp, uo, cost + b, status + b, it, bw, aw, st, lf, lft);
+    if (wave == WV)
+      wave_body2<NT, W, WV, REF>(P, sm, up, yp, uo, cost + b, status + b, it, bw, aw, st, lf, lft,
+                                 refine_flag ? refine_flag + b : nullptr, REF ? nullptr : refine_count);
   });
+  if constexpr (REF) __syncthreads();          // persistent grid: LDS is reused by the next instance
+  }
 }
 
 }  // namespace ddmpc

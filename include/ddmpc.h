@@ -88,6 +88,17 @@ extern "C" {
 #define DDMPC_OPT_CLOSED_LOOP_GRAPH 2 /* 1: record the per-step launches of ddmpc_closed_loop into a HIP graph and replay it
                                          (default 0: measured slower than plain asynchronous launches) */
 
+#define DDMPC_OPT_REFINE 3            /* iterative refinement of the cold solve with exact Hankel products (residual
+                                         t - (H(H'beta) + lam D beta) from the trajectory, correction through the factor at hand):
+                                         0 off, 1 auto (default: only when the pivots indicate an ill-conditioned system),
+                                         2 always.  Passes repeat until the correction is at rounding level or stops shrinking. */
+#define DDMPC_REFINE_OFF 0
+#define DDMPC_REFINE_AUTO 1
+#define DDMPC_REFINE_ALWAYS 2
+#define DDMPC_OPT_REFINE_MAX 4        /* cap on refinement passes per factorisation (default 3) */
+#define DDMPC_OPT_REFINE_COND_LOG10 5 /* auto mode: refine when max K_kk * max 1/d_k (pivots d_k; a lower bound of cond K)
+                                         exceeds 10^(value/10), value in tenths of a decade (default 63: 2e6) */
+
 typedef struct ddmpc_handle ddmpc_handle;
 
 /* Controller parameters = the constructor arguments of

@@ -735,7 +735,8 @@ def test_batched_example_script(gpu, tmp_path):
                          capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("    Time step:")]
-    assert len(lines) == 41 and "MPC cost value:" in lines[0] and "u_1e =" in lines[0] and "y_2e =" in lines[0]
+    # one line per solve (n_mpc_step = n = 4: t = 0, 4, ..., 40), as controller_operation.py:310-329 prints them
+    assert len(lines) == 11 and "MPC cost value:" in lines[0] and "u_1e =" in lines[0] and "y_2e =" in lines[0]
     z = np.load(out)
     assert z["u_sys"].shape == (8, 41, 2) and np.all(z["status"] == 0)
     # instance 0 is the reference example with --seed 0: same closed loop as the oracle (n-step scheme, n = 4)
@@ -872,21 +873,31 @@ def test_random_systems_against_oracle(gpu, case):
     up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
     with _engine(spec, N, B) as eng:
         eng.set_data(d["u_d"], d["y_d"])
+        # Random plants have output gains of order 1-10 against a noise level of 0.002, so the y rows of H are nearly
+        # dependent on its u rows: cond(H) reaches 1e5-5e6 (four-tank data: ~1.3e3) and the Gram route, which squares
+        # it, is good to 1e-9..1e-7 only.  With iterative refinement (residual through two exact products with the
+        # implicit Hankel matrix) the kernels meet the standard bars.
+        eng.set_refinement("always")
         u, cost, status, iters = eng.solve(up, yp)
         uw, cw, sw, iw = eng.step(up, yp)
     for b in range(B):
         sol = orc.solve_fullspace(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
         assert L.STATUS_STRINGS[int(status[b])] == sol.status == "optimal"
         scale = max(np.max(np.abs(sol.optimal_u)), 1e-3)
-        # Random plants have output gains of order 1-10 against a noise level of 0.002, so the y rows of H are
-        # nearly dependent on its u rows: cond(H) reaches 1e5-5e5 (four-tank data: ~1.3e3).  The kernels factor the
-        # Gram matrix, which squares that; the cost then agrees with the full-space oracle to ~3e-9 (GPU and numpy
-        # reduced form alike), hence 10x wider tolerances in this sweep only.
-        assert np.max(np.abs(u[b] - sol.optimal_u)) / scale < 10 * TOL_U, (case, b)
-        assert abs(cost[b] - sol.cost) <= 20 * TOL_COST * max(abs(sol.cost), 1e-6), (case, b)
+        if robust:
+            assert np.max(np.abs(u[b] - sol.optimal_u)) / scale < TOL_U, (case, b)
+            assert abs(cost[b] - sol.cost) <= TOL_COST * max(abs(sol.cost), 1e-6), (case, b)
+        else:
+            # nominal scheme on noisy (full-row-rank) data: every trajectory is reachable, so the optimum is the setpoint
+            # itself -- u = tile(u_s), cost 0 -- which the kernel returns exactly.  The full-space oracle solves a singular
+            # KKT system by truncated least squares and is the LESS accurate side here (up to 2e-7 on these plants):
+            us_t = np.tile(spec.u_s, Lh)
+            assert np.max(np.abs(u[b] - us_t)) <= 1e-12 * scale and abs(cost[b]) <= 1e-12, (case, b)
+            assert np.max(np.abs(sol.optimal_u - us_t)) / scale < 1e-6 and abs(sol.cost) < 1e-8, (case, b)
         if spec.slack == "convex":
             assert int(iters[b]) == sol.iters
-    assert np.max(np.abs(uw - u)) <= 1e-10 * max(np.max(np.abs(u)), 1e-3) and np.array_equal(sw, status) and np.array_equal(iw, iters)
+    # the warm step's affine law is formed from the (unrefined) Gram-route factor: Gram-route accuracy
+    assert np.max(np.abs(uw - u)) <= 10 * TOL_U * max(np.max(np.abs(u)), 1e-3) and np.array_equal(sw, status) and np.array_equal(iw, iters)
 
 
 def test_noise_free_data(gpu):

@@ -254,3 +254,50 @@ def test_set_stream_is_idempotent_and_orders_streams(gpu):
         s.synchronize()
         for o in outs:
             assert all(torch.equal(a, b) for a, b in zip(o, ref))
+
+
+# ------------------------------------------------------------------ refinement with exact Hankel products (cold kernel)
+def test_auto_refinement_flags_ill_conditioned_instances_only(gpu):
+    # default (DDMPC_REFINE_AUTO): the plain kernel flags instances whose pivots bound cond(K) from below by more than
+    # the threshold and only those are solved again by the refining variant.  Benchmark data: nothing flagged, results
+    # bit-equal to refinement OFF.  An ill-conditioned plant (random, high output gain against the noise level): AUTO
+    # equals ALWAYS and meets the standard bars, OFF does not.
+    import test_gpu_parity as T
+    spec = orc.spec_from_params()
+    B = 16
+    d = harness.generate_batch(range(B))
+    up = d["u_d"][:, -4:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -4:, :].reshape(B, -1).copy()
+    with _spec_engine(spec, 400, B) as eng:
+        eng.set_data(d["u_d"], d["y_d"])
+        eng.set_refinement("off"); u0, c0, s0, _ = (x.copy() for x in eng.solve(up, yp))
+        eng.set_refinement("auto"); u1, c1, s1, _ = (x.copy() for x in eng.solve(up, yp))
+        eng.set_refinement("always"); u2, c2, s2, _ = (x.copy() for x in eng.solve(up, yp))
+    assert np.array_equal(u0, u1) and np.array_equal(c0, c1)
+    assert np.max(np.abs(u2 - u0)) / np.max(np.abs(u0)) < 1e-10           # well-conditioned: refinement changes nothing visible
+    rng = np.random.default_rng(1017)                                       # case 17 of the random-plant sweep: cond_lb ~ 2e7
+    m, p, ns = 2, 3, 4
+    plant = T._random_plant(np.random.default_rng(1017), ns, m, p, 0.002)
+    Lh, N = 16, 200
+    spec = orc.QPSpec(n=ns, m=m, p=p, L=Lh, Q=2.0 * np.eye(p * Lh), R=0.05 * np.eye(m * Lh), u_s=rng.uniform(-0.5, 0.5, m),
+                      y_s=rng.uniform(-0.5, 0.5, p), robust=True, eps_max=0.002, lamb_alpha=20.0, lamb_sigma=500.0, c=1.0,
+                      slack="none", tec=True)
+    B = 6
+    d = harness.generate_batch(range(170, 170 + B), N=N, plant=plant)
+    up = d["u_d"][:, -ns:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -ns:, :].reshape(B, -1).copy()
+    out = {}
+    with _spec_engine(spec, N, B) as eng:
+        eng.set_data(d["u_d"], d["y_d"])
+        for mode in ("off", "auto", "always"):
+            eng.set_refinement(mode)
+            out[mode] = tuple(x.copy() for x in eng.solve(up, yp))
+    err = {}
+    for mode, (u, c, s, _) in out.items():
+        eu = ec = 0.0
+        for b in range(B):
+            sol = orc.solve_fullspace(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
+            eu = max(eu, np.max(np.abs(u[b] - sol.optimal_u)) / np.max(np.abs(sol.optimal_u)))
+            ec = max(ec, abs(c[b] - sol.cost) / abs(sol.cost))
+        err[mode] = (eu, ec)
+    assert err["always"][0] < TOL_U and err["always"][1] < TOL_COST, err
+    assert err["auto"][0] < TOL_U and err["auto"][1] < TOL_COST, err
+    assert err["off"][0] > 10 * err["always"][0], err                          # the Gram route alone is visibly worse here

@@ -20,16 +20,16 @@ eng.solve(up, yp)
 eng.debug_stamps(True)
 eng.solve(up, yp)
 st = eng.debug_stamps(False, fetch=True).astype(np.int64)
-names = ["staging+tables", "lag blocks (4x4x4)", "base tiles + walks", "cholesky", "(chol exit)", "back substitution", "-", "-"]
+names = ["staging+tables", "lag blocks (4x4x4)", "base tiles + walks", "fix-up + cholesky", "y + back substitution (+ refinement)", "-", "-", "-"]
 dt = np.diff(st[:, :8], axis=1)
 tot = st[:, 14] - st[:, 0]
 real = (st[:, 13] - st[:, 15]) * 10.0   # ns
 print("kernel", eng.kernel_name(), "B", B, "gram_mode", gram)
-for i, nm in enumerate(names[:6]):
+for i, nm in enumerate(names[:5]):
     col = dt[:, i]
-    print("%-16s median %8.0f  p10 %8.0f  p90 %8.0f cycles" % (nm, np.median(col), np.percentile(col, 10), np.percentile(col, 90)))
+    print("%-38s median %8.0f  p10 %8.0f  p90 %8.0f cycles" % (nm, np.median(col), np.percentile(col, 10), np.percentile(col, 90)))
 print("%-16s median %8.0f cycles; real time median %.1f us; clock %.2f GHz" % ("total", np.median(tot), np.median(real) / 1e3, np.median(tot / np.maximum(real, 1))))
 ph = st[:, 7:12]
-for i, nm in enumerate(["chol: extract", "chol: barrier1", "chol: factor+row", "chol: barrier2", "chol: operands+mfma+wb"]):
-    print("%-24s median %8.0f cycles (sum over steps, wave 0)" % (nm, np.median(ph[:, i])))
+for i, nm in enumerate(["chol: panel wave in-tile factorisation (+ its diag updates)", "chol: wait at barrier B", "chol: TRSM (panel wave: none)", "chol: wait at barriers A1+A2", "chol: next-diagonal update"]):
+    print("%-60s median %8.0f cycles (sum over steps, wave 0)" % (nm, np.median(ph[:, i])))
 print("span first entry -> last exit: %.1f us" % ((st[:, 13].max() - st[:, 15].min()) * 10.0 / 1e3))

@@ -68,6 +68,20 @@ def timing(B=4096, slack=0, stamps=True):
 
 if __name__ == "__main__":
     import os
+    if len(sys.argv) > 1 and sys.argv[1] == "ref":         # refinement modes, in-process
+        for rep in range(3):
+            for ref in ("0", "1"):
+                os.environ["DDMPC_REFINE"] = ref
+                print("DDMPC_REFINE=%s" % ref, end="  ")
+                timing(4096, 0, stamps=False)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "gen":         # in-process A/B of the kernel generations (v1 = the clock reference of the box)
+        for rep in range(3):
+            for gen, ref in (("1", "0"), ("2", "0"), ("2", "1"), ("2", "2")):
+                os.environ["DDMPC_KERNEL"] = gen; os.environ["DDMPC_REFINE"] = ref
+                print("DDMPC_KERNEL=%s DDMPC_REFINE=%s" % (gen, ref), end="  ")
+                timing(4096, 0, stamps=False)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ab":          # in-process A/B of development switches (same box, same clocks)
         for rep in range(3):
             for dev in sys.argv[2:]:
