@@ -725,8 +725,8 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
     lds = vec_bytes;
   }
   if (lds + 1024 > 160 * 1024) return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: %zu rows", r);
-  {   // c-vector per instance for the products with the implicit Hankel matrix (refinement step)
-    int rca = h->d_alpha.ensure((size_t)h->batch * (size_t)h->kp.c * sizeof(double));
+  {   // per instance: a c-vector for the products with the implicit Hankel matrix + the r-vector w of the refinement passes
+    int rca = h->d_alpha.ensure((size_t)h->batch * ((size_t)h->kp.c + (size_t)h->kp.r) * sizeof(double));
     if (rca) return rca;
   }
   {   // z per component + "rescued" flag per instance, read by ddmpc_get_solution

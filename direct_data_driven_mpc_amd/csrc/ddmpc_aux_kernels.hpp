@@ -928,6 +928,18 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return t;
 }
 
+// Maximum of one value per thread over the workgroup (all threads get it).
+__device__ __forceinline__ double block_max(double v, double* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = fmax(t, red[w]);
+  return t;
+}
+
 __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int RPs, const double* __restrict__ u_d,
                                                                const double* __restrict__ y_d,
                                                                const double* __restrict__ u_past,
@@ -1134,9 +1146,18 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   //      B and B' are applied EXACTLY -- two products with the implicit Hankel matrix and one triangular solve each --
   //      while the correction is solved with the factors at hand (L in place of B).  The Gram route squares cond(H);
   //      this step brings the result back to what cond(H) itself allows.
-  double* alpha = alpha_ws + b * (long long)c;
+  double* alpha = alpha_ws + b * (long long)(c + r);
+  double* wk = alpha + c;                                               // the current w = [w1; w2], position order
+  for (int k = tid; k < r; k += nthr) wk[k] = (k < nF) ? col[k] : vv[k - nF];
+  __syncthreads();
+  // The pass is repeated while it still pays: the correction of pass k is applied through the rounded factors, so the
+  // error left behind is about (relative size of that correction) x (relative accuracy of the factors ~ size of the FIRST
+  // correction); another pass is made while that product is above 1e-11 (cap P.refine_max, at least one pass).
+  double rel0 = 0.0, prevrel = 1e300;
+  for (int pass = 0;; ++pass) {
+  for (int a = tid; a < nR; a += nthr) vv[a] = wk[nF + a];             // w2 of this pass ((b) below reads it)
   // (a) z_ex = B w:  w (position order) -> x = L^-T w (zero on rows without a pivot) -> H' x -> H (H' x)
-  for (int k = tid; k < r; k += nthr) ra[k] = (k < nF) ? col[k] : vv[k - nF];
+  for (int k = tid; k < r; k += nthr) ra[k] = wk[k];
   __syncthreads();
   packed_back_substitute(G, r, ra, rb, skip);
   for (int k = tid; k < r; k += nthr) ra[perm[k]] = rb[k];           // component order
@@ -1188,11 +1209,26 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
     double sacc = 0.0;
     if (!skip[nF + a])
       for (int i = a; i < nR; ++i) sacc += G[(size_t)(nF + i) * (nF + i + 1) / 2 + nF + a] * wv[i] * rd[nF + i];
-    vv[a] = skip[nF + a] ? 0.0 : -ra[nF + a] - sacc;                      // rhs of the T system (w2 itself is no longer needed)
+    vv[a] = skip[nF + a] ? 0.0 : -ra[nF + a] - sacc;                      // rhs of the T system
   }
   __syncthreads();
-  packed_forward_substitute(T, nR, vv, col, skipT, red);                 // col: free now (w1 was consumed in (a))
+  packed_forward_substitute(T, nR, vv, col, skipT, red);                 // col: work vector (w lives in wk)
   packed_back_substitute(T, nR, col, vv, skipT);                         // dw2 -> vv
+  // size of this correction relative to w; decide whether another pass pays
+  double dmx = 0.0, wmx = 0.0;
+  for (int k = tid; k < r; k += nthr) {
+    const double dl = (k < nF) ? rb[k] : vv[k - nF];
+    dmx = fmax(dmx, fabs(dl)); wmx = fmax(wmx, fabs(wk[k]));
+  }
+  const double rel = block_max(dmx, red) / fmax(block_max(wmx, red), 1e-300);
+  if (pass == 0) rel0 = rel;
+  const bool more_passes = (pass + 1 < P.refine_max) && (rel * rel0 > 1e-11) && (rel < 0.25 * prevrel);
+  __syncthreads();
+  if (!more_passes) break;
+  prevrel = rel;
+  for (int k = tid; k < r; k += nthr) wk[k] += (k < nF) ? rb[k] : vv[k - nF];
+  __syncthreads();
+  }
   // ---- z_R = z_ex,R + L_RF dw1 + C dw2; outputs ------------------------------------------------------
   double part = 0.0;
   double* uo = u_opt + b * (long long)((P.Ln - n) * m);
@@ -1443,6 +1479,9 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
     //      block factors of the final active set.  The Gram route squares cond(H); with K applied as H H' the result
     //      is what cond(H) itself allows (cfg-5 size: 1e-7 -> 1e-10 in optimal_u).
     double* alpha = alpha_ws + b * (long long)P.c;
+    // passes repeat until the correction is at rounding level or stops shrinking (cap P.refine_max); DDMPC_REFINE_OFF skips them
+    double prev = 1e300;
+    for (int pass = 0; P.refine != 0 && pass < P.refine_max; ++pass) {
     for (int i = tid; i < r; i += nthr) qa[perm[i]] = bv[i];            // beta in component order
     __syncthreads();
     hankel_transpose_times(P, ud, yd, qa, alpha);
@@ -1475,8 +1514,17 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
     }
     __syncthreads();
     packed_back_substitute(G, nA, qb, qa, nullptr);                      // dbeta_A -> qa[0..nA)
-    for (int i = tid; i < r; i += nthr) bv[i] += qa[i];
+    double dmx = 0.0, bmx = 0.0;
+    for (int i = tid; i < r; i += nthr) {
+      const double bn = bv[i] + qa[i];
+      dmx = fmax(dmx, fabs(qa[i])); bmx = fmax(bmx, fabs(bn));
+      bv[i] = bn;
+    }
+    const double rel = block_max(dmx, red) / fmax(block_max(bmx, red), 1e-300);
     __syncthreads();
+    if (!(rel > 1e-13) || !(rel < 0.25 * prev)) break;
+    prev = rel;
+    }
   }
   // ---- outputs: z = t - lam*D*beta; cost = control cost + lam*beta'z + lamb_sigma*|sigma|^2 --------------------
   double part = 0.0, bad = 0.0;

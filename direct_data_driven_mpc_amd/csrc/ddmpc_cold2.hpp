@@ -503,7 +503,11 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
     };
     auto no_pend = [](auto) __attribute__((always_inline)) {};
     auto factor_begin = [&](const d4& Ad, d4& Et) __attribute__((always_inline)) {
-      static_for<4>([&](auto j) __attribute__((always_inline)) { Et[j()] = (l4 + 4 * j() == l15) ? -1.0 : 0.0; });
+      // (opaque lane id: otherwise the -identity pattern is hoisted out of the tile loop as four loop-invariant doubles,
+      //  which then live in scratch memory and are reloaded on the critical path of every diagonal tile)
+      int lz = lane;
+      asm volatile("" : "+v"(lz));
+      static_for<4>([&](auto j) __attribute__((always_inline)) { Et[j()] = ((lz >> 4) + 4 * j() == (lz & 15)) ? -1.0 : 0.0; });
       if (lo == 0) {
         static_for<4>([&](auto j) __attribute__((always_inline)) {
           PT2[(l4 + 4 * j) * 4 + l3] = Ad[j()];

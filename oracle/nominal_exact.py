@@ -69,3 +69,53 @@ def solve_nominal_exact(spec: QPSpec, u_d, y_d, u_past, y_past, rank_tol: float 
     status = "optimal" if residual <= feas_tol * scale else "infeasible"
     return dict(status=status, optimal_u=z[:Ln * m][n * m:], cost=float(np.sum(W * (z[R] - zs) ** 2)),
                 residual=residual, rank=k)
+
+
+def solve_nominal_model_based(spec, plant, u_past, y_past):
+    """The nominal QP on EXACT data restated on a basis of the plant's own trajectory space built from (A, B, C)
+    (D = 0): every noise-free trajectory of length L+n is [u; y] = M [x_0; u], so range(H) = range(M) whenever the data
+    are persistently exciting.  Not data-driven and well conditioned (no Hankel matrix, no Gram matrix): the yardstick
+    for the GPU kernels AND for the SVD route above on exact data, where the latter is only ~1e-8 accurate at
+    cfg-5 size.  Returns optimal_u = ubar[n*m:] and the cost.  TEST INFRASTRUCTURE ONLY."""
+    n, m, p, Lh = spec.n, spec.m, spec.p, spec.L
+    Ln = Lh + n
+    A_, B_, C_ = (np.asarray(plant[k], float) for k in ("A", "B", "C"))
+    ns = A_.shape[0]
+    u_s = np.asarray(spec.u_s, float).reshape(-1); y_s = np.asarray(spec.y_s, float).reshape(-1)
+    u_past = np.asarray(u_past, float).reshape(-1); y_past = np.asarray(y_past, float).reshape(-1)
+    rdiag, qdiag = np.diag(spec.R), np.diag(spec.Q)
+    M = np.zeros((Ln * (m + p), ns + Ln * m))
+    for k in range(Ln):
+        M[k * m:(k + 1) * m, ns + k * m: ns + (k + 1) * m] = np.eye(m)
+    Ak = np.eye(ns); O = []
+    for k in range(Ln):
+        O.append(C_ @ Ak); Ak = A_ @ Ak
+    for k in range(Ln):
+        M[Ln * m + k * p: Ln * m + (k + 1) * p, :ns] = O[k]
+        for j in range(k):
+            M[Ln * m + k * p: Ln * m + (k + 1) * p, ns + j * m: ns + (j + 1) * m] = O[k - 1 - j] @ B_
+    F, R, f, W, zs = [], [], [], [], []
+    for k in range(Ln):
+        kp = k - n
+        for ch in range(m):
+            i = k * m + ch
+            if kp < 0: F.append(i); f.append(u_past[k * m + ch])
+            elif spec.tec and kp >= Lh - n: F.append(i); f.append(u_s[ch])
+            else: R.append(i); W.append(rdiag[kp * m + ch]); zs.append(u_s[ch])
+    for k in range(Ln):
+        kp = k - n
+        for ch in range(p):
+            i = Ln * m + k * p + ch
+            if kp < 0: F.append(i); f.append(y_past[k * p + ch])
+            elif spec.tec and kp >= Lh - n: F.append(i); f.append(y_s[ch])
+            else: R.append(i); W.append(qdiag[kp * p + ch]); zs.append(y_s[ch])
+    f, W, zs = np.array(f), np.array(W), np.array(zs)
+    Qb, _ = np.linalg.qr(M)
+    Uf, Sf, Vft = np.linalg.svd(Qb[F], True)
+    kf = int(np.sum(Sf > Sf[0] * 1e-9))
+    c_p = Vft[:kf].T @ ((Uf[:, :kf].T @ f) / Sf[:kf]); Nn = Vft[kf:].T
+    sw = np.sqrt(W)
+    dd = np.linalg.lstsq(sw[:, None] * (Qb[R] @ Nn), sw * (zs - Qb[R] @ c_p), rcond=None)[0]
+    z = Qb @ (c_p + Nn @ dd)
+    return dict(optimal_u=z[:Ln * m][n * m:], cost=float(np.sum(W * (z[R] - zs) ** 2)),
+                feas_residual=float(np.max(np.abs(Qb[F] @ c_p - f))))

@@ -1170,22 +1170,29 @@ def test_nominal_rank_revealing_with_global_workspace(gpu):
     with _engine(spec, N, B) as eng:
         eng.set_data(d["u_d"], d["y_d"])
         u, cost, status, _ = eng.solve(up, yp)
+    from oracle.nominal_exact import solve_nominal_model_based
     for b in range(B):
         ref = solve_nominal_exact(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
+        mod = solve_nominal_model_based(spec, plant, up[b], yp[b])       # the well-conditioned yardstick (see the cfg-5 test)
         assert ref["status"] == "optimal" and int(status[b]) == 0
-        assert np.max(np.abs(u[b] - ref["optimal_u"])) / np.max(np.abs(ref["optimal_u"])) < 1e-7, b
-        assert abs(cost[b] - ref["cost"]) <= 1e-7 * abs(ref["cost"])
+        sc = np.max(np.abs(mod["optimal_u"]))
+        assert np.max(np.abs(u[b] - mod["optimal_u"])) / sc < TOL_U, b
+        assert abs(cost[b] - mod["cost"]) <= TOL_COST * abs(mod["cost"]), b
+        if np.max(np.abs(ref["optimal_u"] - mod["optimal_u"])) / sc < 3e-9:
+            assert np.max(np.abs(u[b] - ref["optimal_u"])) / sc < TOL_U, b
 
 
 def test_config5_size_nominal_runs_on_the_rank_revealing_kernel(gpu):
     # BASELINE configs[4]: nominal scheme, m = p = 8, n = 8, L = 30, N = 2000, noise-free data of a random stable
     # plant (SURVEY section 8 proposal): r = 608 rows, rank 312.  No register-resident kernel holds that; the
-    # rank-revealing kernel runs it with its matrices in a global workspace.  Measured against the SVD-based CPU
-    # solve over all 512 instances of the configuration: 2.1e-8 in optimal_u, 5e-13 in the cost
-    # (tools/config5_check.py, profiles/r01_cfg5_parity.log); the Gram route squares the conditioning, and a numpy
-    # prototype on another random plant of this size reached only 4e-6, hence 1e-7 here
-    # rather than the 1e-8 of the well-conditioned configurations: partial parity, stated as such.
-    from oracle.nominal_exact import solve_nominal_exact
+    # rank-revealing kernel runs it with its matrices in a global workspace, Gram route + adaptive refinement passes with
+    # exact Hankel products.  Checked on 32 instances of the configuration against
+    #   (i) a MODEL-BASED solve of the same QP (trajectory space from (A, B, C), no Hankel / Gram matrix: well conditioned)
+    #       at the standard bar 1e-8 / 1e-9, and
+    #  (ii) the SVD-based data-driven CPU solve (oracle/nominal_exact.py), which at this size is itself only ~1e-8 accurate
+    #       (exact data rounded to fp64, cond(H) ~ 1e6): wherever the two CPU solves agree to 3e-9 the GPU must meet the
+    #       standard bar against the SVD route too; where they do not, the test shows that the SVD route is the one that is off.
+    from oracle.nominal_exact import solve_nominal_exact, solve_nominal_model_based
     rng = np.random.default_rng(0)
     ns = n = 8; m = p = 8; Lh = 30; N = 2000
     A = rng.normal(size=(ns, ns)); A *= 0.9 / max(abs(np.linalg.eigvals(A)))
@@ -1194,7 +1201,7 @@ def test_config5_size_nominal_runs_on_the_rank_revealing_kernel(gpu):
     y_s = (plant["C"] @ np.linalg.inv(np.eye(ns) - A) @ plant["B"]) @ u_s
     spec = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=3.0 * np.eye(p * Lh), R=1e-4 * np.eye(m * Lh), u_s=u_s, y_s=y_s, robust=False,
                       eps_max=0.0, lamb_alpha=0.0, lamb_sigma=0.0, c=0.0, slack="none", tec=True)
-    B = 2
+    B = 32
     d = generate_batch(range(B), N=N, plant=plant)
     up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
     with _engine(spec, N, B) as eng:
@@ -1203,13 +1210,28 @@ def test_config5_size_nominal_runs_on_the_rank_revealing_kernel(gpu):
         assert np.all(ok) and np.all(rank == m * (Lh + 2 * n))
         eng.set_data(d["u_d"], d["y_d"])
         u, cost, status, _ = eng.solve(up, yp)
+        ub = eng.get_solution("ubar")
         with pytest.raises(L.DDMPCError):
             eng.gain()
+    assert np.all(status == 0) and np.array_equal(ub[:, n * m:], u)
+    n_svd_off = 0
     for b in range(B):
-        ref = solve_nominal_exact(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
-        assert ref["status"] == "optimal" and ref["rank"] == m * (Lh + n) + ns and int(status[b]) == 0
-        assert np.max(np.abs(u[b] - ref["optimal_u"])) / np.max(np.abs(ref["optimal_u"])) < 2e-8, b   # see DESIGN 9: the SVD
-        assert abs(cost[b] - ref["cost"]) <= 1e-9 * abs(ref["cost"])                                     # oracle is ~1e-8 here
+        mod = solve_nominal_model_based(spec, plant, up[b], yp[b])
+        sc = np.max(np.abs(mod["optimal_u"]))
+        assert mod["feas_residual"] < 1e-10
+        assert np.max(np.abs(u[b] - mod["optimal_u"])) / sc < TOL_U, b
+        assert abs(cost[b] - mod["cost"]) <= TOL_COST * abs(mod["cost"]), b
+        if b < 8:                                       # the SVD route takes ~2 s per instance
+            ref = solve_nominal_exact(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
+            assert ref["status"] == "optimal" and ref["rank"] == m * (Lh + n) + ns
+            svd_vs_model = np.max(np.abs(ref["optimal_u"] - mod["optimal_u"])) / sc
+            gpu_vs_svd = np.max(np.abs(u[b] - ref["optimal_u"])) / sc
+            if svd_vs_model < 3e-9:
+                assert gpu_vs_svd < TOL_U, b
+            else:
+                n_svd_off += 1
+                assert np.max(np.abs(u[b] - mod["optimal_u"])) / sc < svd_vs_model, b      # the GPU is the closer of the two
+            assert abs(cost[b] - ref["cost"]) <= TOL_COST * abs(ref["cost"])
     # the robust scheme at this size runs on ddmpc_large_solve_kernel (noisy data of the same plant)
     specr = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=3.0 * np.eye(p * Lh), R=1e-4 * np.eye(m * Lh), u_s=u_s, y_s=y_s, robust=True,
                        eps_max=0.002, lamb_alpha=50.0, lamb_sigma=1000.0, c=1.0, slack="convex", tec=True)

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collect the per-round evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh <tag>         e.g. r01_final
+#   bash tools/collect_profiles.sh <tag>         e.g. r02_final
 # Writes everything under gpurun_out/<tag>/; copy the summaries into profiles/ afterwards.
 # Counter passes are separate runs with --pmc only (no trace domains), as the pool requires.
 set -e -o pipefail
-TAG=${1:-r01_final}
+TAG=${1:-r02_final}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf "$OUT"

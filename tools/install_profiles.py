@@ -11,7 +11,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
 KERNEL = "ddmpc_cold_solve_kernel"
@@ -42,6 +42,7 @@ for row in csv.DictReader(open(one("stats/*/*_kernel_stats.csv"))):
     if KERNEL in row["Name"]:
         print("rocprof: %s calls, avg %.1f us" % (row["Calls"], float(row["AverageNs"]) / 1e3))
 
+traffic = {}
 for name in ("fetch", "write", "sq", "sq2"):
     f = one("pmc_%s/*/*_counter_collection.csv" % name)
     rows = [r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"]]
@@ -56,3 +57,17 @@ for name in ("fetch", "write", "sq", "sq2"):
     print("pmc %-5s VGPR %s scratch %s B/lane LDS %s" % (name, meta["VGPR_Count"], meta["Scratch_Size"], meta["LDS_Block_Size"]))
     for k, v in acc.items():
         print("    %-28s n=%d mean %.6g" % (k, len(v), sum(v) / len(v)))
+        if k in ("FETCH_SIZE", "WRITE_SIZE"):
+            traffic[k] = sum(v) / len(v)
+
+# HBM bytes per launch for bench.py's roofline.traffic, keyed by the hash of the kernel sources the run was built from
+# (FETCH_SIZE x2: gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md "HBM"; both counters are in KB)
+if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
+    entry = dict(kernel=KERNEL, code_hash=b["config"]["kernel_source_hash"], batch=b["config"]["global_batch"], slack="none",
+                 fetch_kb=traffic["FETCH_SIZE"], write_kb=traffic["WRITE_SIZE"],
+                 traffic_bytes=int((2 * traffic["FETCH_SIZE"] + traffic["WRITE_SIZE"]) * 1024), source=tag + "_pmc_fetch.csv / _pmc_write.csv")
+    path = os.path.join(dst, "traffic.json")
+    tab = json.load(open(path)) if os.path.exists(path) else {"entries": []}
+    tab["entries"] = [e for e in tab["entries"] if not (e["kernel"] == KERNEL and e["batch"] == entry["batch"] and e.get("slack") == "none")] + [entry]
+    json.dump(tab, open(path, "w"), indent=1)
+    print("traffic.json: %s -> %.1f MB per launch (hash %s)" % (KERNEL, entry["traffic_bytes"] / 1e6, entry["code_hash"]))
