@@ -235,6 +235,12 @@ static bool spd_inverse(std::vector<double>& a, int n) {
   return true;
 }
 
+// 1/w of an unweighted (w = 0) component: K_ii = lam * 1e25 makes its multiplier beta_i = (t_i - (G beta)_i) / (lam 1e25),
+// zero to ~1e-25 relative, and z_i = t_i - lam D beta_i = (G beta)_i exactly as for a free component; every other
+// pivot sees a perturbation of order G_ij^2 / 1e25.
+static const double DDMPC_UNWEIGHTED = 1e25;
+static inline double inv_weight(double w) { return w > 0.0 ? 1.0 / w : DDMPC_UNWEIGHTED; }
+
 static int upload_params(ddmpc_handle* h) {
   const ddmpc_params& p = h->prm;
   const KParams& k = h->kp;
@@ -258,7 +264,7 @@ static int upload_params(ddmpc_handle* h) {
         if (is_int) { kind = K_UFIX; pidx = kk * p.m + ch; }
         else if (is_term) { kind = K_UFIX; }
         else if (dense) { kind = K_UFREE; }
-        else { kind = K_UFREE; wq = diag ? h->Rh[kp * p.m + ch] : h->Rh[0]; D0 = D1 = 1.0 / wq; }
+        else { kind = K_UFREE; wq = diag ? h->Rh[kp * p.m + ch] : h->Rh[0]; D0 = D1 = inv_weight(wq); }
         if (!is_int) oidx = kp * p.m + ch;
       } else {
         const int cy = ch - p.m;
@@ -268,13 +274,13 @@ static int upload_params(ddmpc_handle* h) {
         if (!robust) {
           if (is_int) { kind = K_YFIX; pidx = p.n * p.m + kk * p.p + cy; }
           else if (is_term) { kind = K_YFIX; }
-          else { kind = K_YFREE; if (!dense) D0 = D1 = 1.0 / q; }
+          else { kind = K_YFREE; if (!dense) D0 = D1 = inv_weight(q); }
         } else {
           const double ils = 1.0 / p.lamb_sigma;
           if (is_int) { kind = K_WINT; pidx = p.n * p.m + kk * p.p + cy; D0 = D1 = ils; }
           else if (is_term) { kind = K_WTERM; D0 = ils; D1 = 0.0; }
-          else if (dense) { kind = K_WPRED; }
-          else { kind = K_WPRED; D0 = 1.0 / q + ils; D1 = 1.0 / q; }
+          else if (dense) { kind = K_WPRED; D0 = ils; D1 = 0.0; }    // + Q_ff^-1 from the dense matrix
+          else { kind = K_WPRED; D0 = inv_weight(q) + ils; D1 = inv_weight(q); }
         }
       }
     }
@@ -299,7 +305,8 @@ static int upload_params(ddmpc_handle* h) {
     // fixed to the setpoint (controller.py:612-627), so their rows/columns of Q, R drop out of the cost.
     //   ubar free:            W = R_ff                      -> W^-1 = R_ff^-1
     //   ybar free (nominal):  W = Q_ff                      -> W^-1 = Q_ff^-1
-    //   ybar+sigma free:      min over the split of q-form + lamb_sigma |sigma|^2 -> W^-1 = Q_ff^-1 + I/lamb_sigma
+    //   ybar+sigma free:      min over the split of q-form + lamb_sigma |sigma|^2 -> W^-1 = Q_ff^-1 + P_I/lamb_sigma,
+    //                         P_I = the components whose sigma is NOT at its bound: the slack box only switches a diagonal term
     // Diagonal-only components (internal / terminal sigma) keep their tabd entries.
     const int nfree = tec ? p.L - p.n : p.L;
     std::vector<double> dm((size_t)RP * RP, 0.0);
@@ -316,9 +323,8 @@ static int upload_params(ddmpc_handle* h) {
         for (int j = 0; j < nn; ++j) {
           const int ri = (p.n + i / nc) * k.nch + (pass == 0 ? 0 : p.m) + i % nc;
           const int rj = (p.n + j / nc) * k.nch + (pass == 0 ? 0 : p.m) + j % nc;
-          double v = a[(size_t)i * nn + j];
-          if (pass == 1 && robust && i == j) v += 1.0 / p.lamb_sigma;
-          dm[(size_t)ri * RP + rj] = v;
+          dm[(size_t)ri * RP + rj] = a[(size_t)i * nn + j];     // (robust y rows: + 1/lamb_sigma on the diagonal via tabd,
+                                                                  //  switched off for a sigma at its bound)
         }
     }
     if ((rc = h->d_dmat.ensure(dm.size() * sizeof(double)))) return rc;
@@ -368,13 +374,13 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   const size_t nq = wdense ? pl * pl : (p.weight_kind == DDMPC_WEIGHT_DIAG ? pl : 1);
   const size_t nr = wdense ? ml * ml : (p.weight_kind == DDMPC_WEIGHT_DIAG ? ml : 1);
   if (!wdense) {
+    // scalar / diagonal weights may be positive SEMI-definite (controller.py:708-710 accepts any PSD matrix): a zero weight
+    // leaves that component unpenalised, i.e. its multiplier is zero -- realised as 1/w = DDMPC_UNWEIGHTED (see upload_params)
     for (size_t i = 0; i < nq; ++i)
-      if (!(p.Q[i] > 0.0)) return fail(DDMPC_ERR_UNSUPPORTED, "Q must have a strictly positive diagonal on the HIP path");
+      if (!(p.Q[i] >= 0.0)) return fail(DDMPC_ERR_INVALID, "Q must be positive semi-definite (negative or NaN diagonal entry)");
     for (size_t i = 0; i < nr; ++i)
-      if (!(p.R[i] > 0.0)) return fail(DDMPC_ERR_UNSUPPORTED, "R must have a strictly positive diagonal on the HIP path");
+      if (!(p.R[i] >= 0.0)) return fail(DDMPC_ERR_INVALID, "R must be positive semi-definite (negative or NaN diagonal entry)");
   } else {
-    if (p.controller_type == DDMPC_ROBUST && p.slack_type == DDMPC_SLACK_CONVEX)
-      return fail(DDMPC_ERR_UNSUPPORTED, "dense Q / R together with the CONVEX slack box are not supported by the HIP path");
     for (int pass = 0; pass < 2; ++pass) {
       const double* W = pass ? p.R : p.Q;
       const size_t nn = pass ? ml : pl;

@@ -918,7 +918,10 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
       double contrib = P.lam * b * z;
       const int kind = cK[rho];
       if (P.dense_w && (kind == K_UFREE || kind == K_YFREE || kind == K_WPRED)) {
-        contrib -= P.lam * b * (z - tb);
+        // (z - t)' W (z - t) summed over the weighted components equals -lam * beta' (z - t), t the (shifted) target;
+        // a sigma held at its bound adds lamb_sigma * bound^2 (W^-1 = Q_ff^-1 + 1/lamb_sigma on the INACTIVE components)
+        contrib -= P.lam * b * (z - t);
+        if (s_act != 0) contrib += P.lamb_sigma * P.bound * P.bound;
       } else
       if (kind == K_UFREE || kind == K_YFREE) { const double dlt = z - tb; contrib += wq * dlt * dlt; }
       else if (kind == K_WINT) { const double sg = z - cT[rho]; contrib += P.lamb_sigma * sg * sg; }

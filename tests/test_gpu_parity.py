@@ -798,10 +798,6 @@ def test_dense_weighting_matrices(gpu, kw):
 
 
 def test_dense_weights_rejections(gpu):
-    spec = orc.spec_from_params(slack_var_constraint_type=1)
-    spec.Q = spec.Q + 0.01                                           # dense + slack CONVEX: unsupported
-    with pytest.raises(L.DDMPCError, match="CONVEX"):
-        _engine(spec, 400, 1)
     spec = orc.spec_from_params()
     Q = spec.Q.copy(); Q[0, 1] = 0.5                                 # not symmetric
     spec.Q = Q
@@ -812,6 +808,74 @@ def test_dense_weights_rejections(gpu):
     spec.Q = Q
     with pytest.raises(L.DDMPCError, match="positive definite"):
         _engine(spec, 400, 1)
+    spec = orc.spec_from_params()
+    spec.R = spec.R.copy(); spec.R[3, 3] = -1e-4                     # diagonal, not PSD
+    with pytest.raises(L.DDMPCError, match="semi-definite"):
+        _engine(spec, 400, 1)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(tec=False), dict(L=10, N=120)], ids=["tec", "ucon", "small"])
+def test_dense_weighting_matrices_with_the_slack_box(gpu, kw):
+    # Dense SPD Q / R together with the CONVEX slack box -- the constructor's DEFAULT slack type (controller.py:111-112)
+    # with the weights of controller.py:708-710.  A sigma at its bound only switches the diagonal 1/lamb_sigma term of
+    # W^-1 = Q_ff^-1 + P_I / lamb_sigma, so the dense part is shared by every active set.  Cold solve, variables, warm
+    # step (affine iterate + cold re-solve of flagged instances) and a short closed loop against the full-space oracle.
+    spec = orc.spec_from_params(slack_var_constraint_type=1, **kw)
+    rng = np.random.default_rng(12)
+    spec.Q = _spd(rng, spec.p * spec.L, 3.0, 3)
+    spec.R = _spd(rng, spec.m * spec.L, 1e-4, 2)
+    N = kw.get("N", 400)
+    B = 6
+    u_d, y_d, up, yp = _instances(B, N=N, seed0=40)
+    with _engine(spec, N, B) as eng:
+        eng.set_data(u_d, y_d)
+        u, cost, status, iters = eng.solve(up, yp)
+        _check(spec, u_d, y_d, up, yp, u, cost, status, range(B))
+        sols = [orc.solve_fullspace(spec, u_d[b], y_d[b], up[b], yp[b]) for b in range(B)]
+        assert [int(i) for i in iters] == [s_.iters for s_ in sols] and max(s_.iters for s_ in sols) >= 2   # the box binds
+        sg, yb, al = eng.get_solution("sigma"), eng.get_solution("ybar"), eng.get_solution("alpha")
+        for b in range(B):
+            assert np.max(np.abs(sg[b] - sols[b].sigma)) < 1e-10 and np.max(np.abs(yb[b] - sols[b].ybar.ravel())) < 1e-8
+            assert np.max(np.abs(al[b] - sols[b].alpha)) < 1e-9
+        assert np.max(np.abs(sg[:, spec.n * spec.p:])) <= spec.c * spec.eps_max * (1 + 1e-12)
+        uw, cw, sw, iw = eng.step(up, yp)
+        _check(spec, u_d, y_d, up, yp, uw, cw, sw, range(B))
+        assert np.array_equal(iw, iters)
+    if not kw:
+        insts = [orc.generate_instance(s_) for s_ in range(2)]
+        ud = np.stack([i["u_d"] for i in insts]); yd = np.stack([i["y_d"] for i in insts])
+        x0 = np.stack([i["plant"].x for i in insts]); n_steps = 8
+        w = np.stack([i["plant"].eps_max * i["rng"].uniform(-1.0, 1.0, (n_steps, 2)) for i in insts])
+        P = orc.FOUR_TANK
+        with _engine(spec, 400, 2) as eng:
+            eng.set_data(ud, yd)
+            u_sys, y_sys, st, *_ = eng.closed_loop(P["A"], P["B"], P["C"], P["D"], x0, ud[:, -4:].reshape(2, -1),
+                                                   yd[:, -4:].reshape(2, -1), w, n_mpc_step=1)
+        for b in range(2):
+            u_ref, y_ref = orc.closed_loop(spec, ud[b], yd[b], insts[b]["plant"], w[b], n_mpc_step=1)
+            assert np.max(np.abs(u_sys[b] - u_ref)) / np.max(np.abs(u_ref)) < 1e-8 and np.max(np.abs(y_sys[b] - y_ref)) < 1e-9
+
+
+@pytest.mark.parametrize("slack", [0, 1], ids=["none", "convex"])
+def test_positive_semidefinite_diagonal_weights(gpu, slack):
+    # Q, R only positive SEMI-definite (controller.py:708-710 takes any PSD matrix): the second output is not weighted
+    # at all, every third input step neither.  Unweighted components are free: multiplier zero, z = (G beta).
+    spec = orc.spec_from_params(slack_var_constraint_type=slack)
+    q = np.diag(spec.Q).copy(); r_ = np.diag(spec.R).copy()
+    q[1::2] = 0.0
+    r_[::3] = 0.0
+    spec.Q, spec.R = np.diag(q), np.diag(r_)
+    B = 6
+    u_d, y_d, up, yp = _instances(B, seed0=60)
+    with _engine(spec, 400, B, diag=True) as eng:
+        eng.set_data(u_d, y_d)
+        u, cost, status, iters = eng.solve(up, yp)
+        _check(spec, u_d, y_d, up, yp, u, cost, status, range(B))
+        uw, cw, sw, _ = eng.step(up, yp)
+        _check(spec, u_d, y_d, up, yp, uw, cw, sw, range(B))
+        sol = orc.solve_fullspace(spec, u_d[0], y_d[0], up[0], yp[0])
+        yb = eng.get_solution("ybar")
+        assert np.max(np.abs(yb[0] - sol.ybar.ravel())) < 1e-8
 
 
 def test_long_data_trajectory(gpu):
