@@ -128,12 +128,15 @@ struct Lds2 {
   static constexpr int cd1 = cd0 + RP;                 //   D (inactive / bound active), target (past window folded in),
   static constexpr int ct0 = cd1 + RP;                 //   kind (ints, RP/2 doubles)
   static constexpr int ckk = ct0 + RP;
-  static constexpr int part = ckk + (RP + 1) / 2;      // back substitution: [8 waves][16] partial sums
-  static constexpr int red = part + 128;               // 32
+  static constexpr int PARTW = NT > 9 ? 8 : 4;        // waves of the instance that uses this NT (ddmpc_instances.inc)
+  static constexpr int part = ckk + (RP + 1) / 2;      // back substitution: 2 x [waves][16] partial sums (alternating rounds)
+  static constexpr int red = part + 2 * 16 * PARTW;    // 32
   static constexpr int ints = red + 32;                // int act[RP], int flags[8]
   static constexpr int pt2 = (ints + (RP + 8 + 1) / 2 + 2) & ~1;   // in-tile panel, row-major: [32 rows][4]
   static constexpr int LRS = 36;                       // row stride of lt16: 32 rows + 4 (spreads the 4 k-rows of an operand read over the banks)
   static constexpr int lt16 = pt2 + 128;               // in-tile factor, k-major: [16][LRS]: x < 16 -> L_JJ[x][k], 16 + x' -> M[k][x']
+  static constexpr int pastw = lt16;                   // prologue only (lt16 is first written two barriers later): [u_past; y_past],
+  static constexpr int cpp = lt16 + 16 * LRS / 2;      //   n (m+p) <= RP/2 entries, and each component's index into it (ints)
   static constexpr int RSB = RP + 4;                   // row stride of the panel buffer
   static constexpr int pb = lt16 + 16 * LRS;           // panel buffer, k-major: PB[k][16 I + i] = U(Jp, I)[k][i]
   static constexpr int ctab = pb + 16 * RSB;           // lag blocks C[d][a][b], d < RP/4 (structured Gram)
@@ -194,19 +197,18 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
   double* cD1 = sm + LD::cd1;
   double* cT = sm + LD::ct0;
   int* cK = reinterpret_cast<int*>(sm + LD::ckk);
-  static_for<NE>([&](auto e) __attribute__((always_inline)) {
-    const int rho = tid0 + e * NTHR;
-    if (rho < RP) {
-      double tt = P.tabd[2 * RP + rho];
-      const int pidx = P.tabi[1 * RP + rho];
-      if (pidx >= 0) tt = (pidx < P.npu) ? up[pidx] : yp[pidx - P.npu];
-      cD0[rho] = P.tabd[0 * RP + rho];
-      cD1[rho] = P.tabd[1 * RP + rho];
-      cT[rho] = tt;
-      cK[rho] = P.tabi[0 * RP + rho];
-      act[rho] = 0;
-    }
-  });
+  {   // (cD0, cD1, cK, setpoint targets and the past window were staged by the kernel function, all loads in flight at once)
+    const int* cP = reinterpret_cast<const int*>(sm + LD::cpp);
+    const double* pastw = sm + LD::pastw;
+    static_for<NE>([&](auto e) __attribute__((always_inline)) {
+      const int rho = tid0 + e * NTHR;
+      if (rho < RP) {
+        const int pidx = cP[rho];
+        if (pidx >= 0) cT[rho] = pastw[pidx];
+        act[rho] = 0;
+      }
+    });
+  }
   if (tid0 < 8) flags[tid0] = 0;
 
   // the panel wave's dependency chain (in-tile factorisation) is the critical path of the workgroup: its instructions
@@ -237,6 +239,139 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
     __syncthreads();   // trajectory staged (first pass), tables visible
     stamp();           // 1
 
+    imax = 0.0;
+    bool f0_done = false;   // structured Gram: the panel wave has already factored diagonal tile 0 (beside the other waves' walks)
+    // -(G + lam*D) of one raw Gram tile; -identity on dummy rows; rhs COLUMN rE := -t (mirrored into the diagonal tile);
+    // dense weighting matrices: lam * W^-1 is a full symmetric matrix shared by the batch (L2)
+    auto fix_tile = [&](auto II, auto JJ, const d4& raw) __attribute__((always_inline)) -> d4 {
+      constexpr int I = II, J = JJ;
+      const int gc = 16 * I + l15;                        // global column (i side)
+      d4 v = -raw;
+      if constexpr (I == J) {
+        static_for<4>([&](auto j) __attribute__((always_inline)) {
+          const int gr = 16 * J + l4 + 4 * j;
+          if (gr == gc && gr < r) { v[j()] -= P.lam * dvec[gr]; kmax = fmax(kmax, -v[j()]); }
+        });
+      }
+      if (16 * I + 15 >= r) {                             // wave-uniform: tile columns that touch the padding / rhs column
+        static_for<4>([&](auto j) __attribute__((always_inline)) {
+          const int gr = 16 * J + l4 + 4 * j;
+          if (gr >= r || gc >= r) v[j()] = 0.0;
+          if (I == J && gr == gc && gr >= r && gr < rE) v[j()] = -1.0;
+          if (gc == rE && gr < r) v[j()] = -tvec[gr];
+          if (I == J && gr == rE && gc < r) v[j()] = -tvec[gc];
+        });
+      }
+      if (P.dense_w) {
+        const double* dm = P.dmat + (long long)(16 * J + l4) * RP + 16 * I + l15;
+        static_for<4>([&](auto j) __attribute__((always_inline)) { v[j()] -= P.lam * dm[4 * j() * RP]; });
+      }
+      return v;
+    };
+    // `pend(h)`, h = 0..11: hooks at which the caller slips independent MFMAs (trailing updates of later diagonal tiles)
+    // into the dependency chain of the sub-step; pinned with sched_barrier so that they run beside the chain's VALU
+    // work and LDS waits instead of in front of it.
+    auto substep = [&](d4& Ad, d4& Et, auto QQ, int nq, auto&& pend) __attribute__((always_inline)) {
+      constexpr int q = QQ;
+      constexpr int c0 = 4 * q;
+#define DDMPC_HOOK(h) do { pend(std::integral_constant<int, h>{}); } while (0)
+      const int x = lane & 31;                                      // lanes 32..63 mirror lanes 0..31
+      const double* Pd = PT2 + c0 * 4;                              // rows c0..c0+3 of the tile, 4 panel entries each
+      const double p00 = -Pd[0];
+      const double p10 = -Pd[4], p11 = -Pd[5];
+      const double p20 = -Pd[8], p21 = -Pd[9], p22 = -Pd[10];
+      const double p30 = -Pd[12], p31 = -Pd[13], p32 = -Pd[14], p33 = -Pd[15];
+      const double r0 = PT2[x * 4 + 0], r1 = PT2[x * 4 + 1], r2 = PT2[x * 4 + 2], r3 = PT2[x * 4 + 3];
+      DDMPC_HOOK(0);
+      const double i0 = rsq_n2(p00);
+      DDMPC_HOOK(1);
+      const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
+      const double i1 = rsq_n2(p11 - l10 * l10);
+      DDMPC_HOOK(2);
+      const double l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
+      const double i2 = rsq_n2(p22 - l20 * l20 - l21 * l21);
+      DDMPC_HOOK(3);
+      const double l32 = (p32 - l30 * l20 - l31 * l21) * i2;
+      const double i3 = rsq_n2(p33 - l30 * l30 - l31 * l31 - l32 * l32);
+      DDMPC_HOOK(4);
+      const double x0 = -r0 * i0;
+      const double x1 = -(r1 + x0 * l10) * i1;
+      DDMPC_HOOK(5);
+      const double x2 = -(r2 + x0 * l20 + x1 * l21) * i2;
+      const double x3 = -(r3 + x0 * l30 + x1 * l31 + x2 * l32) * i3;
+      DDMPC_HOOK(6);
+      if (lane < 32) {                                              // kept for M / L_JJ / y; not on the chain
+        LT[(c0 + 0) * LRS + x] = x0; LT[(c0 + 1) * LRS + x] = x1;
+        LT[(c0 + 2) * LRS + x] = x2; LT[(c0 + 3) * LRS + x] = x3;
+      }
+      // MFMA operands without an LDS round trip.  Lane rows hold [tile rows, identity rows, tile rows, identity rows]
+      // (x = lane & 31); v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second:
+      //   swap(x0, x1) -> [x0.A x1.A x0.A x1.A], [x0.E x1.E x0.E x1.E];  swap(x2, x3) likewise,
+      // so that operand row kk = x_kk of the tile rows (opA) / of the identity rows (opE) is one select away.
+      const d2 s01a = permlane16_swap_f64(x0, x1), s23a = permlane16_swap_f64(x2, x3);
+      const bool lowhalf = lane < 32;
+      const double opA = lowhalf ? s01a[0] : s23a[0];
+      const double opE = lowhalf ? s01a[1] : s23a[1];
+      DDMPC_HOOK(7);
+      Ad = __builtin_amdgcn_mfma_f64_16x16x4f64(opA, opA, Ad, 0, 0, 0);
+      Et = __builtin_amdgcn_mfma_f64_16x16x4f64(opE, opA, Et, 0, 0, 0);
+      DDMPC_HOOK(8);
+      DDMPC_HOOK(9);
+      DDMPC_HOOK(10);
+      DDMPC_HOOK(11);
+      if constexpr (q < 3) {
+        if (q + 1 < nq && lo == q + 1) {
+          static_for<4>([&](auto j) __attribute__((always_inline)) {
+            PT2[(l4 + 4 * j) * 4 + l3] = Ad[j()];
+            PT2[(16 + l4 + 4 * j) * 4 + l3] = Et[j()];
+          });
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // in-wave hand-off through LDS (PT2, LT), see factor_begin
+#undef DDMPC_HOOK
+    };
+    auto no_pend = [](auto) __attribute__((always_inline)) {};
+    auto factor_begin = [&](const d4& Ad, d4& Et) __attribute__((always_inline)) {
+      // (opaque lane id: otherwise the -identity pattern is hoisted out of the tile loop as four loop-invariant doubles,
+      //  which then live in scratch memory and are reloaded on the critical path of every diagonal tile)
+      int lz = lane;
+      asm volatile("" : "+v"(lz));
+      static_for<4>([&](auto j) __attribute__((always_inline)) { Et[j()] = ((lz >> 4) + 4 * j() == (lz & 15)) ? -1.0 : 0.0; });
+      if (lo == 0) {
+        static_for<4>([&](auto j) __attribute__((always_inline)) {
+          PT2[(l4 + 4 * j) * 4 + l3] = Ad[j()];
+          PT2[(16 + l4 + 4 * j) * 4 + l3] = Et[j()];
+        });
+      }
+      // In-wave hand-off through LDS: lanes read what OTHER lanes of the wave just wrote.  Without a fence the compiler
+      // reasons per thread ("my own stores did not touch this address, so the value I loaded last time is still good")
+      // and forwards stale loads; the hardware itself executes a wave's LDS operations in order.
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+    // after the last sub-step: M into the diagonal tile's registers, y of the last tile column, optional export
+    auto factor_end = [&](auto JT, int nq) __attribute__((always_inline)) {
+      constexpr int Jt = JT;
+      constexpr int SD = TM::slot(Jt, Jt);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // LT was written by other lanes of this wave
+      static_for<4>([&](auto j) __attribute__((always_inline)) {
+        const int k = l4 + 4 * j();
+        const double mv = LT[k * LRS + 16 + l15];
+        acc[SD][j()] = (k < 4 * nq) ? mv : 0.0;                     // register j of lane (l4, l15) = M[l4 + 4j][l15]
+        if (k == l15 && k < 4 * nq) imax = fmax(imax, mv);          // diag M = 1/sqrt(pivot): conditioning estimate (refinement trigger)
+      });
+      if (Jt == IR) {                                               // y of the last tile column = the substituted rhs row
+        if (lane < 4 * nq) tvec[16 * Jt + lane] = LT[lane * LRS + rr];
+      }
+      if (lfac != nullptr) {                                        // ddmpc_prepare: L_JJ row-major and its transpose
+        static_for<4>([&](auto e) __attribute__((always_inline)) {
+          const int idx = lane + 64 * e(), xr = idx >> 4, kc = idx & 15;
+          double v = (kc <= xr && kc < 4 * nq) ? LT[kc * LRS + xr] : 0.0;
+          if (xr == kc && kc >= 4 * nq) v = 1.0;
+          lfac[(Jt * (Jt + 1) / 2 + Jt) * 256 + idx] = v;
+          lfacT[(Jt * (Jt + 1) / 2 + Jt) * 256 + kc * 16 + xr] = v;
+        });
+      }
+    };
     if (P.gram_dense) {
       // ---- G = H H' by fp64 MFMA over the implicit Hankel operand (k-major: rows of tile column J are the A operand)
       static_for<TM::MAXS>([&](auto S) __attribute__((always_inline)) { acc[S] = d4{0.0, 0.0, 0.0, 0.0}; });
@@ -387,41 +522,28 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
           }
         }
       });
+      // (4) panel wave: its walk is short (one diagonal); diagonal tile 0 is fixed up and factored NOW, beside the other
+      //     waves' walks and fix-ups (its chain is the longest single piece of the workgroup's critical path)
+      if constexpr (WAVE == 0 && W > 1) {
+        if (rE >= 16 && !(P.dev & 4)) {                   // (tiny systems keep the plain order: their rhs row sits in tile 0)
+          constexpr int S0 = TM::slot(0, 0);
+          d4 Ad = fix_tile(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, acc[S0]);
+          d4 Et;
+          factor_begin(Ad, Et);
+          static_for<4>([&](auto q) __attribute__((always_inline)) { substep(Ad, Et, q, 4, no_pend); });
+          factor_end(std::integral_constant<int, 0>{}, 4);
+          f0_done = true;
+        }
+      }
       stamp();   // 3
     }
 
-    // ---- accumulators := -(G + lam*D); -identity on dummy rows; rhs COLUMN rE := -t (mirrored into the diagonal tile)
+    // ---- accumulators := -(G + lam*D) (fix_tile above)
     static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
       constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
       constexpr int S = TM::slot(I, J);
-      const int gc = 16 * I + l15;                        // global column (i side)
-      d4 v = -acc[S];
-      if constexpr (I == J) {
-        static_for<4>([&](auto j) __attribute__((always_inline)) {
-          const int gr = 16 * J + l4 + 4 * j;
-          if (gr == gc && gr < r) { v[j()] -= P.lam * dvec[gr]; kmax = fmax(kmax, -v[j()]); }
-        });
-      }
-      if (16 * I + 15 >= r) {                             // wave-uniform: tile columns that touch the padding / rhs column
-        static_for<4>([&](auto j) __attribute__((always_inline)) {
-          const int gr = 16 * J + l4 + 4 * j;
-          if (gr >= r || gc >= r) v[j()] = 0.0;
-          if (I == J && gr == gc && gr >= r && gr < rE) v[j()] = -1.0;
-          if (gc == rE && gr < r) v[j()] = -tvec[gr];
-          if (I == J && gr == rE && gc < r) v[j()] = -tvec[gc];
-        });
-      }
-      acc[S] = v;
+      if (!(I == 0 && J == 0 && f0_done)) acc[S] = fix_tile(std::integral_constant<int, I>{}, std::integral_constant<int, J>{}, acc[S]);
     });
-    if (P.dense_w) {      // dense weighting matrices: lam * W^-1 is a full symmetric matrix shared by the batch (L2)
-      static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
-        constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
-        constexpr int S = TM::slot(I, J);
-        const double* dm = P.dmat + (long long)(16 * J + l4) * RP + 16 * I + l15;
-        static_for<4>([&](auto j) __attribute__((always_inline)) { acc[S][j()] -= P.lam * dm[4 * j() * RP]; });
-      });
-    }
-    imax = 0.0;
     __syncthreads();      // every wave has read tvec (targets) for its rhs entries; LT / PT2 / PB are free
 
     // ---- blocked Cholesky, 16-wide panels, software-pipelined over the tile columns --------------------------------
@@ -440,114 +562,18 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
     // update inside the two tiles is one MFMA each, and the next panel's columns go back out to PT2.  A non-positive
     // pivot yields NaN, which reaches beta and is reported through the finite check of the output stage.  Rows above /
     // inside the pivot group carry don't-care values in LT (they only touch finished entries); the export masks them.
-    // `pend(h)`, h = 0..11: hooks at which the caller slips independent MFMAs (trailing updates of later diagonal tiles)
-    // into the dependency chain of the sub-step; pinned with sched_barrier so that they run beside the chain's VALU
-    // work and LDS waits instead of in front of it.
-    auto substep = [&](d4& Ad, d4& Et, auto QQ, int nq, auto&& pend) __attribute__((always_inline)) {
-      constexpr int q = QQ;
-      constexpr int c0 = 4 * q;
-#define DDMPC_HOOK(h) do { pend(std::integral_constant<int, h>{}); } while (0)
-      const int x = lane & 31;                                      // lanes 32..63 mirror lanes 0..31
-      const double* Pd = PT2 + c0 * 4;                              // rows c0..c0+3 of the tile, 4 panel entries each
-      const double p00 = -Pd[0];
-      const double p10 = -Pd[4], p11 = -Pd[5];
-      const double p20 = -Pd[8], p21 = -Pd[9], p22 = -Pd[10];
-      const double p30 = -Pd[12], p31 = -Pd[13], p32 = -Pd[14], p33 = -Pd[15];
-      const double r0 = PT2[x * 4 + 0], r1 = PT2[x * 4 + 1], r2 = PT2[x * 4 + 2], r3 = PT2[x * 4 + 3];
-      DDMPC_HOOK(0);
-      const double i0 = rsq_n2(p00);
-      DDMPC_HOOK(1);
-      const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
-      const double i1 = rsq_n2(p11 - l10 * l10);
-      DDMPC_HOOK(2);
-      const double l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
-      const double i2 = rsq_n2(p22 - l20 * l20 - l21 * l21);
-      DDMPC_HOOK(3);
-      const double l32 = (p32 - l30 * l20 - l31 * l21) * i2;
-      const double i3 = rsq_n2(p33 - l30 * l30 - l31 * l31 - l32 * l32);
-      DDMPC_HOOK(4);
-      const double x0 = -r0 * i0;
-      const double x1 = -(r1 + x0 * l10) * i1;
-      DDMPC_HOOK(5);
-      const double x2 = -(r2 + x0 * l20 + x1 * l21) * i2;
-      const double x3 = -(r3 + x0 * l30 + x1 * l31 + x2 * l32) * i3;
-      DDMPC_HOOK(6);
-      if (lane < 32) {                                              // kept for M / L_JJ / y; not on the chain
-        LT[(c0 + 0) * LRS + x] = x0; LT[(c0 + 1) * LRS + x] = x1;
-        LT[(c0 + 2) * LRS + x] = x2; LT[(c0 + 3) * LRS + x] = x3;
-      }
-      // MFMA operands without an LDS round trip.  Lane rows hold [tile rows, identity rows, tile rows, identity rows]
-      // (x = lane & 31); v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second:
-      //   swap(x0, x1) -> [x0.A x1.A x0.A x1.A], [x0.E x1.E x0.E x1.E];  swap(x2, x3) likewise,
-      // so that operand row kk = x_kk of the tile rows (opA) / of the identity rows (opE) is one select away.
-      const d2 s01a = permlane16_swap_f64(x0, x1), s23a = permlane16_swap_f64(x2, x3);
-      const bool lowhalf = lane < 32;
-      const double opA = lowhalf ? s01a[0] : s23a[0];
-      const double opE = lowhalf ? s01a[1] : s23a[1];
-      DDMPC_HOOK(7);
-      Ad = __builtin_amdgcn_mfma_f64_16x16x4f64(opA, opA, Ad, 0, 0, 0);
-      Et = __builtin_amdgcn_mfma_f64_16x16x4f64(opE, opA, Et, 0, 0, 0);
-      DDMPC_HOOK(8);
-      DDMPC_HOOK(9);
-      DDMPC_HOOK(10);
-      DDMPC_HOOK(11);
-      if constexpr (q < 3) {
-        if (q + 1 < nq && lo == q + 1) {
-          static_for<4>([&](auto j) __attribute__((always_inline)) {
-            PT2[(l4 + 4 * j) * 4 + l3] = Ad[j()];
-            PT2[(16 + l4 + 4 * j) * 4 + l3] = Et[j()];
-          });
-        }
-      }
-#undef DDMPC_HOOK
-    };
-    auto no_pend = [](auto) __attribute__((always_inline)) {};
-    auto factor_begin = [&](const d4& Ad, d4& Et) __attribute__((always_inline)) {
-      // (opaque lane id: otherwise the -identity pattern is hoisted out of the tile loop as four loop-invariant doubles,
-      //  which then live in scratch memory and are reloaded on the critical path of every diagonal tile)
-      int lz = lane;
-      asm volatile("" : "+v"(lz));
-      static_for<4>([&](auto j) __attribute__((always_inline)) { Et[j()] = ((lz >> 4) + 4 * j() == (lz & 15)) ? -1.0 : 0.0; });
-      if (lo == 0) {
-        static_for<4>([&](auto j) __attribute__((always_inline)) {
-          PT2[(l4 + 4 * j) * 4 + l3] = Ad[j()];
-          PT2[(16 + l4 + 4 * j) * 4 + l3] = Et[j()];
-        });
-      }
-    };
-    // after the last sub-step: M into the diagonal tile's registers, y of the last tile column, optional export
-    auto factor_end = [&](auto JT, int nq) __attribute__((always_inline)) {
-      constexpr int Jt = JT;
-      constexpr int SD = TM::slot(Jt, Jt);
-      static_for<4>([&](auto j) __attribute__((always_inline)) {
-        const int k = l4 + 4 * j();
-        const double mv = LT[k * LRS + 16 + l15];
-        acc[SD][j()] = (k < 4 * nq) ? mv : 0.0;                     // register j of lane (l4, l15) = M[l4 + 4j][l15]
-        if (k == l15 && k < 4 * nq) imax = fmax(imax, mv);          // diag M = 1/sqrt(pivot): conditioning estimate (refinement trigger)
-      });
-      if (Jt == IR) {                                               // y of the last tile column = the substituted rhs row
-        if (lane < 4 * nq) tvec[16 * Jt + lane] = LT[lane * LRS + rr];
-      }
-      if (lfac != nullptr) {                                        // ddmpc_prepare: L_JJ row-major and its transpose
-        static_for<4>([&](auto e) __attribute__((always_inline)) {
-          const int idx = lane + 64 * e(), xr = idx >> 4, kc = idx & 15;
-          double v = (kc <= xr && kc < 4 * nq) ? LT[kc * LRS + xr] : 0.0;
-          if (xr == kc && kc >= 4 * nq) v = 1.0;
-          lfac[(Jt * (Jt + 1) / 2 + Jt) * 256 + idx] = v;
-          lfacT[(Jt * (Jt + 1) / 2 + Jt) * 256 + kc * 16 + xr] = v;
-        });
-      }
-    };
     // prologue: the panel wave factors diagonal tile 0 on its own
     {
       const int nq0 = NS < 4 ? NS : 4;
       const long long t0 = now();
       if constexpr (WAVE == 0) {
-        d4 Ad = acc[TM::slot(0, 0)];
-        d4 Et;
-        factor_begin(Ad, Et);
-        static_for<4>([&](auto q) __attribute__((always_inline)) { if (q() < nq0) substep(Ad, Et, q, nq0, no_pend); });
-        factor_end(std::integral_constant<int, 0>{}, nq0);
+        if (!f0_done) {
+          d4 Ad = acc[TM::slot(0, 0)];
+          d4 Et;
+          factor_begin(Ad, Et);
+          static_for<4>([&](auto q) __attribute__((always_inline)) { if (q() < nq0) substep(Ad, Et, q, nq0, no_pend); });
+          factor_end(std::integral_constant<int, 0>{}, nq0);
+        }
       }
       const long long t1 = now();
       __syncthreads();                                              // (B) M_0 is in LT
@@ -684,49 +710,59 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         }
       }
     });
-    __syncthreads();
-    // ---- back substitution U x = y (y in tvec), one tile column per round, right to left:
+    // ---- back substitution U x = y (y in tvec), one tile column per round, right to left.  The panel wave first puts
+    //      its M tiles into the (now free) panel buffer; then per round
     //   (1) every wave: s[k] = sum over its tiles (I > J) of U(J,I)[k][.] x_I  (4 multiply-adds per tile, then one
-    //       16-lane reduction per register) -> part[wave][k]
-    //   (2) panel wave: x_J = M_J' (y_J - sum of the parts)
+    //       16-lane reduction per register) -> part[round parity][wave][k]                      -- one barrier
+    //   (2) EVERY wave, redundantly: x_J = M_J' (y_J - sum of the parts), kept in registers for its own products of the
+    //       later rounds (lane l15 holds x_J[l15]); the panel wave also writes it to `out`
+    //      -- one workgroup barrier per round instead of two.
     auto back_substitute = [&](double* __restrict__ out) __attribute__((always_inline)) {
+      double* Mb = PB;                                               // Mb[J][k][i] = M_J[k][i]
+      if constexpr (WAVE == 0) {
+        static_for<NT>([&](auto J) __attribute__((always_inline)) {
+          if (16 * J < rE) {
+            constexpr int SD = TM::slot(J, J);
+            static_for<4>([&](auto j) __attribute__((always_inline)) { Mb[J * 256 + (l4 + 4 * j) * 16 + l15] = acc[SD][j()]; });
+          }
+        });
+      }
+      __syncthreads();                                               // M tiles and y are in LDS
+      double xl[NT];                                                 // x_I[l15] of the rounds done so far
+      static_for<NT>([&](auto I) __attribute__((always_inline)) { xl[I] = 0.0; });
       static_for<NT>([&](auto JREV) __attribute__((always_inline)) {
         constexpr int J = NT - 1 - JREV;
-        if (16 * J < rE) {                                              // workgroup-uniform
+        if (16 * J < rE) {                                            // workgroup-uniform
+          double* pr = part + (J & 1) * (16 * LD::PARTW);
           if constexpr (TM::has_col(WAVE, J)) {
             d4 s = d4{0.0, 0.0, 0.0, 0.0};
             static_for<NT>([&](auto I) __attribute__((always_inline)) {
               if constexpr (I > J && TM::wave(I, J) == WAVE) {
-                if (16 * I < rE) {
-                  constexpr int S = TM::slot(I, J);
-                  const double b = out[16 * I + l15];
-                  static_for<4>([&](auto j) __attribute__((always_inline)) { s[j()] = fma(acc[S][j()], b, s[j()]); });
-                }
+                constexpr int S = TM::slot(I, J);
+                static_for<4>([&](auto j) __attribute__((always_inline)) { s[j()] = fma(acc[S][j()], xl[I], s[j()]); });
               }
             });
             static_for<4>([&](auto j) __attribute__((always_inline)) { s[j()] = row16_total(s[j()]); });
             if (l15 == 0) {
-              static_for<4>([&](auto j) __attribute__((always_inline)) { part[WAVE * 16 + l4 + 4 * j] = s[j()]; });
+              static_for<4>([&](auto j) __attribute__((always_inline)) { pr[WAVE * 16 + l4 + 4 * j] = s[j()]; });
             }
           }
           __syncthreads();
-          if constexpr (WAVE == 0) {
-            constexpr int SD = TM::slot(J, J);
-            double pi = 0.0;
-            static_for<4>([&](auto j) __attribute__((always_inline)) {
-              const int k = l4 + 4 * j();
-              double v = tvec[16 * J + k];
-              static_for<W>([&](auto w) __attribute__((always_inline)) {
-                if constexpr (TM::has_col(w, J)) v -= part[w * 16 + k];
-              });
-              pi = fma(acc[SD][j()], v, pi);
+          double pi = 0.0;
+          static_for<4>([&](auto j) __attribute__((always_inline)) {
+            const int k = l4 + 4 * j();
+            double v = tvec[16 * J + k];
+            static_for<W>([&](auto w) __attribute__((always_inline)) {
+              if constexpr (TM::has_col(w, J)) v -= pr[w * 16 + k];
             });
-            pi = rows4_total(pi);
-            if (l4 == 0) out[16 * J + l15] = (16 * J + l15 < rE) ? pi : 0.0;
-          }
-          __syncthreads();
+            pi = fma(Mb[J * 256 + k * 16 + l15], v, pi);
+          });
+          pi = rows4_total(pi);
+          xl[J] = (16 * J + l15 < rE) ? pi : 0.0;
+          if constexpr (WAVE == 0) { if (l4 == 0) out[16 * J + l15] = xl[J]; }
         }
       });
+      __syncthreads();                                               // `out` complete
     };
     // ---- forward substitution U' y = rho in place in tvec (refinement only; the first right-hand side rides along
     //      with the factorisation), left to right:
@@ -978,6 +1014,30 @@ __global__ __launch_bounds__(64 * W, DDMPC_MIN_WAVES(NT, W)) void ddmpc_cold_sol
   unsigned long long* st = stamps ? stamps + b * 16 : nullptr;
   if (st && tid == 0) { st[0] = __builtin_amdgcn_s_memtime(); st[15] = __builtin_amdgcn_s_memrealtime(); }
   double* xs = sm + Lds2<NT>::xs;
+  // component tables (L2) and past window: independent loads, issued BEFORE the trajectory staging so that the three
+  // global round trips of the prologue (tables -> past-window gather -> trajectory) overlap instead of following each other
+  constexpr int RPk = 16 * NT;
+  constexpr int NEk = (RPk + NTHR - 1) / NTHR;
+  double tD0[NEk], tD1[NEk], tTb[NEk];
+  int tK[NEk], tP[NEk];
+  static_for<NEk>([&](auto e) __attribute__((always_inline)) {
+    const int rho = tid + e * NTHR;
+    tD0[e()] = 0.0; tD1[e()] = 0.0; tTb[e()] = 0.0; tK[e()] = K_PAD; tP[e()] = -1;
+    if (rho < RPk) {
+      tD0[e()] = P.tabd[0 * RPk + rho];
+      tD1[e()] = P.tabd[1 * RPk + rho];
+      tTb[e()] = P.tabd[2 * RPk + rho];
+      tK[e()] = P.tabi[0 * RPk + rho];
+      tP[e()] = P.tabi[1 * RPk + rho];
+    }
+  });
+  const int npast = P.npu + (P.npu / P.m) * P.p;
+  double pwv[NEk];
+  static_for<NEk>([&](auto e) __attribute__((always_inline)) {
+    const int i = tid + e * NTHR;
+    pwv[e()] = 0.0;
+    if (i < npast) pwv[e()] = (i < P.npu) ? u_past[b * (long long)P.npu + i] : y_past[b * (long long)(npast - P.npu) + (i - P.npu)];
+  });
   {
     const double* ud = u_d + b * (long long)P.N * P.m;
     const double* yd = y_d + b * (long long)P.N * P.p;
@@ -1003,6 +1063,17 @@ __global__ __launch_bounds__(64 * W, DDMPC_MIN_WAVES(NT, W)) void ddmpc_cold_sol
     }
     for (int i = P.N * P.nch + tid; i < P.xs_len; i += NTHR) xs[i] = 0.0;
   }
+  {
+    double* cD0 = sm + Lds2<NT>::cd0; double* cD1 = sm + Lds2<NT>::cd1; double* cT = sm + Lds2<NT>::ct0;
+    int* cK = reinterpret_cast<int*>(sm + Lds2<NT>::ckk); int* cP = reinterpret_cast<int*>(sm + Lds2<NT>::cpp);
+    double* pastw = sm + Lds2<NT>::pastw;
+    static_for<NEk>([&](auto e) __attribute__((always_inline)) {
+      const int rho = tid + e * NTHR;
+      if (rho < RPk) { cD0[rho] = tD0[e()]; cD1[rho] = tD1[e()]; cT[rho] = tTb[e()]; cK[rho] = tK[e()]; cP[rho] = tP[e()]; }
+      if (rho < npast) pastw[rho] = pwv[e()];
+    });
+  }
+  __syncthreads();       // the past window is visible to the threads that own its components
   const int n = P.npu / P.m;
   const double* up = u_past + b * (long long)P.npu;
   const double* yp = y_past + b * (long long)(n * P.p);
