@@ -428,6 +428,8 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   k.lam = robust_ ? p.lamb_alpha * p.eps_max : 0.0;
   k.lamb_sigma = robust_ ? p.lamb_sigma : 1.0;
   k.bound = k.convex ? p.c * p.eps_max : 0.0;
+  k.sig_scale = -k.lam / k.lamb_sigma;
+  k.box_cost = k.lamb_sigma * k.bound * k.bound;
   k.max_iter = p.max_iter > 0 ? p.max_iter : 50;
   k.dev = getenv("DDMPC_DEV") ? atoi(getenv("DDMPC_DEV")) : 0;
   k.refine = getenv("DDMPC_REFINE") ? atoi(getenv("DDMPC_REFINE")) : DDMPC_REFINE_AUTO;   // env: development knob
@@ -470,7 +472,7 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
     {   // r-vectors and the Cholesky panel of the global-workspace kernels live in LDS (launch_cold / launch_nominal_rescue)
       const size_t rv = ((size_t)k.r + 1) & ~(size_t)1;
       const size_t lds = 10 * rv * sizeof(double) + 4 * rv * sizeof(int) + (size_t)PSD_PAN * sizeof(double);
-      if (lds + 1024 > 160 * 1024 || k.r > PSD_RPT * 512) {     // the packed Cholesky keeps PSD_RPT panel rows per thread (512 threads)
+      if (lds + 1024 > 160 * 1024 || k.r > PSD_RPT * 512) {     // the blocked substitutions keep PSD_RPT entries per thread (512 threads)
         delete h;
         return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: (m+p)(L+n) = %d rows (the global-workspace kernels hold %d)", k.r, PSD_RPT * 512);
       }
@@ -605,7 +607,7 @@ int ddmpc_set_data(ddmpc_handle* h, const double* u_d, const double* y_d, int me
 }
 
 static unsigned large_threads(size_t r) {   // workgroup size of the global-workspace kernels: the packed Cholesky keeps
-  return r <= 256 ? 256u : 512u;           // PSD_RPT panel rows per thread in registers (r <= PSD_RPT * threads)
+  return r <= 256 ? 256u : 512u;           // r <= PSD_RPT * threads (blocked substitutions)
 }
 
 // want_ws: also write the beta / active-set workspace (what ddmpc_get_solution, the gain kernel and the slack-box warm

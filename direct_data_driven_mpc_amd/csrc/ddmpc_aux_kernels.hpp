@@ -639,176 +639,318 @@ __device__ __forceinline__ int tri_row(int e) {
   return i;
 }
 
-// In-place Cholesky of a packed lower matrix with `n` rows (n <= PSD_RPT * blockDim.x); pivots <= tol_abs are
-// skipped (column zeroed, skip[k] = 1).  Panel-blocked, left-looking: every thread keeps the PSD_NB panel entries of
-// its (up to PSD_RPT) rows in REGISTERS, updates them with ALL the columns factored so far in one sweep (it streams
-// its own rows of the factor once per panel; the PSD_NB factor rows the whole workgroup needs are staged through
-// LDS in chunks of PSD_CH columns), the 16x16 diagonal block is factored in LDS, and the rows below it are finished
-// by a register-local triangular solve against that block.  LDS: 10 KB, independent of n.
-constexpr int PSD_NB = 16;      // panel width
-constexpr int PSD_CH = 64;      // columns of the factor staged per chunk
-constexpr int PSD_RPT = 2;      // panel rows per thread, held in registers: n <= PSD_RPT * blockDim.x
-constexpr int PSD_PAN = 2048;   // doubles of LDS scratch: diagonal block, its reciprocal pivots, staged chunk (1296 used);
-                                // the rest widens the trajectory chunks of hankel_gram_packed
-// `ncols` < n stops after the first ncols columns (rows >= ncols of those columns hold the factor's off-diagonal
-// block, the trailing block is left untouched).
+// In-place Cholesky of a packed lower matrix ((i,j) at i(i+1)/2 + j) with `n` rows; pivots <= tol_abs are skipped
+// (column zeroed, skip[k] = 1).  `ncols` < n stops after the first ncols columns (rows >= ncols of those columns hold
+// the factor's off-diagonal block, the trailing block is left untouched).  `pan`: PSD_PAN doubles of LDS.
+constexpr int PSD_PAN = 2048;   // doubles of LDS scratch (1312 used by the factorisation; the rest widens the trajectory
+                                // chunks of hankel_gram_packed)
+//
+// Left-looking over 32-wide panels, everything below the diagonal tiles done by v_mfma_f64_16x16x4:
+//
+//   * update:   P(I, C)' = A(I, C)' - sum_{j < k0} L(C, j) L(I, j)'     16x16 accumulator tiles, kept TRANSPOSED
+//     (register q of lane (l4, l15) = entry [panel column l4 + 4q][row l15] of the tile), so that a finished tile is
+//     directly the B operand of the left multiplications below.  Both operands are rows of the packed factor: a lane
+//     loads 4 consecutive entries (32 B) of "its" row per 16 columns of j -- whole cache lines per wave -- and feeds
+//     4 MFMAs per operand pair.
+//   * the two 16x16 diagonal tiles of a panel are factored by ONE wave each in LDS (pivot rule above), which also
+//     forms Mt = S L~^-1 (L~: unit diagonal where a pivot was skipped, S zeroes those rows), so that the rows below are
+//     X' = Mt P' -- 4 MFMAs per tile -- and the second half of the panel is updated with the first by 4 more.
+//   * traffic: the factor is streamed once per 32 columns (left-looking), half of what 16-wide panels read.
+//
+// Row tiles are dealt round-robin to the waves, PSD_TG tiles per wave and pass (64 accumulator VGPRs).
+// LDS: 1312 doubles of `pan`.  Requires at least two waves (blockDim.x a multiple of 64, >= 128).
+constexpr int PSD_TG = 4;
+typedef double d2u8 __attribute__((ext_vector_type(2), aligned(8)));     // 16-byte load from an 8-byte aligned packed row
+
+// One wave factors a 16x16 tile held row-major in LDS (lower triangle valid), columns [0, nbt): pivots <= tol_abs are
+// skipped (column zeroed).  Also writes Ms[k][m] = Mt[m][k], Mt = S L~^-1 restricted to those columns (k-major: the A
+// operand of X' = Mt P').  `skipout` receives nbt flags.
+__device__ __forceinline__ void psd_tile_factor(double* Dg, double* Ms, double* Dinv, int nbt, double tol_abs, int* skipout) {
+  const int lane = threadIdx.x & 63;
+  for (int c = 0; c < nbt; ++c) {
+    const double dk = Dg[c * 16 + c];
+    const bool sk = !(dk > tol_abs);                   // the same value in every lane
+    const double inv = sk ? 0.0 : 1.0 / sqrt(dk);
+    __builtin_amdgcn_wave_barrier();                   // every lane holds the pivot before it is overwritten
+    if (lane < 16 - c) Dg[(c + lane) * 16 + c] *= inv;
+    if (lane == 0) { skipout[c] = sk ? 1 : 0; Dinv[c] = inv; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (!sk) {
+      const int remc = nbt - c - 1, remr = 15 - c;     // columns c+1 .. nbt-1, rows c+1 .. 15
+      for (int x = lane; x < remr * remc; x += 64) {
+        const int rr = c + 1 + x / remc, c2 = c + 1 + x % remc;
+        if (c2 <= rr) Dg[rr * 16 + c2] -= Dg[rr * 16 + c] * Dg[c2 * 16 + c];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane < 16) {                                     // column `lane` of L~^-1 by forward substitution, rows of skipped pivots zero
+    double y[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      double sacc = (c == lane) ? 1.0 : 0.0;
+#pragma unroll
+      for (int c1 = 0; c1 < c; ++c1) sacc -= Dg[c * 16 + c1] * y[c1];
+      y[c] = (c < nbt) ? sacc * Dinv[c] : 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) Ms[lane * 16 + c] = y[c];          // Ms[k = lane][m = c] = Mt[c][lane]
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 __device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol_abs, int* skip, double* pan, int ncols = -1) {
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  double* Dg = pan;                                    // Dg[r * PSD_NB + c]   = A(k0 + r, k0 + c), the diagonal block
-  double* Dinv = pan + PSD_NB * PSD_NB;                // reciprocal pivots of the block (0 for a skipped pivot)
-  double* Lp = Dinv + PSD_NB;                          // Lp[c * PSD_CH + jj]  = A(k0 + c, j0 + jj)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = (int)(blockDim.x >> 6);
+  double* Dga = pan;                 // diagonal tile of the first / second half of the panel, row-major
+  double* Dgb = pan + 256;
+  double* Msa = pan + 512;           // Mt of the two halves, k-major
+  double* Msb = pan + 768;
+  double* Xs = pan + 1024;           // X(1,0)' = rows k0+16.. of the first half's columns, k-major: Xs[k][row]
+  double* Dinv = pan + 1280;         // 2 x 16 reciprocal pivots
   if (ncols < 0) ncols = n;
-  for (int k0 = 0; k0 < ncols; k0 += PSD_NB) {
-    const int nb = (ncols - k0) < PSD_NB ? (ncols - k0) : PSD_NB;
-    // (1) panel rows k0 + tid + e*nthr in registers: A(i, k0..k0+nb) minus the contribution of the columns factored so far
-    double P[PSD_RPT][PSD_NB];
+  auto rowp = [&](int i) -> const double* { i = i < n ? i : n - 1; return A + (size_t)i * (i + 1) / 2; };
+  for (int k0 = 0; k0 < ncols; k0 += 32) {
+    const int nba = (ncols - k0) < 16 ? (ncols - k0) : 16;
+    const int nbb = (ncols - k0 - 16) < 0 ? 0 : ((ncols - k0 - 16) < 16 ? (ncols - k0 - 16) : 16);
+    const int ntile = (n - k0 + 15) >> 4;
+    // the panel's own rows: A operands of the update (clamped to a valid row; masked when P is formed)
+    const double* pa = rowp(k0 + l15) + 4 * l4;
+    const double* pb = rowp(k0 + 16 + l15) + 4 * l4;
+    for (int g0 = 0; g0 < ntile; g0 += nwave * PSD_TG) {
+      d4 acc[PSD_TG][2];
+      const double* rp[PSD_TG];
+      int ti[PSD_TG];
 #pragma unroll
-    for (int e = 0; e < PSD_RPT; ++e)
-#pragma unroll
-      for (int c = 0; c < PSD_NB; ++c) P[e][c] = 0.0;
-    const double* Ar[PSD_RPT];
-#pragma unroll
-    for (int e = 0; e < PSD_RPT; ++e) {
-      const int i = k0 + tid + e * nthr;
-      Ar[e] = A + (size_t)(i < n ? i : k0) * ((i < n ? i : k0) + 1) / 2;
-    }
-    for (int j0 = 0; j0 < k0; j0 += PSD_CH) {
-      const int nj = (k0 - j0) < PSD_CH ? (k0 - j0) : PSD_CH;
-      __syncthreads();                                 // previous chunk consumed
-      for (int x = tid; x < nb * nj; x += nthr) {
-        const int c = x / nj, jj = x - c * nj;
-        Lp[c * PSD_CH + jj] = A[(size_t)(k0 + c) * (k0 + c + 1) / 2 + j0 + jj];
+      for (int s = 0; s < PSD_TG; ++s) {
+        ti[s] = g0 + wave + nwave * s;                                  // tile row (wave-uniform); >= ntile: idle slot
+        rp[s] = rowp(k0 + 16 * ti[s] + l15) + 4 * l4;
+        acc[s][0] = d4{0.0, 0.0, 0.0, 0.0};
+        acc[s][1] = d4{0.0, 0.0, 0.0, 0.0};
       }
-      __syncthreads();
+      // ---- update with the columns factored so far -------------------------------------------------------
+      for (int j0 = 0; j0 < k0; j0 += 16) {
+        const d2u8 a0 = *reinterpret_cast<const d2u8*>(pa + j0), a1 = *reinterpret_cast<const d2u8*>(pa + j0 + 2);
+        d2u8 b0 = a0, b1 = a1;
+        if (nbb > 0) { b0 = *reinterpret_cast<const d2u8*>(pb + j0); b1 = *reinterpret_cast<const d2u8*>(pb + j0 + 2); }
 #pragma unroll
-      for (int e = 0; e < PSD_RPT; ++e) {
-        if (k0 + tid + e * nthr < n) {
-          // eight consecutive entries of the own row are loaded back to back (one or two cache lines, fetched once)
-          int jj = 0;
-          for (; jj + 8 <= nj; jj += 8) {
-            double li[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) li[q] = Ar[e][j0 + jj + q];
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-#pragma unroll
-              for (int c = 0; c < PSD_NB; ++c) P[e][c] += li[q] * Lp[c * PSD_CH + jj + q];
-          }
-          for (; jj < nj; ++jj) {
-            const double li = Ar[e][j0 + jj];
-#pragma unroll
-            for (int c = 0; c < PSD_NB; ++c) P[e][c] += li * Lp[c * PSD_CH + jj];
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < PSD_RPT; ++e) {
-      const int i = k0 + tid + e * nthr;
-#pragma unroll
-      for (int c = 0; c < PSD_NB; ++c) P[e][c] = (i < n && c < nb && k0 + c <= i) ? Ar[e][k0 + c] - P[e][c] : 0.0;
-    }
-    // (2) the diagonal block goes to LDS (its rows belong to the first nb threads) and is factored there
-    __syncthreads();
-    if (tid < nb) {
-#pragma unroll
-      for (int c = 0; c < PSD_NB; ++c) Dg[tid * PSD_NB + c] = P[0][c];
-    }
-    __syncthreads();
-    if (tid < 64) {
-      // one wave factors the 16x16 block: its lanes run in lockstep and a wave's LDS operations complete in program
-      // order, so the column steps need no workgroup barrier (the wave barrier only pins the compiler's ordering)
-      for (int c = 0; c < nb; ++c) {
-        const double dk = Dg[c * PSD_NB + c];
-        const bool sk = !(dk > tol_abs);               // the same value in every lane
-        const double inv = sk ? 0.0 : 1.0 / sqrt(dk);
-        __builtin_amdgcn_wave_barrier();               // every lane holds the pivot before it is overwritten
-        if (tid < nb - c) Dg[(c + tid) * PSD_NB + c] *= inv;
-        if (tid == 0) { skip[k0 + c] = sk ? 1 : 0; Dinv[c] = inv; }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (!sk) {
-          const int rem = nb - c - 1;                  // rows/columns c+1 .. nb-1
-          for (int x = tid; x < rem * rem; x += 64) {
-            const int rr = c + 1 + x / rem, c2 = c + 1 + x % rem;
-            if (c2 <= rr) Dg[rr * PSD_NB + c2] -= Dg[rr * PSD_NB + c] * Dg[c2 * PSD_NB + c];
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-    __syncthreads();
-    // (3) rows below the block: P_i <- P_i L11^-T in registers (L11 and its reciprocal pivots broadcast from LDS);
-    //     rows of the block: the factored block itself; then (4) panel -> matrix
-#pragma unroll
-    for (int e = 0; e < PSD_RPT; ++e) {
-      const int i = k0 + tid + e * nthr;
-      if (i < n) {
-        double* Ai = A + (size_t)i * (i + 1) / 2;
-        if (i < k0 + nb) {
-          for (int c = 0; c < nb; ++c)
-            if (k0 + c <= i) Ai[k0 + c] = Dg[(i - k0) * PSD_NB + c];
-        } else {
-#pragma unroll
-          for (int c = 0; c < PSD_NB; ++c) {
-            if (c < nb) {
-              double v = P[e][c];
-#pragma unroll
-              for (int c1 = 0; c1 < PSD_NB; ++c1)
-                if (c1 < c) v -= P[e][c1] * Dg[c * PSD_NB + c1];
-              P[e][c] = v * Dinv[c];
+        for (int s = 0; s < PSD_TG; ++s) {
+          if (ti[s] < ntile) {
+            const d2u8 x0 = *reinterpret_cast<const d2u8*>(rp[s] + j0), x1 = *reinterpret_cast<const d2u8*>(rp[s] + j0 + 2);
+            acc[s][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], x0[0], acc[s][0], 0, 0, 0);
+            acc[s][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], x0[1], acc[s][0], 0, 0, 0);
+            acc[s][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], x1[0], acc[s][0], 0, 0, 0);
+            acc[s][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], x1[1], acc[s][0], 0, 0, 0);
+            if (nbb > 0 && ti[s] > 0) {
+              acc[s][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[0], x0[0], acc[s][1], 0, 0, 0);
+              acc[s][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[1], x0[1], acc[s][1], 0, 0, 0);
+              acc[s][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[0], x1[0], acc[s][1], 0, 0, 0);
+              acc[s][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[1], x1[1], acc[s][1], 0, 0, 0);
             }
           }
+        }
+      }
+      // ---- P' = A' - acc on the valid entries (row < n, column <= row, column < ncols), zero elsewhere -----
 #pragma unroll
-          for (int c = 0; c < PSD_NB; ++c)
-            if (c < nb) Ai[k0 + c] = P[e][c];
+      for (int s = 0; s < PSD_TG; ++s) {
+        const int i = k0 + 16 * ti[s] + l15;
+        const double* Ai = rowp(i);
+#pragma unroll
+        for (int C = 0; C < 2; ++C)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int cc = k0 + 16 * C + l4 + 4 * q;
+            const bool ok = ti[s] < ntile && i < n && cc <= i && cc < ncols;
+            acc[s][C][q] = ok ? Ai[cc] - acc[s][C][q] : 0.0;
+          }
+      }
+      if (g0 == 0) {
+        // ---- diagonal tiles: wave 0 owns tile row 0, wave 1 (or wave 0 again, single-wave launch) tile row 1 ----
+        if (wave == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Dga[l15 * 16 + l4 + 4 * q] = acc[0][0][q];
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          psd_tile_factor(Dga, Msa, Dinv, nba, tol_abs, skip + k0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {                                   // L(0,0) -> matrix
+            const int idx = lane + 64 * e, rr = idx >> 4, c = idx & 15;
+            if (c <= rr && c < nba && k0 + rr < n) A[(size_t)(k0 + rr) * (k0 + rr + 1) / 2 + k0 + c] = Dga[rr * 16 + c];
+          }
+        }
+        __syncthreads();                                                  // Msa visible
+        constexpr int w1 = 1, s1 = 0;                                     // tile row 1: first slot of wave 1
+#pragma unroll
+        for (int s = 0; s < PSD_TG; ++s) {
+          if (ti[s] >= 1 && ti[s] < ntile) {                              // X(t,0)' = Mta P(t,0)'
+            d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(Msa[(l4 + 4 * q) * 16 + l15], acc[s][0][q], x, 0, 0, 0);
+            acc[s][0] = x;
+          }
+        }
+        if (nbb > 0) {
+          if (wave == w1 && ntile > 1) {
+            d4& x10 = acc[s1][0];
+            d4& p11 = acc[s1][1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Xs[(l4 + 4 * q) * 16 + l15] = x10[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) p11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x10[q], x10[q], p11, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Dgb[l15 * 16 + l4 + 4 * q] = p11[q];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            psd_tile_factor(Dgb, Msb, Dinv + 16, nbb, tol_abs, skip + k0 + 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                                 // L(1,1) -> matrix
+              const int idx = lane + 64 * e, rr = idx >> 4, c = idx & 15;
+              const int gi = k0 + 16 + rr;
+              if (c <= rr && c < nbb && gi < n) A[(size_t)gi * (gi + 1) / 2 + k0 + 16 + c] = Dgb[rr * 16 + c];
+            }
+          }
+          __syncthreads();                                                // Xs, Msb visible
+        }
+      }
+      // ---- rows below the panel's diagonal tiles: second half updated with the first, X(t,1)' = Mtb P(t,1)'; stores ----
+#pragma unroll
+      for (int s = 0; s < PSD_TG; ++s) {
+        if (ti[s] < ntile && ti[s] >= 1) {
+          if (g0 != 0) {                                                  // later passes: Mta is long visible
+            d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(Msa[(l4 + 4 * q) * 16 + l15], acc[s][0][q], x, 0, 0, 0);
+            acc[s][0] = x;
+          }
+          const int i = k0 + 16 * ti[s] + l15;
+          double* Ai = A + (size_t)(i < n ? i : 0) * ((i < n ? i : 0) + 1) / 2;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int cc = k0 + l4 + 4 * q;
+            if (i < n && cc < ncols) Ai[cc] = acc[s][0][q];
+          }
+          if (nbb > 0 && ti[s] >= 2) {
+            d4 p = acc[s][1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) p = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[(l4 + 4 * q) * 16 + l15], acc[s][0][q], p, 0, 0, 0);
+            d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(Msb[(l4 + 4 * q) * 16 + l15], p[q], x, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int cc = k0 + 16 + l4 + 4 * q;
+              if (i < n && cc < ncols) Ai[cc] = x[q];
+            }
+          }
         }
       }
     }
-    __syncthreads();
+    __syncthreads();                                                      // panel stored before the next update reads it; LDS tiles free
   }
 }
 
-// Back substitution L' x = y for a packed lower factor, row-oriented: once x[a] is known, row a of L (contiguous)
-// times x[a] is subtracted from the remaining right-hand side -- coalesced loads, no reduction, one barrier per row.
+// Back substitution L' x = y for a packed lower factor, 16 rows at a time: the 16x16 diagonal block is solved by the
+// first 16 lanes of wave 0 (its entries in registers, the unknowns passed on by lane shuffles), then every thread j
+// below the block subtracts the 16 rows' contributions from y[j].  The operands of that update do not depend on the
+// unknowns, so their loads are issued BEFORE the block solve: two workgroup barriers and one global round trip per 16
+// rows (the row-by-row form paid a barrier and two dependent round trips per row, ~1 ms for 608 rows).
 // y is consumed (overwritten), x must not alias it; `skip` (optional) marks rows whose unknown is zero.
+// Requires n <= PSD_RPT * blockDim.x.
+constexpr int PSD_RPT = 2;      // entries of y per thread
 __device__ __forceinline__ void packed_back_substitute(const double* Lm, int n, double* y, double* x, const int* skip) {
   const int tid = threadIdx.x, nthr = blockDim.x;
-  if (skip) {                                                     // rows without an unknown cost nothing below
-    for (int a = tid; a < n; a += nthr)
-      if (skip[a]) x[a] = 0.0;
-  }
-  for (int a = n - 1; a >= 0; --a) {
-    if (skip && skip[a]) continue;                                // uniform
-    const double* La = Lm + (size_t)a * (a + 1) / 2;
-    const double xa = y[a] / La[a];                               // every thread forms the same value
-    if (tid == 0) x[a] = xa;
-    for (int j = tid; j < a; j += nthr) y[j] -= La[j] * xa;
+  const int a = tid & 15;
+  for (int k0 = ((n - 1) >> 4) << 4; k0 >= 0; k0 -= 16) {
+    const int nb = (n - k0) < 16 ? (n - k0) : 16;
+    // operands of the update of the rows above the block: Lu[e][q] = L(k0 + q, j), j = tid + e * nthr < k0
+    double Lu[PSD_RPT][16];
+#pragma unroll
+    for (int e = 0; e < PSD_RPT; ++e) {
+      const int j = tid + e * nthr;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Lu[e][q] = (j < k0 && q < nb) ? Lm[(size_t)(k0 + q) * (k0 + q + 1) / 2 + j] : 0.0;
+    }
+    if (tid < 64) {
+      // lane a owns unknown k0 + a and column a of the diagonal block: Lc[q] = L(k0 + q, k0 + a), q >= a
+      double Lc[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Lc[q] = (q >= a && q < nb) ? Lm[(size_t)(k0 + q) * (k0 + q + 1) / 2 + k0 + a] : 0.0;
+      const bool dead = a >= nb || (skip != nullptr && skip[k0 + a] != 0);
+      double inv = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) if (q == a) inv = dead ? 0.0 : 1.0 / Lc[q];
+      double v = (a < nb) ? y[k0 + a] : 0.0;
+#pragma unroll
+      for (int q = 15; q >= 0; --q) {
+        const double xq = __shfl(v * inv, q, 16);       // final once every row below q has been subtracted
+        if (a < q) v -= Lc[q] * xq;
+      }
+      if (tid < nb) x[k0 + a] = v * inv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < PSD_RPT; ++e) {
+      const int j = tid + e * nthr;
+      if (j < k0) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sacc += Lu[e][q] * ((q < nb) ? x[k0 + q] : 0.0);
+        y[j] -= sacc;
+      }
+    }
     __syncthreads();
   }
-  __syncthreads();
 }
 
 __device__ __forceinline__ double block_sum(double v, double* red);       // defined below
 
-// L y = rhs over the rows that are not skipped (y = 0 on skipped ones) for a packed lower factor, row by row with the
-// dot products spread over the workgroup.  y must not alias rhs.
+// L y = rhs over the rows that are not skipped (y = 0 on skipped ones) for a packed lower factor, 16 rows at a time:
+// every 32-lane half wave forms the dot product of one row of the block with the y known so far (coalesced 256-byte
+// pieces of the row), then the first 16 lanes of wave 0 solve the 16x16 diagonal block with lane shuffles.  Two
+// workgroup barriers per 16 rows.  y must not alias rhs; `red` holds >= 16 doubles.
 __device__ __forceinline__ void packed_forward_substitute(const double* Lm, int n, const double* rhs, double* y,
                                                           const int* skip, double* red) {
   const int tid = threadIdx.x, nthr = blockDim.x;
-  if (skip) {                                                     // skipped rows: y = 0, no dot product, no barrier
-    for (int k = tid; k < n; k += nthr)
-      if (skip[k]) y[k] = 0.0;
+  const int hw = tid >> 5, t32 = tid & 31, nhw = nthr >> 5;
+  const int a = tid & 15;
+  for (int k0 = 0; k0 < n; k0 += 16) {
+    const int nb = (n - k0) < 16 ? (n - k0) : 16;
+    double Lr[16];                                       // wave 0: row a of the diagonal block, Lr[q] = L(k0 + a, k0 + q), q <= a
+    if (tid < 64) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Lr[q] = (q <= a && a < nb) ? Lm[(size_t)(k0 + a) * (k0 + a + 1) / 2 + k0 + q] : 0.0;
+    }
+    for (int h = hw; h < 16; h += nhw) {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      if (h < nb) {
+        const double* La = Lm + (size_t)(k0 + h) * (k0 + h + 1) / 2;
+        int j = t32;
+        for (; j + 96 < k0; j += 128) {                  // four loads in flight per lane
+          const double l0 = La[j], l1 = La[j + 32], l2 = La[j + 64], l3 = La[j + 96];
+          s0 += l0 * y[j]; s1 += l1 * y[j + 32]; s2 += l2 * y[j + 64]; s3 += l3 * y[j + 96];
+        }
+        for (; j < k0; j += 32) s0 += La[j] * y[j];
+      }
+      double sacc = (s0 + s1) + (s2 + s3);
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 32);
+      if (t32 == 0) red[h] = sacc;
+    }
     __syncthreads();
-  }
-  for (int k = 0; k < n; ++k) {
-    if (skip && skip[k]) continue;                                // uniform
-    const double* Lk = Lm + (size_t)k * (k + 1) / 2;
-    double part = 0.0;
-    for (int j = tid; j < k; j += nthr) part += Lk[j] * y[j];
-    const double s = rhs[k] - block_sum(part, red);
-    if (tid == 0) y[k] = s / Lk[k];
+    if (tid < 64) {
+      const bool dead = a >= nb || (skip != nullptr && skip[k0 + a] != 0);
+      double inv = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) if (q == a) inv = dead ? 0.0 : 1.0 / Lr[q];
+      double v = (a < nb) ? rhs[k0 + a] - red[a] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const double yq = __shfl(v * inv, q, 16);       // final once every row above q has been subtracted
+        if (a > q) v -= Lr[q] * yq;
+      }
+      if (tid < nb) y[k0 + a] = v * inv;
+    }
     __syncthreads();
   }
 }

@@ -184,7 +184,8 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
   int* act = reinterpret_cast<int*>(sm + LD::ints);
   int* flags = act + RP;            // [0] fail, [1] active set changed
 
-  const int tid0 = threadIdx.x;
+  int tid0 = threadIdx.x;
+  asm volatile("" : "+v"(tid0));   // opaque: LDS addresses formed from it in the kernel function would be shared by the four wave bodies, live in scratch
   const int r = P.r, rE = P.rE, nch = P.nch;
   const int NS = rE >> 2;           // 4-wide pivot groups
   const int IR = rE >> 4;           // tile column holding the rhs column (column index rE)
@@ -224,6 +225,12 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
   for (;;) {
     ++iter;
     asm volatile("" : "+v"(tid));       // opaque per-iteration thread id (keeps LICM from hoisting every LDS address)
+    // ... and opaque problem sizes: otherwise every wave-uniform test on them (one per tile column and pivot group) is
+    // hoisted out of this loop as a 64-bit lane mask, ~100 SGPRs that spill into VGPR lanes and push VGPRs into scratch
+    int r_it = P.r, rE_it = P.rE;
+    asm volatile("" : "+s"(r_it), "+s"(rE_it));
+    const int r = r_it, rE = rE_it;
+    const int NS = rE >> 2, IR = rE >> 4, rr = rE & 15;
     const int lane = tid & 63;
     const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lo = l15 >> 2;
     static_for<NE>([&](auto e) __attribute__((always_inline)) {
@@ -912,11 +919,10 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
     // ---- slack box: primal-dual active-set update --------------------------------
     bool again = false;
     if (P.convex) {
-      const double scale = -P.lam / P.lamb_sigma;
       static_for<NE>([&](auto e) __attribute__((always_inline)) {
         const int rho = tid + e * NTHR;
         if (rho < r && (cK[rho] == K_WPRED || cK[rho] == K_WTERM)) {   // sigma[n*p:], controller.py:659
-          const double sh = scale * beta[rho];
+          const double sh = P.sig_scale * beta[rho];
           const int ns = (sh > P.bound) ? 1 : (sh < -P.bound) ? -1 : 0;
           if (ns != act[rho]) { act[rho] = ns; flags[1] = 1; }
         }
@@ -957,7 +963,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         // (z - t)' W (z - t) summed over the weighted components equals -lam * beta' (z - t), t the (shifted) target;
         // a sigma held at its bound adds lamb_sigma * bound^2 (W^-1 = Q_ff^-1 + 1/lamb_sigma on the INACTIVE components)
         contrib -= P.lam * b * (z - t);
-        if (s_act != 0) contrib += P.lamb_sigma * P.bound * P.bound;
+        if (s_act != 0) contrib += P.box_cost;
       } else
       if (kind == K_UFREE || kind == K_YFREE) { const double dlt = z - tb; contrib += wq * dlt * dlt; }
       else if (kind == K_WINT) { const double sg = z - cT[rho]; contrib += P.lamb_sigma * sg * sg; }

@@ -61,6 +61,8 @@ struct KParams {
   double lam;       // lamb_alpha * eps_max (0 for nominal)
   double lamb_sigma;
   double bound;     // c * eps_max
+  double sig_scale; // -lam / lamb_sigma: sigma_hat = sig_scale * beta on the boxed components (host-computed: a uniform
+  double box_cost;  // lamb_sigma * bound^2     fp64 value formed in the kernel would sit in a VGPR pair for its whole run)
   const double* tabd;
   const int* tabi;
   int refine;           // iterative refinement with exact Hankel products: 0 off, 1 auto (conditioning estimate), 2 always
