@@ -955,6 +955,159 @@ __device__ __forceinline__ void packed_forward_substitute(const double* Lm, int 
   }
 }
 
+// Products with blocks of a packed lower matrix.
+// Rows: out(i, sum_{j0 <= j < jend(i)} L(row0 + i, j) x[j - j0]) for i < nrows -- one 32-lane half wave per row: coalesced
+// 256-byte pieces of the row, four loads in flight per lane, shuffle reduction.  (One THREAD per row streams 64 rows per
+// wave through a 32 KB L1 that cannot hold them: every 8 bytes come from L2 again.)  `out` runs on one lane per row.
+template <class EndF, class OutF>
+__device__ __forceinline__ void packed_rows_times(const double* Lm, int row0, int nrows, int j0, const double* x,
+                                                  EndF&& jend, OutF&& out) {
+  const int hw = threadIdx.x >> 5, t32 = threadIdx.x & 31, nhw = blockDim.x >> 5;
+  for (int ib = 0; ib < nrows; ib += nhw) {
+    const int i = ib + hw;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (i < nrows) {
+      const double* Li = Lm + (size_t)(row0 + i) * (row0 + i + 1) / 2;
+      const double* xv = x - j0;
+      const int je = jend(i);
+      int j = j0 + t32;
+      for (; j + 96 < je; j += 128) {
+        const double l0 = Li[j], l1 = Li[j + 32], l2 = Li[j + 64], l3 = Li[j + 96];
+        s0 += l0 * xv[j]; s1 += l1 * xv[j + 32]; s2 += l2 * xv[j + 64]; s3 += l3 * xv[j + 96];
+      }
+      for (; j < je; j += 32) s0 += Li[j] * xv[j];
+    }
+    double sacc = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 32);
+    if (t32 == 0 && i < nrows) out(i, sacc);
+  }
+}
+// Columns: out(k, sum_{ibeg(k) <= i < nrows} L(row0 + i, col0 + k) v(i)) for k < ncols -- one thread per column (coalesced
+// across the threads), four independent loads in flight.
+template <class BegF, class VF, class OutF>
+__device__ __forceinline__ void packed_cols_times(const double* Lm, int row0, int nrows, int col0, int ncols,
+                                                  BegF&& ibeg, VF&& v, OutF&& out) {
+  for (int k = threadIdx.x; k < ncols; k += blockDim.x) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = ibeg(k);
+    for (; i + 3 < nrows; i += 4) {
+      const size_t ri = (size_t)(row0 + i);
+      const double l0 = Lm[ri * (ri + 1) / 2 + col0 + k], l1 = Lm[(ri + 1) * (ri + 2) / 2 + col0 + k];
+      const double l2 = Lm[(ri + 2) * (ri + 3) / 2 + col0 + k], l3 = Lm[(ri + 3) * (ri + 4) / 2 + col0 + k];
+      s0 += l0 * v(i); s1 += l1 * v(i + 1); s2 += l2 * v(i + 2); s3 += l3 * v(i + 3);
+    }
+    for (; i < nrows; ++i) {
+      const size_t ri = (size_t)(row0 + i);
+      s0 += Lm[ri * (ri + 1) / 2 + col0 + k] * v(i);
+    }
+    out(k, (s0 + s1) + (s2 + s3));
+  }
+}
+
+// T = C' W C for the lower-triangular block C(i, a) = L(row0 + i, row0 + a), a <= i < nR, W = diag(w): packed lower
+// triangle of T by v_mfma_f64_16x16x4, the row index i as the contraction index (4 rows per instruction; both operands
+// are 128-byte pieces of packed rows).  A skipped pivot (skipd[a] != 0) has a zero column in L: its row and column of T
+// come out zero and the diagonal entry is set to one.  Work items = (tile row A, group of up to four tile columns).
+__device__ __forceinline__ void packed_weighted_gram_mfma(const double* Lm, int row0, int nR, const double* w,
+                                                          const int* skipd, double* T) {
+  const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwave = (int)(blockDim.x >> 6);
+  const int nt = (nR + 15) >> 4;
+  int item = 0;
+  for (int A = nt - 1; A >= 0; --A) {                  // longest rows first
+    for (int B0 = 0; B0 <= A; B0 += 4, ++item) {
+      if (item % nwave != wave) continue;               // wave-uniform
+      d4 acc[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = d4{0.0, 0.0, 0.0, 0.0};
+      const int a = 16 * A + l15;
+      for (int i0 = 16 * A; i0 < nR; i0 += 4) {
+        const int i = i0 + l4;
+        const size_t ri = (size_t)(row0 + (i < nR ? i : nR - 1));
+        const double* Li = Lm + ri * (ri + 1) / 2 + row0;
+        const double av = (i < nR && a <= i) ? Li[a] * w[i] : 0.0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (B0 + g <= A) {
+            const int bcol = 16 * (B0 + g) + l15;
+            const double bv = (i < nR && bcol <= i) ? Li[bcol] : 0.0;
+            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[g], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (B0 + g <= A) {
+          const int bcol = 16 * (B0 + g) + l15;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int ar = 16 * A + l4 + 4 * q;
+            if (ar < nR && bcol <= ar) T[(size_t)ar * (ar + 1) / 2 + bcol] = (ar == bcol && skipd[ar]) ? 1.0 : acc[g][q];
+          }
+        }
+      }
+    }
+  }
+}
+
+// S(i, j) = A(row0 + i, row0 + j) - sum_{k < nk} L(row0 + i, k) L(row0 + j, k), j <= i < nB: the Schur complement of
+// a trailing block behind nk factored columns (packed lower triangle of S), rows times rows on the matrix pipe with the
+// column index as the contraction index: a lane loads 4 consecutive entries of "its" row per 16 columns.
+__device__ __forceinline__ void packed_schur_mfma(const double* Lm, int row0, int nB, int nk, double* S) {
+  const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwave = (int)(blockDim.x >> 6);
+  const int nt = (nB + 15) >> 4;
+  auto rowp = [&](int i) -> const double* { const size_t ri = (size_t)(row0 + (i < nB ? i : nB - 1)); return Lm + ri * (ri + 1) / 2; };
+  int item = 0;
+  for (int A = nt - 1; A >= 0; --A) {
+    for (int B0 = 0; B0 <= A; B0 += 4, ++item) {
+      if (item % nwave != wave) continue;               // wave-uniform
+      d4 acc[4];
+      const double* rb[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { acc[g] = d4{0.0, 0.0, 0.0, 0.0}; rb[g] = rowp(16 * (B0 + g) + l15) + 4 * l4; }
+      const double* ra = rowp(16 * A + l15) + 4 * l4;
+      for (int k0 = 0; k0 < nk; k0 += 16) {
+        const int kk = k0 + 4 * l4;
+        d2u8 a0 = *reinterpret_cast<const d2u8*>(ra + k0), a1 = *reinterpret_cast<const d2u8*>(ra + k0 + 2);
+        if (k0 + 16 > nk) {                              // last chunk: entries past the factored columns do not count
+          a0[0] = (kk < nk) ? a0[0] : 0.0; a0[1] = (kk + 1 < nk) ? a0[1] : 0.0;
+          a1[0] = (kk + 2 < nk) ? a1[0] : 0.0; a1[1] = (kk + 3 < nk) ? a1[1] : 0.0;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (B0 + g <= A) {
+            d2u8 b0 = *reinterpret_cast<const d2u8*>(rb[g] + k0), b1 = *reinterpret_cast<const d2u8*>(rb[g] + k0 + 2);
+            if (k0 + 16 > nk) {                          // (a zero on one side is not enough: the other side may hold anything)
+              b0[0] = (kk < nk) ? b0[0] : 0.0; b0[1] = (kk + 1 < nk) ? b0[1] : 0.0;
+              b1[0] = (kk + 2 < nk) ? b1[0] : 0.0; b1[1] = (kk + 3 < nk) ? b1[1] : 0.0;
+            }
+            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], b0[0], acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], b0[1], acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], b1[0], acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], b1[1], acc[g], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (B0 + g <= A) {
+          const int j = 16 * (B0 + g) + l15;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = 16 * A + l4 + 4 * q;
+            if (i < nB && j <= i) {
+              const size_t ri = (size_t)(row0 + i);
+              S[(size_t)i * (i + 1) / 2 + j] = Lm[ri * (ri + 1) / 2 + row0 + j] - acc[g][q];
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 // Products with the implicit block-Hankel matrix H (rows rho = k*nch + ch, columns i < c): alpha = H' x and z = H alpha.
 // x and z are r-vectors in COMPONENT order (LDS), alpha is a c-vector in global memory.
 __device__ __forceinline__ void hankel_transpose_times(const KParams& P, const double* __restrict__ ud,
@@ -1017,31 +1170,56 @@ __device__ __forceinline__ void hankel_gram_packed(const KParams& P, const doubl
   const int m = P.m, p = P.p, nch = P.nch, c = P.c;
   const int nlag = P.Ln * nch * nch;
   auto xat = [&](int a, int t) -> double { return (a < m) ? ud[(long long)t * m + a] : yd[(long long)t * p + (a - m)]; };
-  // lag sums: the trajectory is streamed through LDS in chunks of time steps (the LDS scratch of the Cholesky is
-  // free at this point), every thread accumulating its own (d,a,b) entries
-  const int TCH = (PSD_PAN / nch) - P.Ln;                                   // time steps per chunk that fit with the lag overlap
+  // lag sums on the matrix pipe: C_d = X_d' X_0 (X_d: the trajectory shifted by d time steps, one channel per column)
+  // is a 16x16 tile per lag and channel-tile pair with the time index as the contraction index.  The trajectory is
+  // streamed through LDS in chunks of time steps (the LDS scratch of the Cholesky is free at this point); a wave keeps
+  // up to HG_SL lags in accumulators and shares the X_0 operand between them.
+  constexpr int HG_SL = 5;
+  const int TCH = ((PSD_PAN / nch) - P.Ln) & ~3;                            // time steps per chunk that fit with the lag overlap
   double* xc = pan;                                                         // xc[(t - t0) * nch + ch], t0 <= t < t0 + TCH + Ln
-  for (int e = tid; e < nlag; e += nthr) Ctab[e] = 0.0;
-  for (int t0 = 0; t0 < c; t0 += TCH) {
-    const int nt = (c - t0) < TCH ? (c - t0) : TCH;                          // terms of this chunk
-    const int nload = nt + P.Ln - 1;                                        // time steps needed (x_a[t+d], d < Ln)
-    __syncthreads();
-    for (int i = tid; i < nload * nch; i += nthr) {
-      const int tt = i / nch, ch = i - tt * nch;
-      xc[i] = xat(ch, t0 + tt);
-    }
-    __syncthreads();
-    for (int e = tid; e < nlag; e += nthr) {
-      const int d = e / (nch * nch), ab = e - d * nch * nch, a = ab / nch, bb = ab - a * nch;
-      const double* xa = xc + d * nch + a;
-      const double* xb = xc + bb;
-      double s0 = 0.0, s1 = 0.0;
-      int t = 0;
-      for (; t + 1 < nt; t += 2) { s0 += xa[t * nch] * xb[t * nch]; s1 += xa[(t + 1) * nch] * xb[(t + 1) * nch]; }
-      if (t < nt) s0 += xa[t * nch] * xb[t * nch];
-      Ctab[e] += s0 + s1;
-    }
-  }
+  const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6;
+  const int nat = (nch + 15) >> 4;
+  for (int dg = 0; dg < P.Ln; dg += nwave * HG_SL)
+    for (int at = 0; at < nat; ++at)
+      for (int bt = 0; bt < nat; ++bt) {
+        d4 acc[HG_SL];
+#pragma unroll
+        for (int sl = 0; sl < HG_SL; ++sl) acc[sl] = d4{0.0, 0.0, 0.0, 0.0};
+        const int ca = (16 * at + l15 < nch) ? 16 * at + l15 : nch - 1;     // clamped: entries past nch are not stored
+        const int cb = (16 * bt + l15 < nch) ? 16 * bt + l15 : nch - 1;
+        for (int t0 = 0; t0 < c; t0 += TCH) {
+          const int nt = (c - t0) < TCH ? (c - t0) : TCH;                    // terms of this chunk
+          const int nload = nt + P.Ln - 1;                                  // time steps needed (x_a[t+d], d < Ln)
+          __syncthreads();
+          for (int i = tid; i < nload * nch; i += nthr) {
+            const int tt = i / nch, ch = i - tt * nch;
+            xc[i] = xat(ch, t0 + tt);
+          }
+          __syncthreads();
+          for (int s4 = 0; s4 < nt; s4 += 4) {
+            const int t = s4 + l4;
+            const double bv = (t < nt) ? xc[t * nch + cb] : 0.0;
+#pragma unroll
+            for (int sl = 0; sl < HG_SL; ++sl) {
+              const int d = dg + wave + nwave * sl;                         // wave-uniform
+              if (d < P.Ln) {
+                const int row = (t + d < nload) ? t + d : nload - 1;        // masked terms: any finite value
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(xc[row * nch + ca], bv, acc[sl], 0, 0, 0);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int sl = 0; sl < HG_SL; ++sl) {
+          const int d = dg + wave + nwave * sl;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int a = 16 * at + l4 + 4 * q, bb = 16 * bt + l15;
+            if (d < P.Ln && a < nch && bb < nch) Ctab[(d * nch + a) * nch + bb] = acc[sl][q];
+          }
+        }
+      }
   __syncthreads();
   // one (lag, channel pair) diagonal per thread-iteration, walked with the O(1) window update; every unordered
   // pair of components is met exactly once (lag 0: channel pairs a >= b only)
@@ -1192,93 +1370,31 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   packed_psd_cholesky(G, r, rank_tol * dmax, skip, pan);
   if (dbg && tid == 0) dbg[b * 8 + 2] = __builtin_amdgcn_s_memrealtime();
   // ---- hard constraints: L_FF w = f (skipped pivots carry no unknown); residual of the dependent rows ----
-  for (int k = 0; k < nF; ++k) {                      // row by row, the dot product spread over the workgroup
-    const double* Lk = G + k * (k + 1) / 2;
-    double part = 0.0;
-    for (int j = tid; j < k; j += nthr) part += Lk[j] * col[j];
-    const double s = fv[k] - block_sum(part, red);
-    if (tid == 0) {
-      col[k] = skip[k] ? 0.0 : s / Lk[k];
-      vv[k] = skip[k] ? fabs(s) : 0.0;                  // what a dependent constraint row is off by
-    }
-    __syncthreads();
-  }
+  packed_forward_substitute(G, nF, fv, col, skip, red);
+  packed_rows_times(G, 0, nF, 0, col, [&](int i) { return i; },
+                    [&](int i, double sacc) { vv[i] = skip[i] ? fabs(fv[i] - sacc) : 0.0; });   // what a dependent constraint row is off by
+  __syncthreads();
   double resid = 0.0, fmaxv = 1.0;
   for (int k = 0; k < nF; ++k) { resid = fmax(resid, vv[k]); fmaxv = fmax(fmaxv, fabs(fv[k])); }
   // ---- z0 = L_RF w ------------------------------------------------------------------------------
-  for (int i = tid; i < nR; i += nthr) {
-    const double* Li = G + (nF + i) * (nF + i + 1) / 2;
-    double s = 0.0;
-    int k = 0;
-    for (; k + 8 <= nF; k += 8) {
-      double l[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) l[q] = Li[k + q];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) s += l[q] * col[k + q];
-    }
-    for (; k < nF; ++k) s += Li[k] * col[k];
-    z0[i] = s;
-  }
+  packed_rows_times(G, nF, nR, 0, col, [&](int) { return nF; }, [&](int i, double sacc) { z0[i] = sacc; });
   __syncthreads();
   if (dbg && tid == 0) dbg[b * 8 + 3] = __builtin_amdgcn_s_memrealtime();
   // ---- reduced normal equations T = C' W C, rhs = C' W (zs - z0), C(i,a) = L(nF+i, nF+a), i >= a ----
-  {   // 4x4 register blocks of T (16 multiply-adds per 8 loads); a skipped pivot has a zero column in L, so its
-      // row/column of T comes out zero and only the diagonal is set to one (identity row, zero rhs)
-    const int nb4 = (nR + 3) >> 2, nblk = nb4 * (nb4 + 1) / 2;
-    for (int e = tid; e < nblk; e += nthr) {
-      const int ba = tri_row(e), bq = e - ba * (ba + 1) / 2;               // ba >= bq
-      const int a0 = 4 * ba, b0 = 4 * bq;
-      double acc[4][4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[q][t] = 0.0;
-      for (int i = a0; i < nR; ++i) {
-        const double* Li = G + (size_t)(nF + i) * (nF + i + 1) / 2 + nF;     // C(i, .), valid up to column i
-        const double w = wv[i];
-        double a[4], c[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          a[q] = (a0 + q <= i) ? Li[a0 + q] * w : 0.0;
-          c[q] = (b0 + q <= i) ? Li[b0 + q] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[q][t] += a[q] * c[t];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int a = a0 + q, bb = b0 + t;
-          if (a < nR && bb <= a) T[a * (a + 1) / 2 + bb] = (a == bb && skip[nF + a]) ? 1.0 : acc[q][t];
-        }
-    }
-  }
-  for (int a = tid; a < nR; a += nthr) {
-    double s = 0.0;
-    if (!skip[nF + a])
-      for (int i = a; i < nR; ++i) s += G[(nF + i) * (nF + i + 1) / 2 + nF + a] * wv[i] * (zs[i] - z0[i]);
-    vv[a] = s;
-  }
+  packed_weighted_gram_mfma(G, nF, nR, wv, skip + nF, T);
+  for (int i = tid; i < nR; i += nthr) ra[i] = wv[i] * (zs[i] - z0[i]);
+  __syncthreads();
+  packed_cols_times(G, nF, nR, nF, nR, [&](int a) { return a; }, [&](int i) { return ra[i]; },
+                    [&](int a, double sacc) { vv[a] = skip[nF + a] ? 0.0 : sacc; });
   __syncthreads();
   if (dbg && tid == 0) dbg[b * 8 + 4] = __builtin_amdgcn_s_memrealtime();
   double tmx = 0.0;
   for (int a = 0; a < nR; ++a) tmx = fmax(tmx, T[a * (a + 1) / 2 + a]);
   packed_psd_cholesky(T, nR, 1e-14 * tmx, skipT, pan);
   if (dbg && tid == 0) dbg[b * 8 + 5] = __builtin_amdgcn_s_memrealtime();
-  // ---- T v = rhs by the factor, row by row with the dot products spread over the workgroup ----------------
-  for (int a = 0; a < nR; ++a) {
-    const double* Ta = T + a * (a + 1) / 2;
-    double part = 0.0;
-    for (int j = tid; j < a; j += nthr) part += Ta[j] * vv[j];
-    const double s = vv[a] - block_sum(part, red);
-    if (tid == 0) vv[a] = skipT[a] ? 0.0 : s / Ta[a];
-    __syncthreads();
-  }
-  packed_back_substitute(T, nR, vv, ra, skipT);           // w2; col keeps w1 for the refinement step
+  // ---- T v = rhs by the factor ------------------------------------------------------------------------------
+  packed_forward_substitute(T, nR, vv, rb, skipT, red);
+  packed_back_substitute(T, nR, rb, ra, skipT);           // w2; col keeps w1 for the refinement step
   for (int a = tid; a < nR; a += nthr) vv[a] = ra[a];
   __syncthreads();
   if (dbg && tid == 0) dbg[b * 8 + 6] = __builtin_amdgcn_s_memrealtime();
@@ -1310,18 +1426,11 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   __syncthreads();
   for (int k = tid; k < r; k += nthr) rz[k] = rd[perm[k]];           // z_ex in position order
   // (b) multipliers of the starting point: L_FF' mu = -L_RF' W (z_R - zs), z_R = z0 + C w2 (the unrefined solution)
-  for (int i = tid; i < nR; i += nthr) {
-    const double* Li = G + (size_t)(nF + i) * (nF + i + 1) / 2 + nF;
-    double z = z0[i];
-    for (int a = 0; a <= i; ++a) z += Li[a] * vv[a];
-    rb[nF + i] = wv[i] * (z - zs[i]);
-  }
+  packed_rows_times(G, nF, nR, nF, vv, [&](int i) { return nF + i + 1; },
+                    [&](int i, double sacc) { rb[nF + i] = wv[i] * (z0[i] + sacc - zs[i]); });
   __syncthreads();
-  for (int k = tid; k < nF; k += nthr) {
-    double sacc = 0.0;
-    for (int i = 0; i < nR; ++i) sacc += G[(size_t)(nF + i) * (nF + i + 1) / 2 + k] * rb[nF + i];
-    ra[k] = -sacc;
-  }
+  packed_cols_times(G, nF, nR, 0, nF, [&](int) { return 0; }, [&](int i) { return rb[nF + i]; },
+                    [&](int k, double sacc) { ra[k] = -sacc; });
   __syncthreads();
   packed_back_substitute(G, nF, ra, rd, skip);                          // mu -> rd[0..nF)
   // (c) residual of the stationarity rows: rw = -B' v,  v = [mu on the independent fixed rows ; W (z_ex,R - zs)]
@@ -1340,19 +1449,10 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   for (int k = tid; k < nF; k += nthr) rd[k] = fv[k] - rz[k];
   __syncthreads();
   packed_forward_substitute(G, nF, rd, rb, skip, red);                   // dw1 -> rb[0..nF)
-  for (int i = tid; i < nR; i += nthr) {
-    const double* Li = G + (size_t)(nF + i) * (nF + i + 1) / 2;
-    double sacc = 0.0;
-    for (int k = 0; k < nF; ++k) sacc += Li[k] * rb[k];
-    rd[nF + i] = sacc;                                                   // L_RF dw1
-  }
+  packed_rows_times(G, nF, nR, 0, rb, [&](int) { return nF; }, [&](int i, double sacc) { rd[nF + i] = sacc; });   // L_RF dw1
   __syncthreads();
-  for (int a = tid; a < nR; a += nthr) {
-    double sacc = 0.0;
-    if (!skip[nF + a])
-      for (int i = a; i < nR; ++i) sacc += G[(size_t)(nF + i) * (nF + i + 1) / 2 + nF + a] * wv[i] * rd[nF + i];
-    vv[a] = skip[nF + a] ? 0.0 : -ra[nF + a] - sacc;                      // rhs of the T system
-  }
+  packed_cols_times(G, nF, nR, nF, nR, [&](int a) { return a; }, [&](int i) { return wv[i] * rd[nF + i]; },
+                    [&](int a, double sacc) { vv[a] = skip[nF + a] ? 0.0 : -ra[nF + a] - sacc; });              // rhs of the T system
   __syncthreads();
   packed_forward_substitute(T, nR, vv, col, skipT, red);                 // col: work vector (w lives in wk)
   packed_back_substitute(T, nR, col, vv, skipT);                         // dw2 -> vv
@@ -1374,16 +1474,14 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   // ---- z_R = z_ex,R + L_RF dw1 + C dw2; outputs ------------------------------------------------------
   double part = 0.0;
   double* uo = u_opt + b * (long long)((P.Ln - n) * m);
-  for (int i = tid; i < nR; i += nthr) {
-    const double* Li = G + (size_t)(nF + i) * (nF + i + 1) / 2 + nF;
-    double z = rz[nF + i] + rd[nF + i];
-    for (int a = 0; a <= i; ++a) z += Li[a] * vv[a];
+  packed_rows_times(G, nF, nR, nF, vv, [&](int i) { return nF + i + 1; }, [&](int i, double sacc) {
+    const double z = rz[nF + i] + rd[nF + i] + sacc;
     const double dlt = z - zs[i];
     part += wv[i] * dlt * dlt;
     const int oidx = P.tabi[2 * RPs + perm[nF + i]];
     if (oidx >= 0) uo[oidx] = z;
     if (z_ws) z_ws[b * (long long)P.rE + perm[nF + i]] = z;
-  }
+  });
   for (int k = tid; k < nF; k += nthr) {
     const int oidx = P.tabi[2 * RPs + perm[k]];
     if (oidx >= 0) uo[oidx] = fv[k];                    // terminal inputs are part of optimal_u
@@ -1491,78 +1589,10 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
   __syncthreads();
   if (st == 0) {
     // S = K_BB - L_BA L_BA'  (the diagonal shift of B is added per active set)
-    {   // 4x4 register blocks: 16 multiply-adds per 8 loads
-      const int nb4 = (nB + 3) >> 2, nblk = nb4 * (nb4 + 1) / 2;
-      for (int e = tid; e < nblk; e += nthr) {
-        const int bi = tri_row(e), bj = e - bi * (bi + 1) / 2;           // bi >= bj
-        const double* Li[4];
-        const double* Lj[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int ri = (4 * bi + q < nB) ? 4 * bi + q : nB - 1, rj = (4 * bj + q < nB) ? 4 * bj + q : nB - 1;
-          Li[q] = G + (size_t)(nA + ri) * (nA + ri + 1) / 2;
-          Lj[q] = G + (size_t)(nA + rj) * (nA + rj + 1) / 2;
-        }
-        double acc[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[q][t] = 0.0;
-        int k = 0;
-        for (; k + 4 <= nA; k += 4) {                    // four consecutive entries of each row loaded back to back
-          double a[4][4], c[4][4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { a[q][u] = Li[q][k + u]; c[q][u] = Lj[q][k + u]; }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-              for (int t = 0; t < 4; ++t) acc[q][t] += a[q][u] * c[t][u];
-        }
-        for (; k < nA; ++k) {
-          double a[4], c[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { a[q] = Li[q][k]; c[q] = Lj[q][k]; }
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[q][t] += a[q] * c[t];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int i = 4 * bi + q, j = 4 * bj + t;
-            if (i < nB && j <= i) S[i * (i + 1) / 2 + j] = Li[q][nA + j] - acc[q][t];
-          }
-      }
-    }
-    // L_AA y_A = t_A, row by row, the dot product spread over the workgroup (t_A does not depend on the active set)
-    for (int k = 0; k < nA; ++k) {
-      const double* Lk = G + (size_t)k * (k + 1) / 2;
-      double part = 0.0;
-      for (int j = tid; j < k; j += nthr) part += Lk[j] * yv[j];
-      const double s = ct[k] - block_sum(part, red);
-      if (tid == 0) yv[k] = s / Lk[k];
-      __syncthreads();
-    }
-    for (int i = tid; i < nB; i += nthr) {               // zb = L_BA y_A
-      const double* Li = G + (size_t)(nA + i) * (nA + i + 1) / 2;
-      double s = 0.0;
-      int k = 0;
-      for (; k + 8 <= nA; k += 8) {
-        double l[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) l[q] = Li[k + q];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s += l[q] * yv[k + q];
-      }
-      for (; k < nA; ++k) s += Li[k] * yv[k];
-      zb[i] = s;
-    }
+    packed_schur_mfma(G, nA, nB, nA, S);
+    // L_AA y_A = t_A (t_A does not depend on the active set), zb = L_BA y_A
+    packed_forward_substitute(G, nA, ct, yv, nullptr, red);
+    packed_rows_times(G, nA, nB, 0, yv, [&](int) { return nA; }, [&](int i, double sacc) { zb[i] = sacc; });
     __syncthreads();
     // ---- active-set iterations on the B block --------------------------------------------------------------
     while (true) {
@@ -1581,14 +1611,9 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
       for (int i = tid; i < nB; i += nthr) nbad += skip[nA + i] ? 1.0 : 0.0;
       if (block_sum(nbad, red) != 0.0) { st = 4; break; }
       __syncthreads();
-      for (int k = 0; k < nB; ++k) {                     // L_BB y_B = t_B - L_BA y_A
-        const double* Tk = T + (size_t)k * (k + 1) / 2;
-        double part = 0.0;
-        for (int j = tid; j < k; j += nthr) part += Tk[j] * yv[nA + j];
-        const double s = (ct[nA + k] + act[nA + k] * P.bound) - zb[k] - block_sum(part, red);
-        if (tid == 0) yv[nA + k] = s / Tk[k];
-        __syncthreads();
-      }
+      for (int k = tid; k < nB; k += nthr) qa[k] = (ct[nA + k] + act[nA + k] * P.bound) - zb[k];
+      __syncthreads();
+      packed_forward_substitute(T, nB, qa, yv + nA, nullptr, red);   // L_BB y_B = t_B - L_BA y_A
       packed_back_substitute(T, nB, yv + nA, bv + nA, nullptr);   // L_BB' beta_B = y_B
       // slack box: primal-dual active-set update (sigma[n*p:], controller.py:659); B holds exactly those components
       if (tid == 0) flag[0] = 0;
@@ -1609,11 +1634,8 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
   if (st == 0) {
     // L_AA' beta_A = y_A - L_BA' beta_B: the B rows first (column j of L_BA read by thread j: coalesced), then the
     // row-oriented back substitution through L_AA
-    for (int j = tid; j < nA; j += nthr) {
-      double w = yv[j];
-      for (int i = nA; i < r; ++i) w -= G[(size_t)i * (i + 1) / 2 + j] * bv[i];
-      yv[j] = w;
-    }
+    packed_cols_times(G, nA, nB, 0, nA, [&](int) { return 0; }, [&](int i) { return bv[nA + i]; },
+                      [&](int j, double sacc) { yv[j] -= sacc; });
     __syncthreads();
     packed_back_substitute(G, nA, yv, bv, nullptr);
     // ---- one step of iterative refinement: the residual t - (H (H' beta) + lam*D*beta) is formed with two products
@@ -1638,22 +1660,14 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
     }
     __syncthreads();
     packed_forward_substitute(G, nA, qa, qb, nullptr, red);              // y_A
-    for (int i = tid; i < nB; i += nthr) {
-      const double* Li = G + (size_t)(nA + i) * (nA + i + 1) / 2;
-      double sacc = 0.0;
-      for (int k = 0; k < nA; ++k) sacc += Li[k] * qb[k];
-      qa[nA + i] -= sacc;                                                // res_B - L_BA y_A
-    }
+    packed_rows_times(G, nA, nB, 0, qb, [&](int) { return nA; }, [&](int i, double sacc) { qa[nA + i] -= sacc; });   // res_B - L_BA y_A
     __syncthreads();
     if (nB > 0) {
       packed_forward_substitute(T, nB, qa + nA, qb + nA, nullptr, red);  // y_B
       packed_back_substitute(T, nB, qb + nA, qa + nA, nullptr);          // dbeta_B -> qa[nA..r)
     }
-    for (int j = tid; j < nA; j += nthr) {
-      double w = qb[j];
-      for (int i = nA; i < r; ++i) w -= G[(size_t)i * (i + 1) / 2 + j] * qa[i];
-      qb[j] = w;
-    }
+    packed_cols_times(G, nA, nB, 0, nA, [&](int) { return 0; }, [&](int i) { return qa[nA + i]; },
+                      [&](int j, double sacc) { qb[j] -= sacc; });
     __syncthreads();
     packed_back_substitute(G, nA, qb, qa, nullptr);                      // dbeta_A -> qa[0..nA)
     double dmx = 0.0, bmx = 0.0;
