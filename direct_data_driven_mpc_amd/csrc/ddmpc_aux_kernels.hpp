@@ -1108,53 +1108,69 @@ __device__ __forceinline__ void packed_schur_mfma(const double* Lm, int row0, in
   }
 }
 
-// Products with the implicit block-Hankel matrix H (rows rho = k*nch + ch, columns i < c): alpha = H' x and z = H alpha.
-// x and z are r-vectors in COMPONENT order (LDS), alpha is a c-vector in global memory.
-__device__ __forceinline__ void hankel_transpose_times(const KParams& P, const double* __restrict__ ud,
-                                                       const double* __restrict__ yd, const double* x, double* alpha) {
-  const int m = P.m, p = P.p, nch = P.nch;
-  for (int i = threadIdx.x; i < P.c; i += blockDim.x) {
-    // four independent accumulators and a twice-unrolled row loop: the loads of a group are in flight together
-    // (a single dependent load-multiply-add chain over the 608 terms is bound by the memory latency)
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll 2
-    for (int k = 0; k < P.Ln; ++k) {
-      const double* ur = ud + (long long)(i + k) * m;
-      const double* yr = yd + (long long)(i + k) * p;
-      const double* xk = x + k * nch;
-      int ch = 0;
-      for (; ch + 4 <= m; ch += 4) {
-        s0 += ur[ch] * xk[ch]; s1 += ur[ch + 1] * xk[ch + 1]; s2 += ur[ch + 2] * xk[ch + 2]; s3 += ur[ch + 3] * xk[ch + 3];
-      }
-      for (; ch < m; ++ch) s0 += ur[ch] * xk[ch];
-      ch = 0;
-      for (; ch + 4 <= p; ch += 4) {
-        s0 += yr[ch] * xk[m + ch]; s1 += yr[ch + 1] * xk[m + ch + 1]; s2 += yr[ch + 2] * xk[m + ch + 2];
-        s3 += yr[ch + 3] * xk[m + ch + 3];
-      }
-      for (; ch < p; ++ch) s1 += yr[ch] * xk[m + ch];
-    }
-    alpha[i] = (s0 + s1) + (s2 + s3);
-  }
-}
-__device__ __forceinline__ void hankel_times(const KParams& P, const double* __restrict__ ud,
-                                             const double* __restrict__ yd, const double* alpha, double* z) {
-  const int m = P.m, p = P.p, nch = P.nch, c = P.c;
-  for (int rho = threadIdx.x; rho < P.r; rho += blockDim.x) {
-    const int k = rho / nch, ch = rho - k * nch;
-    const double* x = (ch < m) ? ud + (long long)k * m + ch : yd + (long long)k * p + (ch - m);
-    const int st = (ch < m) ? m : p;
-    double sa[8];                                      // eight loads in flight per lane: the loop is latency-bound otherwise
+// z = H (H' x) for the implicit block-Hankel matrix H (rows rho = k*nch + ch, columns i < c); x and z are r-vectors in
+// COMPONENT order (LDS, z must not alias x).  With the trajectory stored channel-interleaved, column i of H is the
+// CONTIGUOUS window xflat[i*nch .. i*nch + r): the trajectory is streamed ONCE through LDS in chunks of time steps and both
+// products are formed from the chunk -- alpha_i = <window_i, x> by one 32-lane half wave per column (conflict-free
+// reads, shuffle reduction), then z += window_i * alpha_i with one thread per component.  `pan`: PSD_PAN doubles of LDS.
+// (alpha itself, c numbers, never leaves the chip.)
+__device__ __forceinline__ void hankel_normal_times(const KParams& P, const double* __restrict__ ud,
+                                                    const double* __restrict__ yd, const double* x, double* z, double* pan) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int hw = tid >> 5, t32 = tid & 31, nhw = nthr >> 5;
+  const int m = P.m, p = P.p, nch = P.nch, c = P.c, r = P.r;
+  const int TC = ((PSD_PAN - r) / (nch + 1)) & ~3;                        // columns per chunk: (TC + Ln) * nch + TC <= PSD_PAN
+  double* xc = pan;                                                         // xc[(t - t0) * nch + ch], t0 <= t < t0 + TC + Ln - 1
+  double* al = pan + (TC + P.Ln) * nch;                                     // alpha of the chunk
+  double zacc[PSD_RPT];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) sa[q] = 0.0;
-    int i = 0;
-    for (; i + 8 <= c; i += 8) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) sa[q] += x[(long long)(i + q) * st] * alpha[i + q];
+  for (int e = 0; e < PSD_RPT; ++e) zacc[e] = 0.0;
+  for (int t0 = 0; t0 < c; t0 += TC) {
+    const int nt = (c - t0) < TC ? (c - t0) : TC;
+    const int nload = (nt + P.Ln - 1) * nch;
+    __syncthreads();                                                        // previous chunk consumed
+    for (int i = tid; i < nload; i += nthr) {
+      const int tt = i / nch, ch = i - tt * nch;
+      xc[i] = (ch < m) ? ud[(long long)(t0 + tt) * m + ch] : yd[(long long)(t0 + tt) * p + (ch - m)];
     }
-    for (; i < c; ++i) sa[0] += x[(long long)i * st] * alpha[i];
-    z[rho] = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]));
+    __syncthreads();
+    for (int ib = 0; ib < nt; ib += nhw) {
+      const int i = ib + hw;
+      double s0 = 0.0, s1 = 0.0;
+      if (i < nt) {
+        const double* win = xc + i * nch;
+        int e = t32;
+        for (; e + 32 < r; e += 64) { s0 += win[e] * x[e]; s1 += win[e + 32] * x[e + 32]; }
+        if (e < r) s0 += win[e] * x[e];
+      }
+      double sacc = s0 + s1;
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 32);
+      if (t32 == 0 && i < nt) al[i] = sacc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < PSD_RPT; ++e) {
+      const int rho = tid + e * nthr;
+      if (rho < r) {
+        const double* colp = xc + rho;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int i = 0;
+        for (; i + 3 < nt; i += 4) {
+          a0 += colp[i * nch] * al[i]; a1 += colp[(i + 1) * nch] * al[i + 1];
+          a2 += colp[(i + 2) * nch] * al[i + 2]; a3 += colp[(i + 3) * nch] * al[i + 3];
+        }
+        for (; i < nt; ++i) a0 += colp[i * nch] * al[i];
+        zacc[e] += (a0 + a1) + (a2 + a3);
+      }
+    }
   }
+#pragma unroll
+  for (int e = 0; e < PSD_RPT; ++e) {
+    const int rho = tid + e * nthr;
+    if (rho < r) z[rho] = zacc[e];
+  }
+  __syncthreads();
 }
 
 // Packed lower triangle of G = H H' for the block-Hankel H of one instance, through the Hankel structure (as in the
@@ -1420,10 +1436,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   packed_back_substitute(G, r, ra, rb, skip);
   for (int k = tid; k < r; k += nthr) ra[perm[k]] = rb[k];           // component order
   __syncthreads();
-  hankel_transpose_times(P, ud, yd, ra, alpha);
-  __syncthreads();
-  hankel_times(P, ud, yd, alpha, rd);
-  __syncthreads();
+  hankel_normal_times(P, ud, yd, ra, rd, pan);
   for (int k = tid; k < r; k += nthr) rz[k] = rd[perm[k]];           // z_ex in position order
   // (b) multipliers of the starting point: L_FF' mu = -L_RF' W (z_R - zs), z_R = z0 + C w2 (the unrefined solution)
   packed_rows_times(G, nF, nR, nF, vv, [&](int i) { return nF + i + 1; },
@@ -1438,10 +1451,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   __syncthreads();
   for (int k = tid; k < r; k += nthr) ra[perm[k]] = rb[k];
   __syncthreads();
-  hankel_transpose_times(P, ud, yd, ra, alpha);
-  __syncthreads();
-  hankel_times(P, ud, yd, alpha, rd);
-  __syncthreads();
+  hankel_normal_times(P, ud, yd, ra, rd, pan);
   for (int k = tid; k < r; k += nthr) rb[k] = rd[perm[k]];
   __syncthreads();
   packed_forward_substitute(G, r, rb, ra, skip, red);                    // ra = L_I^-1 (H_I H' v) = -rw
@@ -1642,16 +1652,12 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
     //      with the implicit Hankel matrix instead of the rounded Gram matrix, the correction is solved with the
     //      block factors of the final active set.  The Gram route squares cond(H); with K applied as H H' the result
     //      is what cond(H) itself allows (cfg-5 size: 1e-7 -> 1e-10 in optimal_u).
-    double* alpha = alpha_ws + b * (long long)P.c;
     // passes repeat until the correction is at rounding level or stops shrinking (cap P.refine_max); DDMPC_REFINE_OFF skips them
     double prev = 1e300;
     for (int pass = 0; P.refine != 0 && pass < P.refine_max; ++pass) {
     for (int i = tid; i < r; i += nthr) qa[perm[i]] = bv[i];            // beta in component order
     __syncthreads();
-    hankel_transpose_times(P, ud, yd, qa, alpha);
-    __syncthreads();
-    hankel_times(P, ud, yd, alpha, qb);                                  // H H' beta, component order
-    __syncthreads();
+    hankel_normal_times(P, ud, yd, qa, qb, pan);                         // H H' beta, component order
     for (int i = tid; i < r; i += nthr) {
       const int rho = perm[i];
       const int a = act[i];
