@@ -657,9 +657,9 @@ constexpr int PSD_PAN = 2048;   // doubles of LDS scratch (1312 used by the fact
 //     X' = Mt P' -- 4 MFMAs per tile -- and the second half of the panel is updated with the first by 4 more.
 //   * traffic: the factor is streamed once per 32 columns (left-looking), half of what 16-wide panels read.
 //
-// Row tiles are dealt round-robin to the waves, PSD_TG tiles per wave and pass (64 accumulator VGPRs).
+// Row tiles are dealt round-robin to the waves, PSD_TG tiles per wave and pass (48 accumulator VGPRs).
 // LDS: 1312 doubles of `pan`.  Requires at least two waves (blockDim.x a multiple of 64, >= 128).
-constexpr int PSD_TG = 4;
+constexpr int PSD_TG = 3;
 typedef double d2u8 __attribute__((ext_vector_type(2), aligned(8)));     // 16-byte load from an 8-byte aligned packed row
 
 // One wave factors a 16x16 tile held row-major in LDS (lower triangle valid), columns [0, nbt): pivots <= tol_abs are
@@ -667,23 +667,31 @@ typedef double d2u8 __attribute__((ext_vector_type(2), aligned(8)));     // 16-b
 // operand of X' = Mt P').  `skipout` receives nbt flags.
 __device__ __forceinline__ void psd_tile_factor(double* Dg, double* Ms, double* Dinv, int nbt, double tol_abs, int* skipout) {
   const int lane = threadIdx.x & 63;
+  const int rr = lane & 15, cg = lane >> 4;            // lane = (row of the tile, one of four column groups)
   for (int c = 0; c < nbt; ++c) {
+    // one LDS round trip per column: every lane reads the pivot, its row's entry of column c and the column-c entries
+    // of the (up to four) columns it updates, scales them itself and writes the results back
     const double dk = Dg[c * 16 + c];
+    const double lrc = Dg[rr * 16 + c];
+    double lcc[4], old[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c2 = c + 1 + cg + 4 * t;
+      const bool on = c2 < nbt && c2 <= rr;
+      lcc[t] = on ? Dg[c2 * 16 + c] : 0.0;
+      old[t] = on ? Dg[rr * 16 + c2] : 0.0;
+    }
     const bool sk = !(dk > tol_abs);                   // the same value in every lane
     const double inv = sk ? 0.0 : 1.0 / sqrt(dk);
-    __builtin_amdgcn_wave_barrier();                   // every lane holds the pivot before it is overwritten
-    if (lane < 16 - c) Dg[(c + lane) * 16 + c] *= inv;
+    const double u = lrc * inv;
+    if (cg == 0 && rr >= c) Dg[rr * 16 + c] = u;
     if (lane == 0) { skipout[c] = sk ? 1 : 0; Dinv[c] = inv; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (!sk) {
-      const int remc = nbt - c - 1, remr = 15 - c;     // columns c+1 .. nbt-1, rows c+1 .. 15
-      for (int x = lane; x < remr * remc; x += 64) {
-        const int rr = c + 1 + x / remc, c2 = c + 1 + x % remc;
-        if (c2 <= rr) Dg[rr * 16 + c2] -= Dg[rr * 16 + c] * Dg[c2 * 16 + c];
-      }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c2 = c + 1 + cg + 4 * t;
+      if (c2 < nbt && c2 <= rr) Dg[rr * 16 + c2] = old[t] - u * (lcc[t] * inv);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // in-wave hand-off through LDS
     __builtin_amdgcn_wave_barrier();
   }
   if (lane < 16) {                                     // column `lane` of L~^-1 by forward substitution, rows of skipped pivots zero
@@ -736,19 +744,26 @@ __device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol
         const d2u8 a0 = *reinterpret_cast<const d2u8*>(pa + j0), a1 = *reinterpret_cast<const d2u8*>(pa + j0 + 2);
         d2u8 b0 = a0, b1 = a1;
         if (nbb > 0) { b0 = *reinterpret_cast<const d2u8*>(pb + j0); b1 = *reinterpret_cast<const d2u8*>(pb + j0 + 2); }
+        // every load of the chunk is issued before the first MFMA (row pointers of idle slots are clamped to a valid
+        // row): one memory round trip per 16 columns, not one per row tile
+        d2u8 x0[PSD_TG], x1[PSD_TG];
+#pragma unroll
+        for (int s = 0; s < PSD_TG; ++s) {
+          x0[s] = *reinterpret_cast<const d2u8*>(rp[s] + j0);
+          x1[s] = *reinterpret_cast<const d2u8*>(rp[s] + j0 + 2);
+        }
 #pragma unroll
         for (int s = 0; s < PSD_TG; ++s) {
           if (ti[s] < ntile) {
-            const d2u8 x0 = *reinterpret_cast<const d2u8*>(rp[s] + j0), x1 = *reinterpret_cast<const d2u8*>(rp[s] + j0 + 2);
-            acc[s][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], x0[0], acc[s][0], 0, 0, 0);
-            acc[s][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], x0[1], acc[s][0], 0, 0, 0);
-            acc[s][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], x1[0], acc[s][0], 0, 0, 0);
-            acc[s][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], x1[1], acc[s][0], 0, 0, 0);
+            acc[s][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], x0[s][0], acc[s][0], 0, 0, 0);
+            acc[s][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], x0[s][1], acc[s][0], 0, 0, 0);
+            acc[s][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], x1[s][0], acc[s][0], 0, 0, 0);
+            acc[s][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], x1[s][1], acc[s][0], 0, 0, 0);
             if (nbb > 0 && ti[s] > 0) {
-              acc[s][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[0], x0[0], acc[s][1], 0, 0, 0);
-              acc[s][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[1], x0[1], acc[s][1], 0, 0, 0);
-              acc[s][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[0], x1[0], acc[s][1], 0, 0, 0);
-              acc[s][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[1], x1[1], acc[s][1], 0, 0, 0);
+              acc[s][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[0], x0[s][0], acc[s][1], 0, 0, 0);
+              acc[s][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[1], x0[s][1], acc[s][1], 0, 0, 0);
+              acc[s][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[0], x1[s][0], acc[s][1], 0, 0, 0);
+              acc[s][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[1], x1[s][1], acc[s][1], 0, 0, 0);
             }
           }
         }
@@ -856,21 +871,16 @@ __device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol
 // unknowns, so their loads are issued BEFORE the block solve: two workgroup barriers and one global round trip per 16
 // rows (the row-by-row form paid a barrier and two dependent round trips per row, ~1 ms for 608 rows).
 // y is consumed (overwritten), x must not alias it; `skip` (optional) marks rows whose unknown is zero.
-// Requires n <= PSD_RPT * blockDim.x.
-constexpr int PSD_RPT = 2;      // entries of y per thread
+constexpr int PSD_RPT = 2;      // r-vector entries per thread where a routine keeps them in registers (r <= PSD_RPT * blockDim.x)
 __device__ __forceinline__ void packed_back_substitute(const double* Lm, int n, double* y, double* x, const int* skip) {
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int a = tid & 15;
   for (int k0 = ((n - 1) >> 4) << 4; k0 >= 0; k0 -= 16) {
     const int nb = (n - k0) < 16 ? (n - k0) : 16;
-    // operands of the update of the rows above the block: Lu[e][q] = L(k0 + q, j), j = tid + e * nthr < k0
-    double Lu[PSD_RPT][16];
+    // operands of the update of the rows above the block: Lu[q] = L(k0 + q, j), j = tid < k0
+    double Lu[16];
 #pragma unroll
-    for (int e = 0; e < PSD_RPT; ++e) {
-      const int j = tid + e * nthr;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) Lu[e][q] = (j < k0 && q < nb) ? Lm[(size_t)(k0 + q) * (k0 + q + 1) / 2 + j] : 0.0;
-    }
+    for (int q = 0; q < 16; ++q) Lu[q] = (tid < k0 && q < nb) ? Lm[(size_t)(k0 + q) * (k0 + q + 1) / 2 + tid] : 0.0;
     if (tid < 64) {
       // lane a owns unknown k0 + a and column a of the diagonal block: Lc[q] = L(k0 + q, k0 + a), q >= a
       double Lc[16];
@@ -889,15 +899,16 @@ __device__ __forceinline__ void packed_back_substitute(const double* Lm, int n, 
       if (tid < nb) x[k0 + a] = v * inv;
     }
     __syncthreads();
+    if (tid < k0) {
+      double sacc = 0.0;
 #pragma unroll
-    for (int e = 0; e < PSD_RPT; ++e) {
-      const int j = tid + e * nthr;
-      if (j < k0) {
-        double sacc = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) sacc += Lu[e][q] * ((q < nb) ? x[k0 + q] : 0.0);
-        y[j] -= sacc;
-      }
+      for (int q = 0; q < 16; ++q) sacc += Lu[q] * ((q < nb) ? x[k0 + q] : 0.0);
+      y[tid] -= sacc;
+    }
+    for (int j = tid + nthr; j < k0; j += nthr) {       // more rows than threads: the remaining entries, loaded now
+      double sacc = 0.0;
+      for (int q = 0; q < nb; ++q) sacc += Lm[(size_t)(k0 + q) * (k0 + q + 1) / 2 + j] * x[k0 + q];
+      y[j] -= sacc;
     }
     __syncthreads();
   }
@@ -1027,14 +1038,15 @@ __device__ __forceinline__ void packed_weighted_gram_mfma(const double* Lm, int 
         const size_t ri = (size_t)(row0 + (i < nR ? i : nR - 1));
         const double* Li = Lm + ri * (ri + 1) / 2 + row0;
         const double av = (i < nR && a <= i) ? Li[a] * w[i] : 0.0;
+        double bv[4];                                    // all loads of the step before the first MFMA
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          if (B0 + g <= A) {
-            const int bcol = 16 * (B0 + g) + l15;
-            const double bv = (i < nR && bcol <= i) ? Li[bcol] : 0.0;
-            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[g], 0, 0, 0);
-          }
+          const int bcol = 16 * ((B0 + g <= A) ? B0 + g : A) + l15;
+          bv[g] = (i < nR && bcol <= i) ? Li[bcol] : 0.0;
         }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (B0 + g <= A) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[g], acc[g], 0, 0, 0);
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -1075,18 +1087,23 @@ __device__ __forceinline__ void packed_schur_mfma(const double* Lm, int row0, in
           a0[0] = (kk < nk) ? a0[0] : 0.0; a0[1] = (kk + 1 < nk) ? a0[1] : 0.0;
           a1[0] = (kk + 2 < nk) ? a1[0] : 0.0; a1[1] = (kk + 3 < nk) ? a1[1] : 0.0;
         }
+        d2u8 b0[4], b1[4];                               // all loads of the chunk before the first MFMA
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          b0[g] = *reinterpret_cast<const d2u8*>(rb[g] + k0);
+          b1[g] = *reinterpret_cast<const d2u8*>(rb[g] + k0 + 2);
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           if (B0 + g <= A) {
-            d2u8 b0 = *reinterpret_cast<const d2u8*>(rb[g] + k0), b1 = *reinterpret_cast<const d2u8*>(rb[g] + k0 + 2);
             if (k0 + 16 > nk) {                          // (a zero on one side is not enough: the other side may hold anything)
-              b0[0] = (kk < nk) ? b0[0] : 0.0; b0[1] = (kk + 1 < nk) ? b0[1] : 0.0;
-              b1[0] = (kk + 2 < nk) ? b1[0] : 0.0; b1[1] = (kk + 3 < nk) ? b1[1] : 0.0;
+              b0[g][0] = (kk < nk) ? b0[g][0] : 0.0; b0[g][1] = (kk + 1 < nk) ? b0[g][1] : 0.0;
+              b1[g][0] = (kk + 2 < nk) ? b1[g][0] : 0.0; b1[g][1] = (kk + 3 < nk) ? b1[g][1] : 0.0;
             }
-            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], b0[0], acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], b0[1], acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], b1[0], acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], b1[1], acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], b0[g][0], acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], b0[g][1], acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], b1[g][0], acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], b1[g][1], acc[g], 0, 0, 0);
           }
         }
       }
