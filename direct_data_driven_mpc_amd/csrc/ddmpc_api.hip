@@ -121,7 +121,7 @@ struct KernelChoice {
 #endif
 const KernelChoice kKernels[] = {
 #define DDMPC_INSTANCE(NT, W) \
-  {NT, W, DDMPC_V1_FN(NT, W), "ddmpc_cold_solve_kernel_v1<" #NT "," #W ">", &ddmpc_cold_solve_kernel2<NT, W, false>, "ddmpc_cold_solve_kernel<" #NT "," #W ">", &ddmpc_cold_solve_kernel2<NT, W, true>},
+  {NT, W, DDMPC_V1_FN(NT, W), "ddmpc_cold_solve_kernel_v1<" #NT "," #W ">", &ddmpc_cold_solve_kernel2<NT, W, false>, "ddmpc_cold_solve_kernel2<" #NT "," #W ">", &ddmpc_cold_solve_kernel2<NT, W, true>},
 #include "ddmpc_instances.inc"
 #undef DDMPC_INSTANCE
 };
@@ -431,7 +431,6 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   k.sig_scale = -k.lam / k.lamb_sigma;
   k.box_cost = k.lamb_sigma * k.bound * k.bound;
   k.max_iter = p.max_iter > 0 ? p.max_iter : 50;
-  k.dev = getenv("DDMPC_DEV") ? atoi(getenv("DDMPC_DEV")) : 0;
   k.refine = getenv("DDMPC_REFINE") ? atoi(getenv("DDMPC_REFINE")) : DDMPC_REFINE_AUTO;   // env: development knob
   k.refine_max = 3;
   k.refine_cond = std::pow(10.0, 6.3);   // 2e6:     // four-tank benchmark data: 1.0e6..1.3e6 with errors ~1e-12 (not refined); see DESIGN.md section 9

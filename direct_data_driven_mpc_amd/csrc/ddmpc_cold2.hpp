@@ -13,8 +13,12 @@
 //     rank-4 updates inside the tile are 2 MFMAs per sub-step.  The other waves do nothing but MFMAs.
 //   * per 16 columns: 2 workgroup barriers (M ready -> TRSM; panel dumped -> trailing update) instead of 8, and the
 //     redundant per-thread 4x4 factorisations of the first kernel happen on one wave only.
-//   * L y = t rides along as column rE of the matrix; L' beta = y is a VALU sweep over the register tiles
-//     (4 multiply-adds per tile + one 16-lane DPP reduction per tile column and wave) and a 16x16 product with M.
+//   * L y = t rides along as column rE of the matrix; L' beta = y runs tile column by tile column, right to left, with
+//     ONE workgroup barrier per column: every wave sums its tiles' contributions (4 multiply-adds per tile + one 16-lane
+//     DPP reduction) into LDS, then every wave forms x_J = M_J' (y_J - parts) redundantly from the M tiles in LDS.
+//   * the panel wave's chain (four 4-wide sub-steps per diagonal tile) is the critical path: the other waves' TRSM and
+//     trailing updates of step J run beside the factorisation of diagonal tile J+1 (its update with panel J comes first),
+//     and diagonal tile 0 is factored beside the other waves' Gram walks.
 //   * the beta / active-set workspace is written only when asked for (ddmpc_get_solution re-solves on demand).
 //
 // Reference formulation: direct_data_driven_mpc_controller.py:409-445 (variables), :506-677 (constraints),
@@ -532,7 +536,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
       // (4) panel wave: its walk is short (one diagonal); diagonal tile 0 is fixed up and factored NOW, beside the other
       //     waves' walks and fix-ups (its chain is the longest single piece of the workgroup's critical path)
       if constexpr (WAVE == 0 && W > 1) {
-        if (rE >= 16 && !(P.dev & 4)) {                   // (tiny systems keep the plain order: their rhs row sits in tile 0)
+        if (rE >= 16) {                                   // (tiny systems keep the plain order: their rhs row sits in tile 0)
           constexpr int S0 = TM::slot(0, 0);
           d4 Ad = fix_tile(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, acc[S0]);
           d4 Et;

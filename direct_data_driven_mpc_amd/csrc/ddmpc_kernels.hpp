@@ -69,7 +69,6 @@ struct KParams {
   int refine_max;       // cap on refinement passes per factorisation
   double refine_cond;   // auto: refine when max K_kk * max 1/d_k (a lower bound of cond K) exceeds this
   int epoch;            // launch counter of the handle (AUTO refinement: flags / last-flagged stamp carry it, nothing is cleared)
-  int dev;              // development switches for in-process A/B measurements (env DDMPC_DEV at create); 0 in production
   int dense_w;          // 1: dense weighting matrices -> lam * W^-1 is the full [RP][RP] matrix `dmat`
   const double* dmat;   //    (shared by the batch, zero outside the weighted components), tabd D0 = D1 = 0
 };

@@ -62,9 +62,10 @@ extern "C" {
 
 #define DDMPC_WEIGHT_SCALAR 0       /* Q = q*I, R = r*I (what the reference loader builds,
                                        utilities/controller/controller_creation.py:125-127) */
-#define DDMPC_WEIGHT_DIAG   1       /* Q = diag(q[0..p*L)), R = diag(r[0..m*L)) */
+#define DDMPC_WEIGHT_DIAG   1       /* Q = diag(q[0..p*L)), R = diag(r[0..m*L)); entries >= 0 (a zero weight leaves the
+                                       component free) */
 #define DDMPC_WEIGHT_DENSE  2       /* Q [p*L, p*L], R [m*L, m*L] row-major, symmetric, positive definite on the free
-                                       prediction steps (controller.py:121-124,708-710); not with slack CONVEX */
+                                       prediction steps (controller.py:121-124,708-710); every slack mode */
 
 #define DDMPC_MEM_HOST   0
 #define DDMPC_MEM_DEVICE 1

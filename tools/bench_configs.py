@@ -6,6 +6,8 @@ import torch
 from direct_data_driven_mpc_amd import _lib as L
 from direct_data_driven_mpc_amd.engine import BatchedDDMPC
 from direct_data_driven_mpc_amd.harness import controller_params, generate_batch
+sys.path.insert(0, "tools")
+from cfg5_time import large_flops, PEAK_TF      # algorithmic flop model of the global-workspace kernels
 
 def run(tag, B, Lh, N, slack, gram=0, steps=10, host=False, pipelined=False):
     cfg = controller_params(dict(L=Lh, N=N, slack_var_constraint_type=slack))
@@ -39,7 +41,9 @@ def run(tag, B, Lh, N, slack, gram=0, steps=10, host=False, pipelined=False):
         st = out[2].cpu().numpy(); it = out[3].cpu().numpy()
         tag += " status_ok=%d iters_mean=%.2f" % (int((st == 0).sum()), it.mean())
     f, b = eng.cost_model()
-    print("%-70s kernel %-30s B=%6d  %.3f ms/step  %.3e solves/s  %.2f TFLOP/s(alg)" % (tag, eng.kernel_name(), B, dt * 1e3, B / dt, f * B / dt / 1e12), flush=True)
+    tf = f * B / dt / 1e12
+    print("%-70s kernel %-30s B=%6d  %.3f ms/step  %.3e solves/s  %.2f TFLOP/s(alg) = %.3f of the %.1f TF fp64-MFMA peak" % (
+        tag, eng.kernel_name(), B, dt * 1e3, B / dt, tf, tf / PEAK_TF, PEAK_TF), flush=True)
     eng.close()
 
 run("cfg2 robust NONE structured", 4096, 30, 400, 0)
@@ -75,8 +79,10 @@ def run_config5(B=512):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
     st = out[2].cpu().numpy()
-    print("%-70s kernel %-30s B=%6d  %.3f ms/step  %.3e solves/s" % (
-        "cfg5 nominal, m=p=8 n=8 L=30 N=2000, exact data status_ok=%d" % int((st == 0).sum()), eng.kernel_name(), B, dt * 1e3, B / dt), flush=True)
+    tf = large_flops(m, p, n, Lh, N, False) * B / dt / 1e12
+    print("%-70s kernel %-30s B=%6d  %.3f ms/step  %.3e solves/s  %.2f TFLOP/s(alg) = %.3f of the %.1f TF fp64-MFMA peak" % (
+        "cfg5 nominal, m=p=8 n=8 L=30 N=2000, exact data status_ok=%d" % int((st == 0).sum()), eng.kernel_name(), B, dt * 1e3, B / dt,
+        tf, tf / PEAK_TF, PEAK_TF), flush=True)
     eng.close()
 
 

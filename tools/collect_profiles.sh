@@ -32,4 +32,27 @@ pass sq2 GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ
 
 timeout -k 10 120 python tools/phase_stamps.py > "$OUT/phase_stamps.log" 2>&1
 timeout -k 10 300 python tools/bench_configs.py > "$OUT/other_configs.log" 2>&1
+echo "[collect] other configs done"
+
+# BASELINE configs[4] (nominal, m=p=8, r=608, exact data) and the robust scheme at that size: the global-workspace kernels
+timeout -k 10 200 python tools/cfg5_time.py > "$OUT/cfg5_time.log" 2>&1
+timeout -k 10 200 python tools/cfg5_time.py --robust >> "$OUT/cfg5_time.log" 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg5_stats" -- \
+    python tools/cfg5_time.py --steps 3 > "$OUT/cfg5_stats.log" 2>&1
+pass5() {  # name, counters...
+    local name=$1; shift
+    timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/cfg5_pmc_$name" -- \
+        python tools/cfg5_time.py --steps 2 > "$OUT/cfg5_pmc_$name.log" 2>&1
+    echo "[collect] cfg5 pmc $name done"
+}
+pass5 fetch FETCH_SIZE
+pass5 write WRITE_SIZE
+pass5 sq SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES SQ_WAVE_CYCLES
+timeout -k 10 200 python tools/rr_stamps.py > "$OUT/cfg5_phase_stamps.log" 2>&1
+timeout -k 10 400 python tools/config5_check.py --check 512 > "$OUT/cfg5_parity.log" 2>&1
+timeout -k 10 600 python tools/config5_check.py --robust --check 512 > "$OUT/cfg5size_robust_parity.log" 2>&1
+timeout -k 10 400 python tools/large_fuzz.py --cases 12 > "$OUT/large_kernel_fuzz.log" 2>&1
+echo "[collect] cfg5 done"
+# refinement modes on the benchmark data and on the 96-case random-plant sweep (conditioning estimate, off / auto / always)
+timeout -k 10 900 python tools/refine_calib.py > "$OUT/refine_calib.log" 2>&1
 echo "[collect] all done"

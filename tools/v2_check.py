@@ -82,18 +82,6 @@ if __name__ == "__main__":
                 print("DDMPC_KERNEL=%s DDMPC_REFINE=%s" % (gen, ref), end="  ")
                 timing(4096, 0, stamps=False)
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "ab":          # in-process A/B of development switches (same box, same clocks)
-        for rep in range(3):
-            for dev in sys.argv[2:]:
-                os.environ["DDMPC_DEV"] = dev
-                print("DDMPC_DEV=%s" % dev, end="  ")
-                timing(4096, 0, stamps=False)
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "fine":        # sub-step internals (dev bit 1): slots = F: mfma+extract, B: factor, T: reads, A: subst, U: LT write+permlane
-        os.environ["DDMPC_DEV"] = "2"
-        for B in (256, 4096):
-            timing(B, 0)
-        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "occ":         # phase stamps at 1, 2 and 3 workgroups per CU
         for B in (256, 512, 768, 4096):
             timing(B, 0)
