@@ -339,7 +339,7 @@ def main():
                        "kernel": eng.kernel_name(), "non_optimal_instances": n_bad, "kernel_source_hash": kernel_source_hash()},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": pmc_traffic("ddmpc_cold_solve_kernel", a.batch_per_gpu, a.slack),
+                         "traffic": pmc_traffic("ddmpc_cold_solve_kernel2", a.batch_per_gpu, a.slack),
                          "kernel_ms": kern_ms, "flops_per_solve": flops, "hbm_bytes_per_solve": bytes_,
                          "hbm_GBps_algorithmic": bytes_ * B / (kern_ms * 1e-3) / 1e9},
         }
