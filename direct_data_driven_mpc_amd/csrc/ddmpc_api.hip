@@ -476,6 +476,15 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
         return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: (m+p)(L+n) = %d rows (the global-workspace kernels hold %d)", k.r, PSD_RPT * 512);
       }
     }
+    {   // the trajectory is streamed through the PSD_PAN doubles of LDS scratch in chunks of time steps: a chunk must hold
+        // at least four of them next to the L+n steps of overlap (hankel_gram_packed, hankel_normal_times)
+      const int tch = ((PSD_PAN / k.nch) - k.Ln) & ~3, tc = ((PSD_PAN - k.r) / (k.nch + 1)) & ~3;
+      if (tch < 4 || tc < 4) {
+        delete h;
+        return fail(DDMPC_ERR_UNSUPPORTED, "problem shape not supported by the global-workspace kernels: m+p = %d channels with "
+                    "L+n = %d", k.nch, k.Ln);
+      }
+    }
     h->large = true;
     h->large_nominal = (p.controller_type == DDMPC_NOMINAL);
     h->kc = h->large_nominal ? kLargeNominal : kLargeSolve;

@@ -1314,6 +1314,11 @@ def test_config5_size_nominal_runs_on_the_rank_revealing_kernel(gpu):
     with pytest.raises(L.DDMPCError, match="too large"):
         BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=3.0 * np.eye(p * Lh) + 0.01, R=1e-4 * np.eye(m * Lh), u_s=u_s, y_s=y_s,
                      batch=1, controller_type=L.ROBUST, eps_max=0.002, lamb_alpha=50.0, lamb_sigma=1000.0, c=1.0)
+    # a shape whose trajectory chunks would not fit the kernels' LDS scratch (hundreds of channels, three time steps) is
+    # refused when the controller is created, not discovered on the device
+    with pytest.raises(L.DDMPCError, match="not supported by the global-workspace kernels"):
+        BatchedDDMPC(n=1, m=170, p=170, L_=2, N=4000, Q=1.0, R=1.0, u_s=np.zeros(170), y_s=np.zeros(170), batch=1,
+                     controller_type=L.ROBUST, eps_max=0.002, lamb_alpha=50.0, lamb_sigma=1000.0, c=1.0)
 
 
 def test_plain_c_caller_of_the_abi(gpu, tmp_path):
