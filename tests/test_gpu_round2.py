@@ -301,3 +301,67 @@ def test_auto_refinement_flags_ill_conditioned_instances_only(gpu):
     assert err["always"][0] < TOL_U and err["always"][1] < TOL_COST, err
     assert err["auto"][0] < TOL_U and err["auto"][1] < TOL_COST, err
     assert err["off"][0] > 10 * err["always"][0], err                          # the Gram route alone is visibly worse here
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [1, 2, 4], ids=["m3p2-convex", "m1p4-none", "m2p5-none-ucon"])
+def test_global_workspace_kernels_with_channel_counts_that_do_not_fill_a_tile(gpu, case):
+    # beyond 271 rows the Gram, the Cholesky, the Schur complement and C'WC run on 16x16 MFMA tiles over packed matrices:
+    # channel counts 5 and 7 (partly filled lag tiles, panels that end inside a tile) on seeded random plants, against the
+    # full-space oracle (the cases of tools/large_fuzz.py; controller.py:506-547,679-722)
+    from direct_data_driven_mpc_amd.harness import generate_batch
+    rng = np.random.default_rng(5000 + case)
+    m, p = [(2, 2), (3, 2), (1, 4), (4, 1), (2, 5), (3, 3)][case % 6]
+    ns = n = int(rng.integers(2, 5))
+    rows = int(rng.integers(280, 780))
+    Lh = max(2 * n, rows // (m + p) - n)
+    N = (m + 1) * (Lh + 2 * n) + int(rng.integers(150, 400))
+    eps = 0.002
+    slack = "convex" if case % 2 == 1 else "none"
+    tec = case % 5 != 4
+    Q = np.diag(rng.uniform(1.0, 4.0, p * Lh)); R = np.diag(rng.uniform(0.01, 0.1, m * Lh))
+    A = rng.normal(size=(ns, ns)); A *= rng.uniform(0.5, 0.9) / max(abs(np.linalg.eigvals(A)))
+    plant = dict(A=A, B=rng.normal(size=(ns, m)), C=rng.normal(size=(p, ns)), D=np.zeros((p, m)), eps_max=eps)
+    spec = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=Q, R=R, u_s=rng.uniform(-0.5, 0.5, m), y_s=rng.uniform(-0.5, 0.5, p),
+                      robust=True, eps_max=eps, lamb_alpha=20.0, lamb_sigma=500.0, c=1.0, slack=slack, tec=tec)
+    B = 2
+    d = generate_batch(range(case * 10, case * 10 + B), N=N, plant=plant)
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    with BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=np.diag(Q), R=np.diag(R), u_s=spec.u_s, y_s=spec.y_s, batch=B,
+                      controller_type=L.ROBUST, slack_type=L.SLACK_CONVEX if slack == "convex" else L.SLACK_NONE, eps_max=eps,
+                      lamb_alpha=20.0, lamb_sigma=500.0, c=1.0, use_terminal_constraint=tec) as eng:
+        assert eng.kernel_name() == "ddmpc_large_solve_kernel" and (m + p) * (Lh + n) > 271
+        eng.set_data(d["u_d"], d["y_d"])
+        u, cost, status, iters = eng.solve(up, yp)
+    for b in range(B):
+        sol = orc.solve_fullspace(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
+        assert L.STATUS_STRINGS[int(status[b])] == sol.status == "optimal"
+        if slack == "convex":
+            assert int(iters[b]) == sol.iters
+        assert np.max(np.abs(u[b] - sol.optimal_u)) <= TOL_U * max(np.max(np.abs(sol.optimal_u)), 1e-3)
+        assert abs(cost[b] - sol.cost) <= TOL_COST * max(abs(sol.cost), 1e-6)
+
+
+@pytest.mark.gpu
+def test_nominal_rescue_on_exact_data_of_a_plant_with_five_channels(gpu):
+    # the rank-revealing rescue (exact data, controller.py:506-538) on a random stable plant with m = 2, p = 3: the lag
+    # tiles of its Hankel Gram are only partly filled; against the SVD-based CPU solve and the analytic properties
+    from direct_data_driven_mpc_amd.harness import generate_batch
+    from oracle.nominal_exact import solve_nominal_exact
+    rng = np.random.default_rng(77)
+    ns = n = 3; m, p = 2, 3; Lh = 12; N = 260; B = 3
+    A = rng.normal(size=(ns, ns)); A *= 0.8 / max(abs(np.linalg.eigvals(A)))
+    plant = dict(A=A, B=rng.normal(size=(ns, m)), C=rng.normal(size=(p, ns)), D=np.zeros((p, m)), eps_max=0.0)
+    u_s = np.array([0.3, -0.2]); y_s = (plant["C"] @ np.linalg.inv(np.eye(ns) - A) @ plant["B"]) @ u_s    # a true equilibrium
+    spec = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=2.0 * np.eye(p * Lh), R=0.1 * np.eye(m * Lh), u_s=u_s, y_s=y_s, robust=False,
+                      eps_max=0.0, lamb_alpha=0.0, lamb_sigma=0.0, c=0.0, slack="none", tec=True)
+    d = generate_batch(range(B), N=N, plant=plant)
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    with BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=2.0, R=0.1, u_s=u_s, y_s=y_s, batch=B, controller_type=L.NOMINAL) as eng:
+        eng.set_data(d["u_d"], d["y_d"])
+        u, cost, status, _ = eng.solve(up, yp)
+    for b in range(B):
+        ref = solve_nominal_exact(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
+        assert ref["status"] == "optimal" and L.STATUS_STRINGS[int(status[b])] == "optimal", (b, ref["residual"])
+        assert np.max(np.abs(u[b] - ref["optimal_u"])) <= TOL_U * np.max(np.abs(ref["optimal_u"])), b
+        assert abs(cost[b] - ref["cost"]) <= 1e-8 * max(abs(ref["cost"]), 1e-6)
