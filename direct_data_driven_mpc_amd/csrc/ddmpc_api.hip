@@ -641,13 +641,11 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
     if ((rc = h->d_act.ensure((size_t)h->batch * h->kp.rE))) return rc;
     const size_t lds = 6 * rv * sizeof(double) + 4 * rv * sizeof(int) + (size_t)PSD_PAN * sizeof(double);
     if (lds + 1024 > 160 * 1024) return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: %zu rows", r);
-    if ((rc = h->d_alpha.ensure((size_t)h->batch * (size_t)h->kp.c * sizeof(double)))) return rc;
     if (lds > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_large_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(ddmpc_large_solve_kernel, dim3((unsigned)h->batch), dim3(large_threads(r)), lds, h->stream,
                        kp_override ? *kp_override : h->kp, 16 * h->kc.NT, h->ud, h->yd, up, yp, uo, cost, (int*)status,
-                       (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, (double*)h->d_rr.p, (long long)stride,
-                       (double*)h->d_alpha.p);
+                       (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, (double*)h->d_rr.p, (long long)stride);
     HIP_TRY(hipGetLastError());
     return DDMPC_OK;
   }
@@ -741,8 +739,8 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
     lds = vec_bytes;
   }
   if (lds + 1024 > 160 * 1024) return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: %zu rows", r);
-  {   // per instance: a c-vector for the products with the implicit Hankel matrix + the r-vector w of the refinement passes
-    int rca = h->d_alpha.ensure((size_t)h->batch * ((size_t)h->kp.c + (size_t)h->kp.r) * sizeof(double));
+  {   // per instance: the r-vector w of the refinement passes
+    int rca = h->d_alpha.ensure((size_t)h->batch * (size_t)h->kp.r * sizeof(double));
     if (rca) return rca;
   }
   {   // z per component + "rescued" flag per instance, read by ddmpc_get_solution

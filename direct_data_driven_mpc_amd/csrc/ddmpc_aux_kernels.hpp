@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
                                                                double* __restrict__ u_opt, double* __restrict__ cost,
                                                                int* __restrict__ status, int* __restrict__ iters,
                                                                double rank_tol, double feas_tol, double* scratch,
-                                                               long long scratch_stride, double* alpha_ws,
+                                                               long long scratch_stride, double* w_ws,
                                                                unsigned long long* dbg, double* __restrict__ z_ws,
                                                                int* __restrict__ rescued) {
   extern __shared__ __attribute__((aligned(16))) double rsm_lds[];
@@ -1437,8 +1437,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   //      B and B' are applied EXACTLY -- two products with the implicit Hankel matrix and one triangular solve each --
   //      while the correction is solved with the factors at hand (L in place of B).  The Gram route squares cond(H);
   //      this step brings the result back to what cond(H) itself allows.
-  double* alpha = alpha_ws + b * (long long)(c + r);
-  double* wk = alpha + c;                                               // the current w = [w1; w2], position order
+  double* wk = w_ws + b * (long long)r;                                 // the current w = [w1; w2], position order
   for (int k = tid; k < r; k += nthr) wk[k] = (k < nF) ? col[k] : vv[k - nF];
   __syncthreads();
   // The pass is repeated while it still pays: the correction of pass k is applied through the rounded factors, so the
@@ -1549,7 +1548,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
                                                                 int* __restrict__ status, int* __restrict__ iters,
                                                                 double* __restrict__ beta_ws,
                                                                 signed char* __restrict__ act_ws, double* scratch,
-                                                                long long scratch_stride, double* alpha_ws) {
+                                                                long long scratch_stride) {
   extern __shared__ __attribute__((aligned(16))) double lsm_lds[];
   const long long b = blockIdx.x;
   const int tid = threadIdx.x, nthr = blockDim.x;
