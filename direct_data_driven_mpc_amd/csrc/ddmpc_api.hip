@@ -620,6 +620,16 @@ static unsigned large_threads(size_t r) {   // workgroup size of the global-work
 
 // want_ws: also write the beta / active-set workspace (what ddmpc_get_solution, the gain kernel and the slack-box warm
 // step read).  A plain cold solve skips it (1.2 KB of HBM writes per instance) and ddmpc_get_solution re-solves on demand.
+// Next launch stamp of the AUTO refinement flags (flag[b] == stamp <=> instance b was flagged by THIS launch; the counter word
+// holds the largest stamp that flagged anything).  Stamps only grow, so nothing is cleared between launches -- except
+// before the 32-bit stamp would wrap, when the flags and the counter are zeroed once and the stamps restart.
+static int next_refine_epoch(ddmpc_handle* h) {
+  if (h->epoch >= 0x3fffffff &&
+      (!h->d_rflag.p || hipMemsetAsync(h->d_rflag.p, 0, h->d_rflag.bytes, h->stream) == hipSuccess))
+    h->epoch = 0;
+  return ++h->epoch;
+}
+
 static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
                        int32_t* status, int32_t* iters, double* lfac = nullptr, const int* only = nullptr,
                        const KParams* kp_override = nullptr, bool want_ws = true, double* lfacT = nullptr) {
@@ -674,7 +684,7 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
       if (fresh) HIP_TRY(hipMemsetAsync(h->d_rflag.p, 0, ((size_t)h->batch + 1) * sizeof(int), h->stream));
       int* rcount = (int*)h->d_rflag.p + h->batch;
       if (only) HIP_TRY(hipMemsetAsync(h->d_rflag.p, 0, (size_t)h->batch * sizeof(int), h->stream));   // filtered-out instances: no flag
-      kq.epoch = ++h->epoch;
+      kq.epoch = next_refine_epoch(h);
       hipLaunchKernelGGL(h->kc.fn2, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                          (int*)iters, bws, aws, stp, lfac, lfacT, (int*)h->d_rflag.p, only, 0LL, rcount);
       HIP_TRY(hipGetLastError());
@@ -883,7 +893,7 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
     if (fresh) HIP_TRY(hipMemsetAsync(rflag, 0, (B + 1) * sizeof(int), h->stream));
   }
   KParams kchunk = h->kp;
-  kchunk.epoch = ++h->epoch;
+  kchunk.epoch = next_refine_epoch(h);
   int rcl = DDMPC_OK;
   for (size_t k = 0; k < nchunks && rcl == DDMPC_OK; ++k) {
     const size_t b0 = B * k / nchunks, b1 = B * (k + 1) / nchunks, nb = b1 - b0;
