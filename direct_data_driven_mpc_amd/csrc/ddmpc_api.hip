@@ -996,6 +996,27 @@ int ddmpc_prepare(ddmpc_handle* h) {
 #undef DDMPC_INSTANCE
   if (!launched) return fail(DDMPC_ERR_UNSUPPORTED, "no gain kernel for %d tile rows", NT);
   HIP_TRY(hipGetLastError());
+  if (h->v2 && k.lam != 0.0 && k.refine == DDMPC_REFINE_ALWAYS) {
+    // refinement ALWAYS: the substitutions above went through the unrefined factor, whose error is the Gram route's
+    // (cond(H) squared).  Replace every column of the law by refining cold solves: beta is affine in the past window, so
+    // column 1 + f = beta(e_f) - beta(0).  nf + 1 launches of the refining kernel variant, once per data set.
+    const int npu = p.n * p.m, npy = p.n * p.p;
+    double* pu = (double*)h->d_zero.p;               // the zero past window of the launch above becomes e_f (its own buffer:
+    double* py = pu + B * (size_t)npu;               // the handle's staging buffers may hold a caller's window)
+    KParams kr = k0;
+    kr.refine = DDMPC_REFINE_ALWAYS;
+    const unsigned gp = (unsigned)((B * (size_t)(npu + npy) + 255) / 256), gg = (unsigned)((B * (size_t)k.r + 255) / 256);
+    for (int j = 0; j < nrhs; ++j) {
+      hipLaunchKernelGGL(ddmpc_unit_past_kernel, dim3(gp), dim3(256), 0, h->stream, (long long)B, npu, npy, j - 1,
+                         pu, py);
+      if ((rc = launch_cold(h, (const double*)pu, (const double*)py, (double*)h->d_uopt.p, (double*)h->d_cost.p,
+                            (int32_t*)h->d_prep_status.p, nullptr, nullptr, nullptr, &kr, true)))
+        return rc;
+      hipLaunchKernelGGL(ddmpc_gain_column_kernel, dim3(gg), dim3(256), 0, h->stream, (long long)B, k.r, k.rE, nrhs, j,
+                         (const double*)h->d_beta.p, (double*)h->d_gain.p);
+    }
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->d_lfac.release();                           // the factor is only needed to form the gain
   h->d_lfacT.release();

@@ -311,6 +311,30 @@ __global__ __launch_bounds__(256) void ddmpc_gain_kernel(KParams P, int RPs, int
   }
 }
 
+// Refined affine law (ddmpc_prepare with DDMPC_REFINE_ALWAYS): the columns of the gain are obtained from full refining cold
+// solves instead of substitutions through the unrefined factor -- beta is affine in the past window, so column 1 + f is
+// beta(past = e_f) - beta(past = 0).  Two helpers: the unit past window e_f for the whole batch (f < 0: all zero), and
+// the difference of a solve's beta with the offset column.
+__global__ void ddmpc_unit_past_kernel(long long batch, int npu, int npy, int f, double* __restrict__ up, double* __restrict__ yp) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const int np = npu + npy;
+  if (idx >= batch * np) return;
+  const long long b = idx / np;
+  const int i = (int)(idx - b * np);
+  const double v = (i == f) ? 1.0 : 0.0;
+  if (i < npu) up[b * npu + i] = v; else yp[b * npy + (i - npu)] = v;
+}
+__global__ void ddmpc_gain_column_kernel(long long batch, int r, int rE, int nrhs, int j, const double* __restrict__ beta,
+                                         double* __restrict__ gain) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= batch * r) return;
+  const long long b = idx / r;
+  const int rho = (int)(idx - b * r);
+  const double v = beta[b * rE + rho];
+  double* g0 = gain + (b * nrhs) * (long long)r + rho;
+  if (j == 0) *g0 = v; else g0[(long long)j * r] = v - *g0;
+}
+
 // Output stage shared by the warm kernels: z, cost contribution and optimal_u of one component
 // (same formulas as the cold kernel's output stage, active set empty).
 __device__ __forceinline__ double warm_component(const KParams& P, int RPs, int rho, double beta, const double* pv,

@@ -92,7 +92,9 @@ extern "C" {
 #define DDMPC_OPT_REFINE 3            /* iterative refinement of the cold solve with exact Hankel products (residual
                                          t - (H(H'beta) + lam D beta) from the trajectory, correction through the factor at hand):
                                          0 off, 1 auto (default: only when the pivots indicate an ill-conditioned system),
-                                         2 always.  Passes repeat until the correction is at rounding level or stops shrinking. */
+                                         2 always.  Passes repeat until the correction is at rounding level or stops shrinking.
+                                         With 2, ddmpc_prepare also forms the affine law of ddmpc_step from refining solves
+                                         (n(m+p)+1 launches, once per data set); changing the mode invalidates the law. */
 #define DDMPC_REFINE_OFF 0
 #define DDMPC_REFINE_AUTO 1
 #define DDMPC_REFINE_ALWAYS 2

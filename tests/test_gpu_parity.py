@@ -960,8 +960,9 @@ def test_random_systems_against_oracle(gpu, case):
             assert np.max(np.abs(sol.optimal_u - us_t)) / scale < 1e-6 and abs(sol.cost) < 1e-8, (case, b)
         if spec.slack == "convex":
             assert int(iters[b]) == sol.iters
-    # the warm step's affine law is formed from the (unrefined) Gram-route factor: Gram-route accuracy
-    assert np.max(np.abs(uw - u)) <= 10 * TOL_U * max(np.max(np.abs(u)), 1e-3) and np.array_equal(sw, status) and np.array_equal(iw, iters)
+    # with refinement ALWAYS the affine law of the warm step is formed from refining solves too (ddmpc_prepare): the warm
+    # step meets the cold solve at the same bar
+    assert np.max(np.abs(uw - u)) <= TOL_U * max(np.max(np.abs(u)), 1e-3) and np.array_equal(sw, status) and np.array_equal(iw, iters)
 
 
 def test_noise_free_data(gpu):
