@@ -166,6 +166,7 @@ struct ddmpc_handle {
   DevBuf d_zws, d_resc;                    // NOMINAL rescue kernel: z per component and a per-instance "rescued" flag (ddmpc_get_solution)
   bool rescue_ran = false;
   int epoch = 0;                           // cold launches so far (KParams::epoch)
+  int prep_epoch = 0;                      // stamp of the flags recorded by ddmpc_prepare's factor-export launch (AUTO)
   bool v2 = true;                          // 16-wide-panel cold kernel (default); false: first-generation kernel (DDMPC_KERNEL=1)
   bool ws_stale = false;                   // the last solve was a cold solve that skipped the beta / active-set workspace                 // the last solve launched the rescue kernel (its flags are current)
   HostBuf h_io;
@@ -693,8 +694,18 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
       hipLaunchKernelGGL(h->kc.fn2r, dim3(pg), block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                          (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, (const int*)h->d_rflag.p, (long long)h->batch, rcount);
     } else {
+      // factor export for ddmpc_prepare under AUTO: the plain kernel still records which instances AUTO would refine
+      // (their columns of the affine law are then formed from refining solves, see ddmpc_prepare)
+      int *rf = nullptr, *rcount = nullptr;
+      if (lfac != nullptr && kq.lam != 0.0 && kq.refine == DDMPC_REFINE_AUTO && only == nullptr) {
+        const bool fresh = h->d_rflag.bytes < ((size_t)h->batch + 1) * sizeof(int);
+        if ((rc = h->d_rflag.ensure(((size_t)h->batch + 1) * sizeof(int)))) return rc;
+        if (fresh) HIP_TRY(hipMemsetAsync(h->d_rflag.p, 0, ((size_t)h->batch + 1) * sizeof(int), h->stream));
+        rf = (int*)h->d_rflag.p; rcount = rf + h->batch;
+        kq.epoch = h->prep_epoch = next_refine_epoch(h);
+      }
       hipLaunchKernelGGL(h->kc.fn2, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
-                         (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, only, 0LL, (int*)nullptr);
+                         (int*)iters, bws, aws, stp, lfac, lfacT, rf, only, 0LL, rcount);
     }
   } else
     hipLaunchKernelGGL(h->kc.fn, grid, block, h->lds_bytes, h->stream, kp_override ? *kp_override : h->kp, h->ud, h->yd,
@@ -996,10 +1007,13 @@ int ddmpc_prepare(ddmpc_handle* h) {
 #undef DDMPC_INSTANCE
   if (!launched) return fail(DDMPC_ERR_UNSUPPORTED, "no gain kernel for %d tile rows", NT);
   HIP_TRY(hipGetLastError());
-  if (h->v2 && k.lam != 0.0 && k.refine == DDMPC_REFINE_ALWAYS) {
-    // refinement ALWAYS: the substitutions above went through the unrefined factor, whose error is the Gram route's
-    // (cond(H) squared).  Replace every column of the law by refining cold solves: beta is affine in the past window, so
-    // column 1 + f = beta(e_f) - beta(0).  nf + 1 launches of the refining kernel variant, once per data set.
+  if (h->v2 && k.lam != 0.0 && (k.refine == DDMPC_REFINE_ALWAYS || k.refine == DDMPC_REFINE_AUTO)) {
+    // The substitutions above went through the unrefined factor, whose error is the Gram route's (cond(H) squared).
+    // Replace columns of the law by refining cold solves: beta is affine in the past window, so column 1 + f =
+    // beta(e_f) - beta(0).  nf + 1 launches of the refining kernel variant, once per data set -- ALWAYS: for every
+    // instance; AUTO: a filtered launch that only works on the instances the factor-export launch flagged (it reads one
+    // word per workgroup and leaves when there is none: the benchmark data).
+    const bool flagged_only = k.refine == DDMPC_REFINE_AUTO;
     const int npu = p.n * p.m, npy = p.n * p.p;
     double* pu = (double*)h->d_zero.p;               // the zero past window of the launch above becomes e_f (its own buffer:
     double* py = pu + B * (size_t)npu;               // the handle's staging buffers may hold a caller's window)
@@ -1009,11 +1023,22 @@ int ddmpc_prepare(ddmpc_handle* h) {
     for (int j = 0; j < nrhs; ++j) {
       hipLaunchKernelGGL(ddmpc_unit_past_kernel, dim3(gp), dim3(256), 0, h->stream, (long long)B, npu, npy, j - 1,
                          pu, py);
-      if ((rc = launch_cold(h, (const double*)pu, (const double*)py, (double*)h->d_uopt.p, (double*)h->d_cost.p,
-                            (int32_t*)h->d_prep_status.p, nullptr, nullptr, nullptr, &kr, true)))
-        return rc;
+      if (!flagged_only) {
+        if ((rc = launch_cold(h, (const double*)pu, (const double*)py, (double*)h->d_uopt.p, (double*)h->d_cost.p,
+                              (int32_t*)h->d_prep_status.p, nullptr, nullptr, nullptr, &kr, true)))
+          return rc;
+      } else {
+        if ((rc = h->d_act.ensure(B * k.rE))) return rc;
+        kr.epoch = h->prep_epoch;
+        hipLaunchKernelGGL(h->kc.fn2r, dim3((unsigned)(B < 768 ? B : 768)), dim3(64 * h->kc.W), h->lds_bytes, h->stream, kr, h->ud,
+                           h->yd, (const double*)pu, (const double*)py, (double*)h->d_uopt.p, (double*)h->d_cost.p,
+                           (int*)h->d_prep_status.p, (int*)nullptr, (double*)h->d_beta.p, (signed char*)h->d_act.p,
+                           (unsigned long long*)nullptr, (double*)nullptr, (double*)nullptr, (int*)nullptr,
+                           (const int*)h->d_rflag.p, (long long)B, (int*)h->d_rflag.p + B);
+      }
       hipLaunchKernelGGL(ddmpc_gain_column_kernel, dim3(gg), dim3(256), 0, h->stream, (long long)B, k.r, k.rE, nrhs, j,
-                         (const double*)h->d_beta.p, (double*)h->d_gain.p);
+                         (const double*)h->d_beta.p, (double*)h->d_gain.p,
+                         flagged_only ? (const int*)h->d_rflag.p : (const int*)nullptr, h->prep_epoch);
     }
     HIP_TRY(hipGetLastError());
   }

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void ddmpc_gain_kernel(KParams P, int RPs, int
   }
 }
 
-// Refined affine law (ddmpc_prepare with DDMPC_REFINE_ALWAYS): the columns of the gain are obtained from full refining cold
+// Refined affine law (ddmpc_prepare with DDMPC_REFINE_ALWAYS, or _AUTO for flagged instances): the columns of the gain are obtained from full refining cold
 // solves instead of substitutions through the unrefined factor -- beta is affine in the past window, so column 1 + f is
 // beta(past = e_f) - beta(past = 0).  Two helpers: the unit past window e_f for the whole batch (f < 0: all zero), and
 // the difference of a solve's beta with the offset column.
@@ -325,10 +325,11 @@ __global__ void ddmpc_unit_past_kernel(long long batch, int npu, int npy, int f,
   if (i < npu) up[b * npu + i] = v; else yp[b * npy + (i - npu)] = v;
 }
 __global__ void ddmpc_gain_column_kernel(long long batch, int r, int rE, int nrhs, int j, const double* __restrict__ beta,
-                                         double* __restrict__ gain) {
+                                         double* __restrict__ gain, const int* __restrict__ flags, int epoch) {
   const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (idx >= batch * r) return;
   const long long b = idx / r;
+  if (flags != nullptr && flags[b] != epoch) return;      // AUTO: only the instances the factor-export launch flagged
   const int rho = (int)(idx - b * r);
   const double v = beta[b * rE + rho];
   double* g0 = gain + (b * nrhs) * (long long)r + rho;

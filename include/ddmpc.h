@@ -93,8 +93,9 @@ extern "C" {
                                          t - (H(H'beta) + lam D beta) from the trajectory, correction through the factor at hand):
                                          0 off, 1 auto (default: only when the pivots indicate an ill-conditioned system),
                                          2 always.  Passes repeat until the correction is at rounding level or stops shrinking.
-                                         With 2, ddmpc_prepare also forms the affine law of ddmpc_step from refining solves
-                                         (n(m+p)+1 launches, once per data set); changing the mode invalidates the law. */
+                                         ddmpc_prepare forms the affine law of ddmpc_step from refining solves as well
+                                         (n(m+p)+1 launches, once per data set): with 2 for every instance, with 1 for the
+                                         instances it flags; changing the mode invalidates the law. */
 #define DDMPC_REFINE_OFF 0
 #define DDMPC_REFINE_AUTO 1
 #define DDMPC_REFINE_ALWAYS 2

@@ -287,9 +287,11 @@ def test_auto_refinement_flags_ill_conditioned_instances_only(gpu):
     out = {}
     with _spec_engine(spec, N, B) as eng:
         eng.set_data(d["u_d"], d["y_d"])
+        warm = {}
         for mode in ("off", "auto", "always"):
-            eng.set_refinement(mode)
+            eng.set_refinement(mode)                                         # (also invalidates the affine law of the warm step)
             out[mode] = tuple(x.copy() for x in eng.solve(up, yp))
+            warm[mode] = eng.step(up, yp)[0].copy()
     err = {}
     for mode, (u, c, s, _) in out.items():
         eu = ec = 0.0
@@ -301,6 +303,12 @@ def test_auto_refinement_flags_ill_conditioned_instances_only(gpu):
     assert err["always"][0] < TOL_U and err["always"][1] < TOL_COST, err
     assert err["auto"][0] < TOL_U and err["auto"][1] < TOL_COST, err
     assert err["off"][0] > 10 * err["always"][0], err                          # the Gram route alone is visibly worse here
+    # the warm step: its affine law comes from refining solves for the instances AUTO flags (ddmpc_prepare), so it meets the
+    # cold solve at the same bar; with refinement off it inherits the Gram route's error
+    scale = np.max(np.abs(out["always"][0]))
+    assert np.max(np.abs(warm["always"] - out["always"][0])) < TOL_U * scale
+    assert np.max(np.abs(warm["auto"] - out["always"][0])) < TOL_U * scale
+    assert np.max(np.abs(warm["off"] - out["always"][0])) > 10 * np.max(np.abs(warm["auto"] - out["always"][0]))
 
 
 @pytest.mark.gpu
