@@ -54,5 +54,5 @@ timeout -k 10 600 python tools/config5_check.py --robust --check 512 > "$OUT/cfg
 timeout -k 10 400 python tools/large_fuzz.py --cases 12 > "$OUT/large_kernel_fuzz.log" 2>&1
 echo "[collect] cfg5 done"
 # refinement modes on the benchmark data and on the 96-case random-plant sweep (conditioning estimate, off / auto / always)
-timeout -k 10 900 python tools/refine_calib.py > "$OUT/refine_calib.log" 2>&1
+timeout -k 10 900 python tools/refine_calib.py 96 > "$OUT/refine_calib.log" 2>&1
 echo "[collect] all done"
