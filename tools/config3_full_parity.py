@@ -1,6 +1,6 @@
 """BASELINE configs[2] at its full size -- 262,144 instances = 8 shards of 32,768 -- solved shard by shard on ONE GPU
 (each shard is exactly what rank r of an 8-GPU job owns: direct_data_driven_mpc_amd.distributed.shard_bounds) and
-EVERY instance checked against the CPU oracle (16 forked worker processes, before the GPU runtime starts).
+EVERY instance checked against the compiled CPU restatement (oracle/ddmpc_oracle_c.c, all host cores).
 
     python tools/config3_full_parity.py [--shards 8]
 """
@@ -8,7 +8,8 @@ import argparse, os, sys, time
 import multiprocessing as mp
 import numpy as np
 sys.path.insert(0, ".")
-import bench                                                   # reuses the oracle worker of the benchmark
+import bench                                                   # its QPSpec builder for the benchmark parameters
+from oracle import oracle_c                                    # compiled restatement of the reduced form (OpenMP)
 from direct_data_driven_mpc_amd.distributed import shard_bounds
 from direct_data_driven_mpc_amd.harness import controller_params, generate_batch
 
@@ -23,9 +24,11 @@ for rank in range(a.shards):                                   # CPU side first 
     lo, hi = shard_bounds(total, rank, a.shards)
     d = generate_batch(range(lo, hi), N=cfg["N"])
     up = d["u_d"][:, -n:, :].reshape(hi - lo, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(hi - lo, -1).copy()
-    rec, u_ref, c_ref = bench.cpu_baseline(cfg, d["u_d"], d["y_d"], up, yp, hi - lo)
+    ts = time.perf_counter()
+    u_ref, c_ref, st_ref, _ = oracle_c.solve_batch(bench._oracle_spec(cfg), cfg["N"], d["u_d"], d["y_d"], up, yp, threads=bench.host_cores())
+    assert not np.count_nonzero(st_ref)
     refs.append((u_ref, c_ref)); inputs.append((d["u_d"], d["y_d"], up, yp))
-    print("shard %d: oracle %.0f solves/s on %d worker processes" % (rank, rec["value"], rec["cores"]), flush=True)
+    print("shard %d: C restatement %.0f solves/s on %d threads" % (rank, (hi - lo) / (time.perf_counter() - ts), bench.host_cores()), flush=True)
 t_cpu = time.perf_counter() - t0
 
 import torch
@@ -51,4 +54,4 @@ for rank in range(a.shards):
     print("shard %d: %d instances, max rel err u %.3e cost %.3e, non-optimal %d" % (rank, B, eu, ec, int(np.count_nonzero(st))), flush=True)
     eng.close()
 print("TOTAL %d instances: max rel err u %.3e (tol 1e-8), cost %.3e (tol 1e-9), non-optimal %d; GPU solve time %.1f ms "
-      "(%.3e solves/s on one GPU), CPU oracle %.1f s" % (total, worst_u, worst_c, bad, t_gpu * 1e3, total / t_gpu, t_cpu))
+      "(%.3e solves/s on one GPU), C restatement %.1f s" % (total, worst_u, worst_c, bad, t_gpu * 1e3, total / t_gpu, t_cpu))
