@@ -464,10 +464,10 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
     // global-workspace kernels (plain VALU code): ROBUST controllers by
     // ddmpc_large_solve_kernel, NOMINAL ones by the rank-revealing kernel (accurate only to the extent the Gram
     // route allows at that size).  Dense weights are unsupported here.
-    if (p.weight_kind == DDMPC_WEIGHT_DENSE) {
+    if (p.weight_kind == DDMPC_WEIGHT_DENSE && p.controller_type != DDMPC_ROBUST) {
       delete h;
       return fail(DDMPC_ERR_UNSUPPORTED, "problem too large for the single-workgroup kernels: (m+p)(L+n) = %d rows "
-                  "(dense weighting matrices are limited to 271 rows)", k.r);
+                  "(dense weighting matrices of a NOMINAL controller are limited to 271 rows)", k.r);
     }
     {   // r-vectors and the Cholesky panel of the global-workspace kernels live in LDS (launch_cold / launch_nominal_rescue)
       const size_t rv = ((size_t)k.r + 1) & ~(size_t)1;

@@ -1562,7 +1562,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
 // box acts on (set B, the sigma rows of the prediction window) are ordered LAST: the factor of the other columns
 // (set A) and the Schur complement S = K_BB - L_BA L_BA' are formed once, and an active-set iteration only
 // re-factors S + lam*D_B(active set) (|B| = p*L rows) and substitutes through it.  Same component tables, outputs,
-// status and iteration count as ddmpc_cold_solve_kernel (ddmpc_kernels.hpp), diagonal weights only.  One workgroup
+// status and iteration count as ddmpc_cold_solve_kernel (ddmpc_kernels.hpp); scalar, diagonal or dense weights.  One workgroup
 // per instance.  Workspace per instance: r(r+1)/2 + max(Ln*nch^2, 2*|B|(|B|+1)/2) doubles.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, int RPs, const double* __restrict__ u_d,
@@ -1626,8 +1626,31 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
     act[i] = 0;
   }
   __syncthreads();
+  // dense weights: wib[rho] = (W^-1 betac)[rho] for a beta in COMPONENT order, one 32-lane half wave per row of the matrix
+  auto dense_times = [&](const double* betac, double* wib) {
+    const int hw = tid >> 5, t32 = tid & 31, nhw = nthr >> 5;
+    for (int r0 = 0; r0 < r; r0 += nhw) {
+      const int rho = r0 + hw;
+      double sacc = 0.0;
+      if (rho < r) {
+        const double* dr = P.dmat + (long long)rho * RPs;
+        for (int j = t32; j < r; j += 32) sacc += dr[j] * betac[j];
+      }
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 32);
+      if (t32 == 0 && rho < r) wib[rho] = sacc;
+    }
+  };
   hankel_gram_packed(P, ud, yd, G, G + npk, iperm, pan);   // lag table in the (not yet used) storage behind G
   __syncthreads();
+  if (P.dense_w) {     // dense weighting matrices: lam * W^-1 (shared by the batch, component order) on every pair of components;
+                       // the diagonal table below then only carries the 1/lamb_sigma terms, which is all the slack box switches
+    for (int e = tid; e < npk; e += nthr) {
+      const int i = tri_row(e), j = e - i * (i + 1) / 2;
+      G[e] += P.lam * P.dmat[(long long)perm[i] * RPs + perm[j]];
+    }
+    __syncthreads();
+  }
   for (int i = tid; i < nA; i += nthr) G[i * (i + 1) / 2 + i] += P.lam * P.tabd[0 * RPs + perm[i]];
   __syncthreads();
   packed_psd_cholesky(G, r, 0.0, skip, pan, nA);        // columns of A only; a pivot that is not positive is skipped
@@ -1699,6 +1722,12 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
     for (int i = tid; i < r; i += nthr) qa[perm[i]] = bv[i];            // beta in component order
     __syncthreads();
     hankel_normal_times(P, ud, yd, qa, qb, pan);                         // H H' beta, component order
+    if (P.dense_w) {                                                     // + lam W^-1 beta (zb is free after the active-set loop)
+      dense_times(qa, zb);
+      __syncthreads();
+      for (int rho = tid; rho < r; rho += nthr) qb[rho] += P.lam * zb[rho];
+      __syncthreads();
+    }
     for (int i = tid; i < r; i += nthr) {
       const int rho = perm[i];
       const int a = act[i];
@@ -1732,6 +1761,12 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
   // ---- outputs: z = t - lam*D*beta; cost = control cost + lam*beta'z + lamb_sigma*|sigma|^2 --------------------
   double part = 0.0, bad = 0.0;
   double* uo = u_opt + b * (long long)((P.Ln - n) * m);
+  if (st == 0 && P.dense_w) {                            // zb[rho] = (W^-1 beta)[rho], component order
+    for (int i = tid; i < r; i += nthr) qa[perm[i]] = bv[i];
+    __syncthreads();
+    dense_times(qa, zb);
+    __syncthreads();
+  }
   if (st == 0) {
     for (int i = tid; i < r; i += nthr) {
       const int rho = perm[i];
@@ -1739,13 +1774,19 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
       const double bb = bv[i];
       const double D = s_act ? P.tabd[1 * RPs + rho] : P.tabd[0 * RPs + rho];
       const double t = ct[i] + s_act * P.bound;
-      const double z = t - P.lam * D * bb;
+      const double z = t - P.lam * (D * bb + (P.dense_w ? zb[rho] : 0.0));
       const double wq = P.tabd[3 * RPs + rho];
       const double tb = P.tabd[2 * RPs + rho];          // setpoint of the component (u_s / y_s)
       const int oidx = P.tabi[2 * RPs + rho];
       const int kind = P.tabi[0 * RPs + rho];
       if (!(fabs(bb) < 1e300)) bad = 1.0;
       double contrib = P.lam * bb * z;
+      if (P.dense_w && (kind == K_UFREE || kind == K_YFREE || kind == K_WPRED)) {
+        // (z - t)' W (z - t) summed over the weighted components equals -lam * beta' (z - t); a sigma held at its bound adds
+        // lamb_sigma * bound^2 (as in the register-resident kernel)
+        contrib -= P.lam * bb * (z - t);
+        if (s_act != 0) contrib += P.box_cost;
+      } else
       if (kind == K_UFREE || kind == K_YFREE) { const double dlt = z - tb; contrib += wq * dlt * dlt; }
       else if (kind == K_WINT) { const double sg = z - ct[i]; contrib += P.lamb_sigma * sg * sg; }
       else if (kind == K_WTERM) { const double sg = z - tb; contrib += P.lamb_sigma * sg * sg; }

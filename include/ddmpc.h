@@ -131,12 +131,12 @@ const char* ddmpc_last_error(void);
 int ddmpc_device_count(void);
 
 /* Problem sizes: (m+p)(L+n) <= 271 rows run on the register-resident cold-solve kernels (all schemes, all weight
- * kinds).  Beyond that, controllers with scalar/diagonal weights run on single-workgroup kernels that keep their
+ * kinds).  Beyond that, controllers run on single-workgroup kernels that keep their
  * matrices in a global workspace (a Gram-route solve plus refinement with exact Hankel products; throughput: see
  * profiles/README.md): ROBUST ones on ddmpc_large_solve_kernel (same outputs, status, iterations, ddmpc_get_solution),
  * NOMINAL ones on the rank-revealing kernel (ddmpc_get_solution: ubar / ybar; alpha is not formed there and reads NaN).  No affine law at that size: ddmpc_prepare is a no-op, ddmpc_step == ddmpc_solve, ddmpc_get_gain
- * is DDMPC_ERR_UNSUPPORTED.  Dense weighting matrices beyond 271 rows, and any problem beyond 1024 rows, are
- * DDMPC_ERR_UNSUPPORTED (reported by ddmpc_create).
+ * is DDMPC_ERR_UNSUPPORTED.  Dense weighting matrices of a NOMINAL controller beyond 271 rows, and any problem beyond
+ * 1024 rows, are DDMPC_ERR_UNSUPPORTED (reported by ddmpc_create).
  *
  * Replaces DirectDataDrivenMPCController.__init__ parameter validation
  * (controller.py:165-168,211-222,298-343,664-670) for a batch of instances on

@@ -401,6 +401,31 @@ def test_robust_scheme_beyond_the_register_resident_kernels(gpu, slack):
             _engine(orc.spec_from_params(L=300, N=1000), 1000, 1)
 
 
+@pytest.mark.parametrize("slack", [0, 1], ids=["none", "convex"])
+def test_dense_weighting_matrices_beyond_the_register_resident_kernels(gpu, slack):
+    # dense SPD Q, R (controller.py:121-124,708-710) at 296 rows: ddmpc_large_solve_kernel adds lam * W^-1 to the whole
+    # Gram matrix, the slack box still only switches diagonal entries; outputs and variables against the full-space oracle
+    spec = orc.spec_from_params(L=70, N=1200, slack_var_constraint_type=slack)
+    rng = np.random.default_rng(12)
+    spec.Q = _spd(rng, spec.p * spec.L, 3.0, 3)
+    spec.R = _spd(rng, spec.m * spec.L, 1e-4, 2)
+    B = 2
+    u_d, y_d, up, yp = _instances(B, N=1200, seed0=31)
+    with _engine(spec, 1200, B) as eng:
+        assert "large_solve" in eng.kernel_name()
+        eng.set_data(u_d, y_d)
+        u, cost, status, iters = eng.solve(up, yp)
+        sg = eng.get_solution("sigma"); yb = eng.get_solution("ybar"); ub = eng.get_solution("ubar")
+    _check(spec, u_d, y_d, up, yp, u, cost, status, range(B))
+    for b in range(B):
+        ref = orc.solve_fullspace(spec, u_d[b], y_d[b], up[b], yp[b])
+        if slack == 1:
+            assert int(iters[b]) == ref.iters
+        assert np.max(np.abs(sg[b] - ref.sigma.ravel())) <= 1e-9 * max(1.0, np.max(np.abs(ref.sigma)))
+        assert np.max(np.abs(yb[b] - ref.ybar.ravel())) <= 1e-8
+        assert np.max(np.abs(ub[b] - ref.ubar.ravel())) <= 1e-8 * np.max(np.abs(ref.ubar))
+
+
 def test_convex_active_set_converges_on_full_batch(gpu):
     # slack CONVEX on 4096 seeds: every instance must reach a stable active set ("optimal"),
     # a sample is compared with the full-space oracle, and the bound must hold everywhere
@@ -1311,10 +1336,10 @@ def test_config5_size_nominal_runs_on_the_rank_revealing_kernel(gpu):
     _check(specr, dn["u_d"], dn["y_d"], upn, ypn, ur, costr, statusr, range(B))
     for b in range(B):
         assert int(itr[b]) == orc.solve_fullspace(specr, dn["u_d"][b], dn["y_d"][b], upn[b], ypn[b]).iters
-    # dense weighting matrices stay limited to the register-resident kernels
+    # dense weighting matrices of a NOMINAL controller stay limited to the register-resident kernels
     with pytest.raises(L.DDMPCError, match="too large"):
         BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=3.0 * np.eye(p * Lh) + 0.01, R=1e-4 * np.eye(m * Lh), u_s=u_s, y_s=y_s,
-                     batch=1, controller_type=L.ROBUST, eps_max=0.002, lamb_alpha=50.0, lamb_sigma=1000.0, c=1.0)
+                     batch=1, controller_type=L.NOMINAL)
     # a shape whose trajectory chunks would not fit the kernels' LDS scratch (hundreds of channels, three time steps) is
     # refused when the controller is created, not discovered on the device
     with pytest.raises(L.DDMPCError, match="not supported by the global-workspace kernels"):
