@@ -167,6 +167,16 @@ struct ddmpc_handle {
   bool rescue_ran = false;
   int epoch = 0;                           // cold launches so far (KParams::epoch)
   int prep_epoch = 0;                      // stamp of the flags recorded by ddmpc_prepare's factor-export launch (AUTO)
+  // AUTO refinement without the slack box: which instances get flagged depends on the data set only (the conditioning estimate
+  // is read off the pivots of G + lam*D, not off the right-hand side), so the answer of the first solve on a data set is
+  // kept: FLAG_CLEAN -> later solves are ONE launch of the plain kernel; FLAG_SET -> plain kernel + the filtered refining
+  // launch on the recorded flags; FLAG_PENDING: the counter word is on its way to the host (4-byte copy + event).
+  enum { FLAG_UNKNOWN = 0, FLAG_PENDING = 1, FLAG_CLEAN = 2, FLAG_SET = 3 };
+  int flag_state = FLAG_UNKNOWN;
+  int flag_epoch = 0;                      // latest stamp written into d_rflag (what a filtered launch must carry)
+  int probe_epoch = 0;                     // stamp the pending probe was taken for
+  HostBuf h_probe;                         // pinned: the counter word of the probed launch
+  hipEvent_t ev_probe = nullptr;
   bool v2 = true;                          // 16-wide-panel cold kernel (default); false: first-generation kernel (DDMPC_KERNEL=1)
   bool ws_stale = false;                   // the last solve was a cold solve that skipped the beta / active-set workspace                 // the last solve launched the rescue kernel (its flags are current)
   HostBuf h_io;
@@ -553,6 +563,8 @@ int ddmpc_destroy(ddmpc_handle* h) {
                     &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_rflag};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
+  h->h_probe.release();
+  if (h->ev_probe) (void)hipEventDestroy(h->ev_probe);
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -612,6 +624,7 @@ int ddmpc_set_data(ddmpc_handle* h, const double* u_d, const double* y_d, int me
   h->have_data = true;
   h->solved = false;
   h->prepared = false;
+  h->flag_state = ddmpc_handle::FLAG_UNKNOWN;      // new data: the refinement flags are a function of the data set
   return DDMPC_OK;
 }
 
@@ -626,8 +639,10 @@ static unsigned large_threads(size_t r) {   // workgroup size of the global-work
 // before the 32-bit stamp would wrap, when the flags and the counter are zeroed once and the stamps restart.
 static int next_refine_epoch(ddmpc_handle* h) {
   if (h->epoch >= 0x3fffffff &&
-      (!h->d_rflag.p || hipMemsetAsync(h->d_rflag.p, 0, h->d_rflag.bytes, h->stream) == hipSuccess))
+      (!h->d_rflag.p || hipMemsetAsync(h->d_rflag.p, 0, h->d_rflag.bytes, h->stream) == hipSuccess)) {
     h->epoch = 0;
+    h->flag_state = ddmpc_handle::FLAG_UNKNOWN;      // the recorded flags are gone with their stamps
+  }
   return ++h->epoch;
 }
 
@@ -678,6 +693,25 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
       hipLaunchKernelGGL(h->kc.fn2r, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                          (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, only, 0LL, (int*)nullptr);
     } else if (mode == DDMPC_REFINE_AUTO) {
+      // without the slack box the flags depend on the data set only: answer kept per data set (see ddmpc_handle::flag_state)
+      const bool cacheable = !kq.convex && only == nullptr && h->d_rflag.bytes >= ((size_t)h->batch + 1) * sizeof(int);
+      if (cacheable && h->flag_state == ddmpc_handle::FLAG_PENDING && hipEventQuery(h->ev_probe) == hipSuccess)
+        h->flag_state = (*(volatile int*)h->h_probe.p == h->probe_epoch) ? ddmpc_handle::FLAG_SET : ddmpc_handle::FLAG_CLEAN;
+      if (cacheable && (h->flag_state == ddmpc_handle::FLAG_CLEAN || h->flag_state == ddmpc_handle::FLAG_SET)) {
+        hipLaunchKernelGGL(h->kc.fn2, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
+                           (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, only, 0LL, (int*)nullptr);
+        if (h->flag_state == ddmpc_handle::FLAG_SET) {
+          HIP_TRY(hipGetLastError());
+          kq.refine = DDMPC_REFINE_ALWAYS;
+          kq.epoch = h->flag_epoch;
+          const unsigned pgs = (unsigned)(h->batch < 768 ? h->batch : 768);
+          hipLaunchKernelGGL(h->kc.fn2r, dim3(pgs), block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
+                             (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, (const int*)h->d_rflag.p, (long long)h->batch,
+                             (int*)h->d_rflag.p + h->batch);
+        }
+        HIP_TRY(hipGetLastError());
+        return DDMPC_OK;
+      }
       // flags [batch] + one counter behind them (number of flagged instances of this launch; the refinement pass leaves at
       // once when it is zero)
       const bool fresh = h->d_rflag.bytes < ((size_t)h->batch + 1) * sizeof(int);
@@ -693,6 +727,19 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
       const unsigned pg = (unsigned)(h->batch < 768 ? h->batch : 768);       // persistent grid, 3 workgroups per CU
       hipLaunchKernelGGL(h->kc.fn2r, dim3(pg), block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                          (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, (const int*)h->d_rflag.p, (long long)h->batch, rcount);
+      h->flag_epoch = kq.epoch;                   // the flags now carry this stamp
+      if (!kq.convex && only == nullptr && h->flag_state == ddmpc_handle::FLAG_UNKNOWN) {
+        // first solve on this data set: send the counter word to the host (outside a stream capture) and look at it later
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h->stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone &&
+            h->h_probe.ensure(sizeof(int)) == DDMPC_OK &&
+            (h->ev_probe != nullptr || hipEventCreateWithFlags(&h->ev_probe, hipEventDisableTiming) == hipSuccess) &&
+            hipMemcpyAsync(h->h_probe.p, rcount, sizeof(int), hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+            hipEventRecord(h->ev_probe, h->stream) == hipSuccess) {
+          h->probe_epoch = kq.epoch;
+          h->flag_state = ddmpc_handle::FLAG_PENDING;
+        }
+      }
     } else {
       // factor export for ddmpc_prepare under AUTO: the plain kernel still records which instances AUTO would refine
       // (their columns of the affine law are then formed from refining solves, see ddmpc_prepare)
@@ -703,6 +750,8 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
         if (fresh) HIP_TRY(hipMemsetAsync(h->d_rflag.p, 0, ((size_t)h->batch + 1) * sizeof(int), h->stream));
         rf = (int*)h->d_rflag.p; rcount = rf + h->batch;
         kq.epoch = h->prep_epoch = next_refine_epoch(h);
+        h->flag_epoch = kq.epoch;
+        if (h->flag_state == ddmpc_handle::FLAG_PENDING) h->flag_state = ddmpc_handle::FLAG_UNKNOWN;   // (its probe refers to an older stamp)
       }
       hipLaunchKernelGGL(h->kc.fn2, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                          (int*)iters, bws, aws, stp, lfac, lfacT, rf, only, 0LL, rcount);
@@ -905,6 +954,8 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
   }
   KParams kchunk = h->kp;
   kchunk.epoch = next_refine_epoch(h);
+  h->flag_state = ddmpc_handle::FLAG_UNKNOWN;        // new data set (uploaded below): the recorded refinement decision is void
+  h->flag_epoch = kchunk.epoch;
   int rcl = DDMPC_OK;
   for (size_t k = 0; k < nchunks && rcl == DDMPC_OK; ++k) {
     const size_t b0 = B * k / nchunks, b1 = B * (k + 1) / nchunks, nb = b1 - b0;
@@ -1090,6 +1141,7 @@ int ddmpc_set_option(ddmpc_handle* h, int option, int value) {
         return fail(DDMPC_ERR_INVALID, "refinement mode must be DDMPC_REFINE_OFF, _AUTO or _ALWAYS");
       h->kp.refine = value;
       h->prepared = false;              // the affine law is formed from a refined solve of the offset column
+      h->flag_state = ddmpc_handle::FLAG_UNKNOWN;
       return DDMPC_OK;
     case DDMPC_OPT_REFINE_MAX:
       if (value < 1 || value > 10) return fail(DDMPC_ERR_INVALID, "refinement passes must be within [1, 10]");
@@ -1098,6 +1150,8 @@ int ddmpc_set_option(ddmpc_handle* h, int option, int value) {
     case DDMPC_OPT_REFINE_COND_LOG10:
       if (value < 0 || value > 3000) return fail(DDMPC_ERR_INVALID, "refinement threshold (tenths of a decade) must be within [0, 3000]");
       h->kp.refine_cond = std::pow(10.0, 0.1 * (double)value);
+      h->prepared = false;
+      h->flag_state = ddmpc_handle::FLAG_UNKNOWN;
       return DDMPC_OK;
     default: return fail(DDMPC_ERR_INVALID, "unknown option %d", option);
   }

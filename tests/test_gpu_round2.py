@@ -312,6 +312,59 @@ def test_auto_refinement_flags_ill_conditioned_instances_only(gpu):
 
 
 @pytest.mark.gpu
+def test_auto_refinement_decision_is_kept_per_data_set(gpu):
+    # without the slack box the AUTO flags depend on the data only, so the first solve's answer is kept: later solves are
+    # one launch (nothing flagged) or plain + filtered refining launch on the recorded flags.  Results must not depend on
+    # which of the paths ran, a changed past window must be honoured, and new data must void the recorded answer.
+    import torch
+    import test_gpu_parity as T
+    rng = np.random.default_rng(1017)
+    m, p, ns = 2, 3, 4
+    plant = T._random_plant(np.random.default_rng(1017), ns, m, p, 0.002)      # ill-conditioned: every instance gets flagged
+    Lh, N, B = 16, 200, 6
+    spec = orc.QPSpec(n=ns, m=m, p=p, L=Lh, Q=2.0 * np.eye(p * Lh), R=0.05 * np.eye(m * Lh), u_s=rng.uniform(-0.5, 0.5, m),
+                      y_s=rng.uniform(-0.5, 0.5, p), robust=True, eps_max=0.002, lamb_alpha=20.0, lamb_sigma=500.0, c=1.0,
+                      slack="none", tec=True)
+    d = harness.generate_batch(range(170, 170 + B), N=N, plant=plant)
+    d2 = harness.generate_batch(range(270, 270 + B), N=N, plant=plant)
+    up = d["u_d"][:, -ns:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -ns:, :].reshape(B, -1).copy()
+    up2 = d2["u_d"][:, -ns:, :].reshape(B, -1).copy(); yp2 = d2["y_d"][:, -ns:, :].reshape(B, -1).copy()
+    with _spec_engine(spec, N, B) as eng:
+        eng.set_data(d["u_d"], d["y_d"])
+        runs = []
+        for k in range(4):                                    # 1st: flags recorded; later ones: recorded flags reused
+            runs.append(tuple(x.copy() for x in eng.solve(up, yp)))
+            torch.cuda.synchronize()
+        for r in runs[1:]:
+            assert np.array_equal(r[0], runs[0][0]) and np.array_equal(r[1], runs[0][1]) and np.array_equal(r[2], runs[0][2])
+        eng.set_refinement("always"); ref = tuple(x.copy() for x in eng.solve(up, yp))
+        assert np.max(np.abs(runs[0][0] - ref[0])) <= 1e-12 * np.max(np.abs(ref[0]))        # flagged instances were refined
+        eng.set_refinement("auto")
+        a_other = tuple(x.copy() for x in eng.solve(up2, yp2)); torch.cuda.synchronize()     # another past window, same data
+        b_other = tuple(x.copy() for x in eng.solve(up2, yp2))
+        eng.set_refinement("always"); r_other = eng.solve(up2, yp2)[0].copy()
+        assert np.array_equal(a_other[0], b_other[0]) and np.max(np.abs(a_other[0] - r_other)) <= 1e-12 * np.max(np.abs(r_other))
+    # benchmark data: nothing flagged -> every solve equals refinement OFF bit for bit, before and after the answer is known
+    specb = orc.spec_from_params()
+    Bb = 8
+    db = harness.generate_batch(range(Bb))
+    upb = db["u_d"][:, -4:, :].reshape(Bb, -1).copy(); ypb = db["y_d"][:, -4:, :].reshape(Bb, -1).copy()
+    with _spec_engine(specb, 400, Bb) as eng:
+        eng.set_data(db["u_d"], db["y_d"])
+        autos = []
+        for k in range(3):
+            autos.append(tuple(x.copy() for x in eng.solve(upb, ypb))); torch.cuda.synchronize()
+        eng.set_refinement("off"); off = eng.solve(upb, ypb)
+        for r in autos:
+            assert np.array_equal(r[0], off[0]) and np.array_equal(r[1], off[1])
+        # new (ill-scaled) data in the same handle: the recorded "nothing flagged" must not survive ddmpc_set_data
+        eng.set_refinement("auto")
+        eng.set_data(db["u_d"][::-1].copy(), db["y_d"][::-1].copy())
+        x1 = eng.solve(upb[::-1].copy(), ypb[::-1].copy())[0].copy()
+        assert np.array_equal(x1, autos[0][0][::-1])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", [1, 2, 4], ids=["m3p2-convex", "m1p4-none", "m2p5-none-ucon"])
 def test_global_workspace_kernels_with_channel_counts_that_do_not_fill_a_tile(gpu, case):
     # beyond 271 rows the Gram, the Cholesky, the Schur complement and C'WC run on 16x16 MFMA tiles over packed matrices:
