@@ -1,14 +1,16 @@
 #!/usr/bin/env python
 """bench.py -- QP solves/sec of the batched Data-Driven MPC cold solve on MI355X.
 
-Workload (BASELINE.json configs[1]): four-tank robust DD-MPC, L=30, N=400, slack
-NONE (the reference YAML default), batch = 4096 noise seeds per GPU, inputs
-resident in HBM.  One "step" = one cold QP solve (implicit Hankel -> Gram ->
-reduced KKT -> Cholesky -> solve) for every instance of the batch.
+Workload: four-tank robust DD-MPC, L=30, N=400, slack NONE (the reference YAML default), inputs resident in HBM.
+  --gpus 1 : BASELINE.json configs[1], batch = 4096 noise seeds on one GPU;
+  --gpus N : BASELINE.json configs[2]'s sharding, 32,768 seeds per GPU (262,144 over 8), one all-gather at the end.
+One "step" = one cold QP solve (implicit Hankel -> Gram -> reduced KKT -> Cholesky -> solve) for every instance of the
+batch.  Consecutive steps alternate between two resident data sets of the batch (a pointer swap through ddmpc_set_data),
+so no step can reuse anything a previous step derived from its data.
 
     python bench.py [--gpus N --steps K --warmup W]
 
-With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks
+With --gpus N > 1 (or --force-dist) and no WORLD_SIZE in the environment the script starts its own ranks
 (python -m torch.distributed.run, one process per GPU, RCCL) BEFORE anything touches the GPU
 runtime and relays rank 0's JSON line; under torch.distributed.run it is one of the ranks.
 
@@ -139,6 +141,12 @@ def cpu_baseline(cfg, u_d, y_d, up, yp, n_sample, repeats=5):
     return rec, (u_c, c_c, st_c), (u_f, c_f)
 
 
+def default_batch_per_gpu(gpus):
+    """--gpus 1: BASELINE configs[1] (4096 seeds on one GPU).  --gpus N > 1: BASELINE configs[2]'s shard, 32,768 seeds
+    per GPU (262,144 over 8), the batch at which a GPU is 9 % faster per instance than at 4096 (profiles/)."""
+    return 4096 if gpus <= 1 else 32768
+
+
 def self_launch(a, argv):
     """--gpus N > 1 from a bare shell: start the N ranks as child processes (nothing here has touched the GPU
     runtime, and this process never does), relay their output, exit with their code."""
@@ -147,7 +155,7 @@ def self_launch(a, argv):
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(max(a.gpus, 1)),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     res = subprocess.run(cmd, env=env)
     raise SystemExit(res.returncode)
@@ -158,7 +166,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch-per-gpu", type=int, default=4096)
+    ap.add_argument("--batch-per-gpu", type=int, default=None,
+                    help="default: 4096 at --gpus 1 (BASELINE configs[1]), 32768 at --gpus N > 1 (configs[2]: 262,144 over 8)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the torch.distributed / RCCL branch (process group, device barriers, all_gather_into_tensor) "
+                         "at any world size, including 1")
     ap.add_argument("--slack", choices=["none", "convex"], default="none")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -170,8 +182,10 @@ def main():
                     help="rank 0 saves the gathered optimal_u/cost/status to this .npz (tests)")
     a = ap.parse_args()
 
+    if a.batch_per_gpu is None:
+        a.batch_per_gpu = default_batch_per_gpu(a.gpus)
     env_world = os.environ.get("WORLD_SIZE")
-    if env_world is None and a.gpus > 1:
+    if env_world is None and (a.gpus > 1 or a.force_dist):
         self_launch(a, sys.argv[1:])
     world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
@@ -196,6 +210,10 @@ def main():
     n, m, p = cfg["n"], cfg["m"], cfg["p"]
     up_h = u_d_h[:, -n:, :].reshape(B, -1).copy()
     yp_h = y_d_h[:, -n:, :].reshape(B, -1).copy()
+    # second resident data set of the same shape (other seeds): the timed steps alternate between the two
+    alt = generate_batch(range(total + lo, total + hi), N=cfg["N"])
+    up2_h = alt["u_d"][:, -n:, :].reshape(B, -1).copy()
+    yp2_h = alt["y_d"][:, -n:, :].reshape(B, -1).copy()
     cpu = None
     if world == 1 and rank == 0 and not a.no_cpu_baseline:
         cpu = cpu_baseline(cfg, u_d_h, y_d_h, up_h, yp_h, min(a.cpu_sample, B))
@@ -205,7 +223,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         if a.rehearse_on_one_gpu:
             dist.init_process_group(backend="gloo")
         else:
@@ -225,18 +244,27 @@ def main():
     cost = torch.empty((B,), dtype=torch.float64, device=dev)
     status = torch.empty((B,), dtype=torch.int32, device=dev)
     iters = torch.empty((B,), dtype=torch.int32, device=dev)
-    eng.set_data(u_d, y_d)
+    sets = [(u_d, y_d, up, yp),
+            (torch.from_numpy(alt["u_d"]).to(dev), torch.from_numpy(alt["y_d"]).to(dev),
+             torch.from_numpy(up2_h).to(dev), torch.from_numpy(yp2_h).to(dev))]
+    del alt
+
+    def step(k):
+        # data set of step k: the LAST timed step works on set 0, whose results are checked below
+        du, dy, pu, py = sets[(a.steps - 1 - k) % 2]
+        eng.set_data(du, dy)                       # device pointers: a pointer swap, nothing is copied or precomputed
+        eng.solve(pu, py, u_opt, cost, status, iters)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             if a.rehearse_on_one_gpu:
                 dist.barrier()
             else:
                 dist.barrier(device_ids=[local_rank])
 
-    for _ in range(a.warmup):
-        eng.solve(up, yp, u_opt, cost, status, iters)
-    if world > 1 and a.warmup > 0:              # the gather's first call sets up RCCL channels: part of the warm-up
+    for k in range(a.warmup):
+        step(a.steps + k)
+    if use_dist and a.warmup > 0:              # the gather's first call sets up RCCL channels: part of the warm-up
         if a.rehearse_on_one_gpu:
             gather_results(u_opt.cpu(), cost.cpu(), status.cpu(), total)
         else:
@@ -250,23 +278,23 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     for k in range(a.steps):
-        eng.solve(up, yp, u_opt, cost, status, iters)
+        step(k)
     ev1.record()
-    if world > 1:
+    if use_dist:
         if a.rehearse_on_one_gpu:
             g_u, g_c, g_s = gather_results(u_opt.cpu(), cost.cpu(), status.cpu(), total)
         else:
             g_u, g_c, g_s = gather_results(u_opt, cost, status, total)
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=("cpu" if a.rehearse_on_one_gpu else dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms = float(ev0.elapsed_time(ev1)) / a.steps
     st = status.cpu().numpy()
     n_bad = int(np.count_nonzero(st != 0))
-    if world > 1:
+    if use_dist:
         n_bad = int(np.count_nonzero(g_s.cpu().numpy() != 0))
         assert g_u.shape[0] == total and torch.equal(g_u[lo:hi].cpu(), u_opt.cpu()), "gather mismatch"
         if rank == 0 and a.dump_gathered:
@@ -340,8 +368,14 @@ def main():
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "four-tank robust DD-MPC cold solve, L=30 N=400 n=4 m=p=2, slack %s, TEC, "
-                                   "batch=%d noise seeds per GPU (BASELINE configs[1])" % (a.slack.upper(), a.batch_per_gpu),
-                       "global_batch": total, "parallelism": "instances sharded dp%d, no data-path collective, one final all-gather" % world,
+                                   "batch=%d noise seeds per GPU (%s); steps alternate between two resident data sets" % (
+                                       a.slack.upper(), a.batch_per_gpu,
+                                       "BASELINE configs[1]" if (world == 1 and a.batch_per_gpu == 4096) else
+                                       "BASELINE configs[2]: 262,144 over 8 GPUs" if a.batch_per_gpu == 32768 else "custom batch"),
+                       "global_batch": total,
+                       "parallelism": "instances sharded dp%d, no data-path collective, one final all-gather%s" % (
+                           world, " (RCCL branch forced at world size 1)" if (a.force_dist and world == 1) else ""),
+                       "refinement": "auto (every solve checked with the exact-Hankel residual; flagged instances re-solved)",
                        "kernel": eng.kernel_name(), "non_optimal_instances": n_bad, "kernel_source_hash": kernel_source_hash()},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
@@ -368,7 +402,7 @@ def main():
                                  vs_fullspace_numpy=dict(u=fu, cost=fc, checked=int(u_f.shape[0])))
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

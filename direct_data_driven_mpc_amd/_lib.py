@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libddmpc.so")
 
 # ---- constants mirrored from include/ddmpc.h ---------------------------------
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_READY = 0, -1, -2, -3, -4, -5
 NOMINAL, ROBUST = 0, 1
 SLACK_NON_CONVEX, SLACK_CONVEX, SLACK_NONE = 0, 1, 2
@@ -22,7 +22,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 GRAM_AUTO, GRAM_DENSE, GRAM_STRUCTURED = 0, 1, 2
 OPT_CLOSED_LOOP_PATH = 1
 OPT_CLOSED_LOOP_GRAPH = 2
-OPT_REFINE, OPT_REFINE_MAX, OPT_REFINE_COND_LOG10 = 3, 4, 5
+OPT_REFINE, OPT_REFINE_MAX, OPT_REFINE_RES_LOG10 = 3, 4, 5
 REFINE_OFF, REFINE_AUTO, REFINE_ALWAYS = 0, 1, 2
 PATH_AUTO, PATH_COLD, PATH_WARM = 0, 1, 2
 SOL_ALPHA, SOL_UBAR, SOL_YBAR, SOL_SIGMA = 0, 1, 2, 3

@@ -51,8 +51,6 @@ def instances():
 # checkouts and copies that only change modification times)
 INST_DEPS = ["ddmpc_inst.hip", "ddmpc_kernels.hpp", "ddmpc_cold2.hpp"]
 API_DEPS = ["ddmpc_api.hip", "ddmpc_aux_kernels.hpp", "ddmpc_kernels.hpp", "ddmpc_cold2.hpp", "ddmpc_instances.inc"]
-# first-generation kernels (DDMPC_KERNEL=1, A/B measurements): built too unless DDMPC_SKIP_V1 is set (development)
-SKIP_V1 = os.environ.get("DDMPC_SKIP_V1", "") not in ("", "0")
 ONLY_NT = int(os.environ.get("DDMPC_ONLY_NT", "0") or 0)          # development: build just this instance of the kernels
 
 
@@ -87,17 +85,16 @@ def build(force: bool = False, jobs: int = 0, verbose: bool = True) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     header = os.path.join(os.path.dirname(PKG_DIR), "include", "ddmpc.h")
     tasks = []
-    dev = SKIP_LARGE or SKIP_V1 or ONLY_NT
+    dev = SKIP_LARGE or ONLY_NT
     api_obj = os.path.join(OBJ_DIR, "ddmpc_api_dev.o" if dev else "ddmpc_api.o")
-    api_flags = (["-DDDMPC_NO_LARGE"] if SKIP_LARGE else []) + (["-DDDMPC_NO_V1"] if SKIP_V1 else []) + \
-                (["-DDDMPC_ONLY_NT=%d" % ONLY_NT] if ONLY_NT else [])
+    api_flags = (["-DDDMPC_NO_LARGE"] if SKIP_LARGE else []) + (["-DDDMPC_ONLY_NT=%d" % ONLY_NT] if ONLY_NT else [])
     cmd = [hipcc] + COMMON_FLAGS + api_flags + ["-c", os.path.join(CSRC, "ddmpc_api.hip"), "-o", api_obj]
     tasks.append((cmd, api_obj, _fingerprint(cmd, API_DEPS, [header])))
     for nt, w in instances():
-        # 2: the 16-wide-panel kernel, "2r": the same with the iterative-refinement loop compiled in, 1: first generation
-        for gen in (("2", "2r") if SKIP_V1 else ("2", "2r", "1")):
-            obj = os.path.join(OBJ_DIR, "ddmpc_inst%s_%d_%d.o" % ("" if gen == "1" else gen, nt, w))
-            extra = {"1": ["-DDDMPC_INST_V1"], "2": [], "2r": ["-DDDMPC_INST_REF=true"]}[gen]
+        # 2: the cold-solve kernel, "2r": the same with the iterative-refinement loop compiled in
+        for gen in ("2", "2r"):
+            obj = os.path.join(OBJ_DIR, "ddmpc_inst%s_%d_%d.o" % (gen, nt, w))
+            extra = {"2": [], "2r": ["-DDDMPC_INST_REF=true"]}[gen]
             cmd = [hipcc] + COMMON_FLAGS + ["-DDDMPC_INST_NT=%d" % nt, "-DDDMPC_INST_W=%d" % w] + extra + \
                   ["-c", os.path.join(CSRC, "ddmpc_inst.hip"), "-o", obj]
             tasks.append((cmd, obj, _fingerprint(cmd, INST_DEPS)))

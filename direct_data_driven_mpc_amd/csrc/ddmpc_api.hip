@@ -1,4 +1,4 @@
-// ddmpc_api.hip -- C ABI (include/ddmpc.h) over the gfx950 kernels in ddmpc_kernels.hpp.
+// ddmpc_api.hip -- C ABI (include/ddmpc.h) over the gfx950 kernels in ddmpc_cold2.hpp / ddmpc_aux_kernels.hpp.
 // Host-side responsibilities: parameter validation with the reference's error
 // conditions (direct_data_driven_mpc_controller.py:165-168,211-222,298-343,664-670),
 // device buffer ownership, kernel-instance selection, launch.
@@ -18,14 +18,6 @@ using namespace ddmpc;
 
 // The kernels are instantiated in their own translation units (ddmpc_inst.hip).
 namespace ddmpc {
-#ifndef DDMPC_NO_V1
-#define DDMPC_INSTANCE(NT, W)                                                                        \
-  extern template __global__ void ddmpc_cold_solve_kernel<NT, W>(                                    \
-      KParams, const double*, const double*, const double*, const double*, double*, double*, int*,  \
-      int*, double*, signed char*, unsigned long long*, double*, const int*);
-#include "ddmpc_instances.inc"
-#undef DDMPC_INSTANCE
-#endif
 #define DDMPC_INSTANCE(NT, W)                                                                              \
   extern template __global__ void ddmpc_cold_solve_kernel2<NT, W, false>(                                  \
       KParams, const double*, const double*, const double*, const double*, double*, double*, int*,        \
@@ -97,43 +89,32 @@ struct HostBuf {            // pinned host staging
   }
 };
 
-typedef void (*cold_kernel_t)(KParams, const double*, const double*, const double*, const double*, double*,
-                              double*, int*, int*, double*, signed char*, unsigned long long*, double*, const int*);
-
 typedef void (*cold_kernel2_t)(KParams, const double*, const double*, const double*, const double*, double*,
                                double*, int*, int*, double*, signed char*, unsigned long long*, double*, double*, int*, const int*, long long, int*);
 
 struct KernelChoice {
   int NT, W;
-  cold_kernel_t fn;          // first-generation kernel (4-wide panels), DDMPC_KERNEL=1
-  const char* name;
-  cold_kernel2_t fn2;        // 16-wide-panel kernel (ddmpc_cold2.hpp), the default
+  cold_kernel2_t fn2;        // cold-solve kernel (ddmpc_cold2.hpp)
   const char* name2;
   cold_kernel2_t fn2r;       // the same with the iterative-refinement loop compiled in
+  int lds_fixed;             // Lds2<NT, W>::xs: doubles in front of the trajectory region
+  int max_past;              // Lds2Limits: entries of [u_past; y_past] the prologue staging holds
+  int scratch;               // Lds2Limits: doubles free for the residual check of AUTO refinement
 };
 
 // Instantiated (tile rows, waves) pairs.  A problem uses the smallest NT that
 // holds rE+1 rows; larger problems are rejected as unsupported.
-#ifndef DDMPC_NO_V1
-#define DDMPC_V1_FN(NT, W) &ddmpc_cold_solve_kernel<NT, W>
-#else
-#define DDMPC_V1_FN(NT, W) nullptr
-#endif
 const KernelChoice kKernels[] = {
 #define DDMPC_INSTANCE(NT, W) \
-  {NT, W, DDMPC_V1_FN(NT, W), "ddmpc_cold_solve_kernel_v1<" #NT "," #W ">", &ddmpc_cold_solve_kernel2<NT, W, false>, "ddmpc_cold_solve_kernel2<" #NT "," #W ">", &ddmpc_cold_solve_kernel2<NT, W, true>},
+  {NT, W, &ddmpc_cold_solve_kernel2<NT, W, false>, "ddmpc_cold_solve_kernel2<" #NT "," #W ">", &ddmpc_cold_solve_kernel2<NT, W, true>, \
+   Lds2<NT, W>::xs, Lds2Limits<NT, W>::max_past, Lds2Limits<NT, W>::scratch},
 #include "ddmpc_instances.inc"
 #undef DDMPC_INSTANCE
 };
 
-size_t lds_doubles_for(int NT, int xs_len, bool v2) {
-  // the LDS carve-up depends on NT only (several W may share an NT)
-#define DDMPC_INSTANCE(NT_, W_) \
-  if (NT == NT_) return v2 ? (size_t)Lds2<NT_>::total(xs_len) : (size_t)Lds<NT_>::total(xs_len);
-#include "ddmpc_instances.inc"
-#undef DDMPC_INSTANCE
-  return 0;
-}
+// LDS doubles of a launch: the compile-time carve-up of the instance (Lds2<NT, W>::total) -- the same struct the kernel
+// takes its offsets from.
+size_t lds_doubles_for(const KernelChoice& kc, int xs_len) { return ((size_t)kc.lds_fixed + (size_t)xs_len + 1) & ~(size_t)1; }
 
 }  // namespace
 
@@ -163,21 +144,11 @@ struct ddmpc_handle {
   // host-pointer solves: one packed device buffer and its pinned host mirror (two copies per solve instead of six)
   DevBuf d_io, d_rr, d_alpha;
   DevBuf d_rflag;                          // AUTO refinement: per-instance "refine me" flags of the plain cold kernel
-  DevBuf d_zws, d_resc;                    // NOMINAL rescue kernel: z per component and a per-instance "rescued" flag (ddmpc_get_solution)
+  DevBuf d_zws, d_resc, d_xws;             // NOMINAL rescue kernel: z per component, a per-instance "rescued" flag and x = L^-T w (ddmpc_get_solution)
   bool rescue_ran = false;
   int epoch = 0;                           // cold launches so far (KParams::epoch)
   int prep_epoch = 0;                      // stamp of the flags recorded by ddmpc_prepare's factor-export launch (AUTO)
-  // AUTO refinement without the slack box: which instances get flagged depends on the data set only (the conditioning estimate
-  // is read off the pivots of G + lam*D, not off the right-hand side), so the answer of the first solve on a data set is
-  // kept: FLAG_CLEAN -> later solves are ONE launch of the plain kernel; FLAG_SET -> plain kernel + the filtered refining
-  // launch on the recorded flags; FLAG_PENDING: the counter word is on its way to the host (4-byte copy + event).
-  enum { FLAG_UNKNOWN = 0, FLAG_PENDING = 1, FLAG_CLEAN = 2, FLAG_SET = 3 };
-  int flag_state = FLAG_UNKNOWN;
-  int flag_epoch = 0;                      // latest stamp written into d_rflag (what a filtered launch must carry)
-  int probe_epoch = 0;                     // stamp the pending probe was taken for
-  HostBuf h_probe;                         // pinned: the counter word of the probed launch
-  hipEvent_t ev_probe = nullptr;
-  bool v2 = true;                          // 16-wide-panel cold kernel (default); false: first-generation kernel (DDMPC_KERNEL=1)
+  int flag_epoch = 0;                      // latest stamp written into d_rflag
   bool ws_stale = false;                   // the last solve was a cold solve that skipped the beta / active-set workspace                 // the last solve launched the rescue kernel (its flags are current)
   HostBuf h_io;
   bool prepared = false;
@@ -442,9 +413,12 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   k.sig_scale = -k.lam / k.lamb_sigma;
   k.box_cost = k.lamb_sigma * k.bound * k.bound;
   k.max_iter = p.max_iter > 0 ? p.max_iter : 50;
-  k.refine = getenv("DDMPC_REFINE") ? atoi(getenv("DDMPC_REFINE")) : DDMPC_REFINE_AUTO;   // env: development knob
+  k.refine = DDMPC_REFINE_AUTO;
   k.refine_max = 3;
-  k.refine_cond = std::pow(10.0, 6.3);   // 2e6:     // four-tank benchmark data: 1.0e6..1.3e6 with errors ~1e-12 (not refined); see DESIGN.md section 9
+  // AUTO: relative exact-Hankel residual above which an instance is re-solved with refinement.  Four-tank benchmark data:
+  // <= ~1e-12 with errors ~1e-12 (never flagged); the random-plant sweep misses the cost bar from ~1.3e-10 on and errors
+  // stay below ~30x the residual (tools/auto_flag_calib_cpu.py, profiles/r03_refine_calib.log)
+  k.refine_res = std::pow(10.0, -0.1 * DDMPC_REFINE_RES_DEFAULT);
   if (p.gram_mode == DDMPC_GRAM_STRUCTURED && k.nch != 4) {
     delete h;
     return fail(DDMPC_ERR_UNSUPPORTED, "DDMPC_GRAM_STRUCTURED needs m + p == 4 (got %d); use DDMPC_GRAM_AUTO", k.nch);
@@ -459,16 +433,8 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   const KernelChoice* kc = nullptr;
   for (const KernelChoice& cand : kKernels)
     if (16 * cand.NT >= rows_needed) { kc = &cand; break; }
-  if (kc) {   // development knob: prefer a given number of waves per instance among equal-NT instances
-    const char* wenv = getenv("DDMPC_WAVES");
-    if (wenv) {
-      const int want = atoi(wenv);
-      for (const KernelChoice& cand : kKernels)
-        if (cand.NT == kc->NT && cand.W == want) { kc = &cand; break; }
-    }
-  }
-  static const KernelChoice kLargeNominal = {0, 4, nullptr, "ddmpc_nominal_rr_kernel", nullptr, "ddmpc_nominal_rr_kernel", nullptr};
-  static const KernelChoice kLargeSolve = {0, 4, nullptr, "ddmpc_large_solve_kernel", nullptr, "ddmpc_large_solve_kernel", nullptr};
+  static const KernelChoice kLargeNominal = {0, 4, nullptr, "ddmpc_nominal_rr_kernel", nullptr, 0, 0, 0};
+  static const KernelChoice kLargeSolve = {0, 4, nullptr, "ddmpc_large_solve_kernel", nullptr, 0, 0, 0};
   if (!kc) {
     // No register-resident kernel holds this many rows.  With scalar/diagonal weights the problem is served by the
     // global-workspace kernels (plain VALU code): ROBUST controllers by
@@ -518,20 +484,23 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
     return DDMPC_OK;
   }
   // dense-Gram operand reads reach (c+2)*nch + 16*NT; the structured walks read up to
-  // x[c + 4*NT + 2]; everything past N*nch is zero padding
+  // x[c + 4*NT + 2]; everything past N*nch is zero padding (the residual check of AUTO refinement clamps its operand
+  // addresses to the region: whatever it reads past the data meets a zero in the other operand)
   k.xs_len = ((p.N - k.Ln + 4) * k.nch + 16 * h->kc.NT + 8 + 64 + 1) & ~1;   // + lag groups past Ln in the 4x4x4 base loop
   if (k.xs_len < (p.N + 2) * k.nch) k.xs_len = ((p.N + 2) * k.nch + 1) & ~1;
-  if (const char* gen = getenv("DDMPC_KERNEL")) h->v2 = atoi(gen) != 1;    // development knob: 1 = first-generation kernel
-  if (!h->v2 && !h->kc.fn) h->v2 = true;
-  const size_t lds_doubles = lds_doubles_for(h->kc.NT, k.xs_len, h->v2);
-  h->lds_bytes = lds_doubles * sizeof(double);
-  if (const char* pad = getenv("DDMPC_LDS_PAD")) {        // development knob: extra LDS bytes to lower the occupancy
-    const long v = atol(pad);
-    if (v > 0 && h->lds_bytes + (size_t)v <= 160 * 1024) h->lds_bytes += (size_t)v;
-  }
+  h->lds_bytes = lds_doubles_for(h->kc, k.xs_len) * sizeof(double);
   if (h->lds_bytes > 160 * 1024) {
     delete h;
     return fail(DDMPC_ERR_UNSUPPORTED, "trajectory too long for LDS staging: needs %zu bytes of LDS", h->lds_bytes);
+  }
+  if (p.n * k.nch > h->kc.max_past) {       // (implied by L >= n and the instance table; kept as a guard of the LDS aliasing)
+    delete h;
+    return fail(DDMPC_ERR_UNSUPPORTED, "past window of n (m+p) = %d entries exceeds the %d the kernel stages", p.n * k.nch, h->kc.max_past);
+  }
+  {   // AUTO refinement's residual check keeps alpha (16-column tiles) and at least one 16-row chunk of the second product
+      // in the LDS scratch region; shapes where it does not fit are refined unconditionally
+    const int nA = (k.c + 15) / 16, MTA = (nA + 15) / 16;
+    k.res_fits = (h->kc.scratch - 256 * MTA) / 17 >= 16 ? 1 : 0;
   }
 
   if (hipSetDevice(device) != hipSuccess) { delete h; return fail(DDMPC_ERR_HIP, "hipSetDevice(%d) failed", device); }
@@ -541,9 +510,8 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   }
   h->own_stream = true;
   if (h->lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(h->v2 ? reinterpret_cast<const void*>(h->kc.fn2) : reinterpret_cast<const void*>(h->kc.fn),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-    if (e == hipSuccess && h->v2)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(h->kc.fn2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+    if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(h->kc.fn2r), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
     if (e != hipSuccess) { ddmpc_destroy(h); return fail(DDMPC_ERR_HIP, "hipFuncSetAttribute(LDS=%zu) failed: %s", h->lds_bytes, hipGetErrorString(e)); }
   }
@@ -560,11 +528,9 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_rflag};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
-  h->h_probe.release();
-  if (h->ev_probe) (void)hipEventDestroy(h->ev_probe);
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -624,7 +590,6 @@ int ddmpc_set_data(ddmpc_handle* h, const double* u_d, const double* y_d, int me
   h->have_data = true;
   h->solved = false;
   h->prepared = false;
-  h->flag_state = ddmpc_handle::FLAG_UNKNOWN;      // new data: the refinement flags are a function of the data set
   return DDMPC_OK;
 }
 
@@ -639,10 +604,8 @@ static unsigned large_threads(size_t r) {   // workgroup size of the global-work
 // before the 32-bit stamp would wrap, when the flags and the counter are zeroed once and the stamps restart.
 static int next_refine_epoch(ddmpc_handle* h) {
   if (h->epoch >= 0x3fffffff &&
-      (!h->d_rflag.p || hipMemsetAsync(h->d_rflag.p, 0, h->d_rflag.bytes, h->stream) == hipSuccess)) {
+      (!h->d_rflag.p || hipMemsetAsync(h->d_rflag.p, 0, h->d_rflag.bytes, h->stream) == hipSuccess))
     h->epoch = 0;
-    h->flag_state = ddmpc_handle::FLAG_UNKNOWN;      // the recorded flags are gone with their stamps
-  }
   return ++h->epoch;
 }
 
@@ -683,82 +646,47 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
   signed char* aws = want_ws ? (signed char*)h->d_act.p : nullptr;
   unsigned long long* stp = h->stamps_on ? (unsigned long long*)h->d_stamps.p : (unsigned long long*)nullptr;
   dim3 grid((unsigned)h->batch), block(64 * h->kc.W);
-  if (h->v2) {
-    // Refinement (DDMPC_OPT_REFINE).  OFF / factor export / nominal scheme (z = t does not depend on beta): plain kernel.
-    // ALWAYS: the kernel variant with the refinement loop.  AUTO: plain kernel, which flags the instances whose pivots
-    // bound cond(K) from below by more than the threshold; those alone are solved again by the refining variant.
-    KParams kq = kp_override ? *kp_override : h->kp;
-    int mode = (lfac != nullptr || kq.lam == 0.0) ? DDMPC_REFINE_OFF : kq.refine;
-    if (mode == DDMPC_REFINE_ALWAYS) {
-      hipLaunchKernelGGL(h->kc.fn2r, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
-                         (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, only, 0LL, (int*)nullptr);
-    } else if (mode == DDMPC_REFINE_AUTO) {
-      // without the slack box the flags depend on the data set only: answer kept per data set (see ddmpc_handle::flag_state)
-      const bool cacheable = !kq.convex && only == nullptr && h->d_rflag.bytes >= ((size_t)h->batch + 1) * sizeof(int);
-      if (cacheable && h->flag_state == ddmpc_handle::FLAG_PENDING && hipEventQuery(h->ev_probe) == hipSuccess)
-        h->flag_state = (*(volatile int*)h->h_probe.p == h->probe_epoch) ? ddmpc_handle::FLAG_SET : ddmpc_handle::FLAG_CLEAN;
-      if (cacheable && (h->flag_state == ddmpc_handle::FLAG_CLEAN || h->flag_state == ddmpc_handle::FLAG_SET)) {
-        hipLaunchKernelGGL(h->kc.fn2, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
-                           (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, only, 0LL, (int*)nullptr);
-        if (h->flag_state == ddmpc_handle::FLAG_SET) {
-          HIP_TRY(hipGetLastError());
-          kq.refine = DDMPC_REFINE_ALWAYS;
-          kq.epoch = h->flag_epoch;
-          const unsigned pgs = (unsigned)(h->batch < 768 ? h->batch : 768);
-          hipLaunchKernelGGL(h->kc.fn2r, dim3(pgs), block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
-                             (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, (const int*)h->d_rflag.p, (long long)h->batch,
-                             (int*)h->d_rflag.p + h->batch);
-        }
-        HIP_TRY(hipGetLastError());
-        return DDMPC_OK;
-      }
-      // flags [batch] + one counter behind them (number of flagged instances of this launch; the refinement pass leaves at
-      // once when it is zero)
+  // Refinement (DDMPC_OPT_REFINE).  OFF / factor export / nominal scheme (z = t does not depend on beta): plain kernel.
+  // ALWAYS: the kernel variant with the refinement loop.  AUTO: plain kernel, which checks every instance's solve with
+  // the exact-Hankel residual and flags the ones above the threshold; those alone are solved again by the refining
+  // variant in a short persistent launch (it reads one counter word and leaves when nothing was flagged).  The decision
+  // is taken per solve: nothing about a data set is remembered, so borrowed device data may change between solves.
+  KParams kq = kp_override ? *kp_override : h->kp;
+  const int mode = (lfac != nullptr || kq.lam == 0.0) ? DDMPC_REFINE_OFF : kq.refine;
+  if (mode == DDMPC_REFINE_ALWAYS) {
+    hipLaunchKernelGGL(h->kc.fn2r, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
+                       (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, only, 0LL, (int*)nullptr);
+  } else if (mode == DDMPC_REFINE_AUTO) {
+    // flags [batch] + one counter word behind them (the largest stamp that flagged anything)
+    const bool fresh = h->d_rflag.bytes < ((size_t)h->batch + 1) * sizeof(int);
+    if ((rc = h->d_rflag.ensure(((size_t)h->batch + 1) * sizeof(int)))) return rc;
+    if (fresh) HIP_TRY(hipMemsetAsync(h->d_rflag.p, 0, ((size_t)h->batch + 1) * sizeof(int), h->stream));
+    int* rcount = (int*)h->d_rflag.p + h->batch;
+    if (only) HIP_TRY(hipMemsetAsync(h->d_rflag.p, 0, (size_t)h->batch * sizeof(int), h->stream));   // filtered-out instances: no flag
+    kq.epoch = next_refine_epoch(h);
+    hipLaunchKernelGGL(h->kc.fn2, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
+                       (int*)iters, bws, aws, stp, lfac, lfacT, (int*)h->d_rflag.p, only, 0LL, rcount);
+    HIP_TRY(hipGetLastError());
+    kq.refine = DDMPC_REFINE_ALWAYS;
+    const unsigned pg = (unsigned)(h->batch < 768 ? h->batch : 768);       // persistent grid, 3 workgroups per CU
+    hipLaunchKernelGGL(h->kc.fn2r, dim3(pg), block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
+                       (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, (const int*)h->d_rflag.p, (long long)h->batch, rcount);
+    h->flag_epoch = kq.epoch;                   // the flags now carry this stamp
+  } else {
+    // factor export for ddmpc_prepare under AUTO: the plain kernel still records which instances AUTO would refine
+    // (their columns of the affine law are then formed from refining solves, see ddmpc_prepare)
+    int *rf = nullptr, *rcount = nullptr;
+    if (lfac != nullptr && kq.lam != 0.0 && kq.refine == DDMPC_REFINE_AUTO && only == nullptr) {
       const bool fresh = h->d_rflag.bytes < ((size_t)h->batch + 1) * sizeof(int);
       if ((rc = h->d_rflag.ensure(((size_t)h->batch + 1) * sizeof(int)))) return rc;
       if (fresh) HIP_TRY(hipMemsetAsync(h->d_rflag.p, 0, ((size_t)h->batch + 1) * sizeof(int), h->stream));
-      int* rcount = (int*)h->d_rflag.p + h->batch;
-      if (only) HIP_TRY(hipMemsetAsync(h->d_rflag.p, 0, (size_t)h->batch * sizeof(int), h->stream));   // filtered-out instances: no flag
-      kq.epoch = next_refine_epoch(h);
-      hipLaunchKernelGGL(h->kc.fn2, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
-                         (int*)iters, bws, aws, stp, lfac, lfacT, (int*)h->d_rflag.p, only, 0LL, rcount);
-      HIP_TRY(hipGetLastError());
-      kq.refine = DDMPC_REFINE_ALWAYS;
-      const unsigned pg = (unsigned)(h->batch < 768 ? h->batch : 768);       // persistent grid, 3 workgroups per CU
-      hipLaunchKernelGGL(h->kc.fn2r, dim3(pg), block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
-                         (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, (const int*)h->d_rflag.p, (long long)h->batch, rcount);
-      h->flag_epoch = kq.epoch;                   // the flags now carry this stamp
-      if (!kq.convex && only == nullptr && h->flag_state == ddmpc_handle::FLAG_UNKNOWN) {
-        // first solve on this data set: send the counter word to the host (outside a stream capture) and look at it later
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(h->stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone &&
-            h->h_probe.ensure(sizeof(int)) == DDMPC_OK &&
-            (h->ev_probe != nullptr || hipEventCreateWithFlags(&h->ev_probe, hipEventDisableTiming) == hipSuccess) &&
-            hipMemcpyAsync(h->h_probe.p, rcount, sizeof(int), hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
-            hipEventRecord(h->ev_probe, h->stream) == hipSuccess) {
-          h->probe_epoch = kq.epoch;
-          h->flag_state = ddmpc_handle::FLAG_PENDING;
-        }
-      }
-    } else {
-      // factor export for ddmpc_prepare under AUTO: the plain kernel still records which instances AUTO would refine
-      // (their columns of the affine law are then formed from refining solves, see ddmpc_prepare)
-      int *rf = nullptr, *rcount = nullptr;
-      if (lfac != nullptr && kq.lam != 0.0 && kq.refine == DDMPC_REFINE_AUTO && only == nullptr) {
-        const bool fresh = h->d_rflag.bytes < ((size_t)h->batch + 1) * sizeof(int);
-        if ((rc = h->d_rflag.ensure(((size_t)h->batch + 1) * sizeof(int)))) return rc;
-        if (fresh) HIP_TRY(hipMemsetAsync(h->d_rflag.p, 0, ((size_t)h->batch + 1) * sizeof(int), h->stream));
-        rf = (int*)h->d_rflag.p; rcount = rf + h->batch;
-        kq.epoch = h->prep_epoch = next_refine_epoch(h);
-        h->flag_epoch = kq.epoch;
-        if (h->flag_state == ddmpc_handle::FLAG_PENDING) h->flag_state = ddmpc_handle::FLAG_UNKNOWN;   // (its probe refers to an older stamp)
-      }
-      hipLaunchKernelGGL(h->kc.fn2, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
-                         (int*)iters, bws, aws, stp, lfac, lfacT, rf, only, 0LL, rcount);
+      rf = (int*)h->d_rflag.p; rcount = rf + h->batch;
+      kq.epoch = h->prep_epoch = next_refine_epoch(h);
+      h->flag_epoch = kq.epoch;
     }
-  } else
-    hipLaunchKernelGGL(h->kc.fn, grid, block, h->lds_bytes, h->stream, kp_override ? *kp_override : h->kp, h->ud, h->yd,
-                       up, yp, uo, cost, (int*)status, (int*)iters, bws, aws, stp, lfac, only);
+    hipLaunchKernelGGL(h->kc.fn2, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
+                       (int*)iters, bws, aws, stp, lfac, lfacT, rf, only, 0LL, rcount);
+  }
   HIP_TRY(hipGetLastError());
   return DDMPC_OK;
 }
@@ -816,6 +744,7 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
   {   // z per component + "rescued" flag per instance, read by ddmpc_get_solution
     int rcz = h->d_zws.ensure((size_t)h->batch * h->kp.rE * sizeof(double));
     if (!rcz) rcz = h->d_resc.ensure((size_t)h->batch * sizeof(int));
+    if (!rcz) rcz = h->d_xws.ensure((size_t)h->batch * h->kp.rE * sizeof(double));
     if (rcz) return rcz;
     HIP_TRY(hipMemsetAsync(h->d_resc.p, 0, (size_t)h->batch * sizeof(int), h->stream));
   }
@@ -829,7 +758,7 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
                      (double*)h->d_alpha.p,
                      (h->stamps_on && h->d_stamps.bytes >= (size_t)h->batch * 8 * sizeof(uint64_t)) ? (unsigned long long*)h->d_stamps.p
                                                                                                       : (unsigned long long*)nullptr,
-                     (double*)h->d_zws.p, (int*)h->d_resc.p);
+                     (double*)h->d_zws.p, (int*)h->d_resc.p, (double*)h->d_xws.p);
   HIP_TRY(hipGetLastError());
   h->rescue_ran = true;
   return DDMPC_OK;
@@ -943,7 +872,7 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
   for (size_t k = 0; k < nchunks; ++k) HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
   // refinement (see launch_cold): ALWAYS -> the refining kernel variant per chunk; AUTO -> the chunks flag the instances
   // that need it and one filtered launch of the refining variant follows the last chunk
-  const bool refinable = h->v2 && h->kp.lam != 0.0;
+  const bool refinable = h->kp.lam != 0.0;
   const bool always = refinable && h->kp.refine == DDMPC_REFINE_ALWAYS;
   int* rflag = nullptr;
   if (refinable && h->kp.refine == DDMPC_REFINE_AUTO) {
@@ -954,7 +883,6 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
   }
   KParams kchunk = h->kp;
   kchunk.epoch = next_refine_epoch(h);
-  h->flag_state = ddmpc_handle::FLAG_UNKNOWN;        // new data set (uploaded below): the recorded refinement decision is void
   h->flag_epoch = kchunk.epoch;
   int rcl = DDMPC_OK;
   for (size_t k = 0; k < nchunks && rcl == DDMPC_OK; ++k) {
@@ -965,18 +893,11 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
       rcl = fail(DDMPC_ERR_HIP, "ddmpc_solve_from_host: upload of chunk %zu failed", k);
       break;
     }
-    if (h->v2)
-      hipLaunchKernelGGL(always ? h->kc.fn2r : h->kc.fn2, dim3((unsigned)nb), dim3(64 * h->kc.W), h->lds_bytes, h->stream, kchunk,
-                         (const double*)(dud + b0 * su), (const double*)(dyd + b0 * sy), (const double*)(dup + b0 * sup),
-                         (const double*)(dyp + b0 * syp), duo + b0 * suo, dco + b0, (int*)(dst + b0), (int*)(dit + b0),
-                         (double*)nullptr, (signed char*)nullptr, (unsigned long long*)nullptr, (double*)nullptr,
-                         (double*)nullptr, rflag ? rflag + b0 : (int*)nullptr, (const int*)nullptr, 0LL, rflag ? rflag + B : (int*)nullptr);
-    else
-      hipLaunchKernelGGL(h->kc.fn, dim3((unsigned)nb), dim3(64 * h->kc.W), h->lds_bytes, h->stream, h->kp,
-                         (const double*)(dud + b0 * su), (const double*)(dyd + b0 * sy), (const double*)(dup + b0 * sup),
-                         (const double*)(dyp + b0 * syp), duo + b0 * suo, dco + b0, (int*)(dst + b0), (int*)(dit + b0),
-                         (double*)nullptr, (signed char*)nullptr, (unsigned long long*)nullptr, (double*)nullptr,
-                         (const int*)nullptr);
+    hipLaunchKernelGGL(always ? h->kc.fn2r : h->kc.fn2, dim3((unsigned)nb), dim3(64 * h->kc.W), h->lds_bytes, h->stream, kchunk,
+                       (const double*)(dud + b0 * su), (const double*)(dyd + b0 * sy), (const double*)(dup + b0 * sup),
+                       (const double*)(dyp + b0 * syp), duo + b0 * suo, dco + b0, (int*)(dst + b0), (int*)(dit + b0),
+                       (double*)nullptr, (signed char*)nullptr, (unsigned long long*)nullptr, (double*)nullptr,
+                       (double*)nullptr, rflag ? rflag + b0 : (int*)nullptr, (const int*)nullptr, 0LL, rflag ? rflag + B : (int*)nullptr);
     if (hipGetLastError() != hipSuccess) rcl = fail(DDMPC_ERR_HIP, "ddmpc_solve_from_host: launch of chunk %zu failed", k);
   }
   if (rcl == DDMPC_OK && rflag) {
@@ -1039,9 +960,6 @@ int ddmpc_prepare(ddmpc_handle* h) {
     return rc;
   const size_t ntiles = B * (size_t)(NT * (NT + 1) / 2);
   if (ntiles > 0x7fffffffULL) return fail(DDMPC_ERR_INVALID, "batch too large for ddmpc_prepare");
-  if (!h->v2)       // the first-generation kernel exports L only; the 16-wide-panel kernel writes both layouts itself
-    hipLaunchKernelGGL(ddmpc_transpose_tiles_kernel, dim3((unsigned)ntiles), dim3(256), 0, h->stream,
-                       (const double*)h->d_lfac.p, (double*)h->d_lfacT.p);
   if ((rc = h->d_beta.ensure(B * k.rE * sizeof(double)))) return rc;     // beta of the cold launch above
   bool launched = false;
 #define DDMPC_INSTANCE(NT_, W_)                                                                              \
@@ -1058,7 +976,7 @@ int ddmpc_prepare(ddmpc_handle* h) {
 #undef DDMPC_INSTANCE
   if (!launched) return fail(DDMPC_ERR_UNSUPPORTED, "no gain kernel for %d tile rows", NT);
   HIP_TRY(hipGetLastError());
-  if (h->v2 && k.lam != 0.0 && (k.refine == DDMPC_REFINE_ALWAYS || k.refine == DDMPC_REFINE_AUTO)) {
+  if (k.lam != 0.0 && (k.refine == DDMPC_REFINE_ALWAYS || k.refine == DDMPC_REFINE_AUTO)) {
     // The substitutions above went through the unrefined factor, whose error is the Gram route's (cond(H) squared).
     // Replace columns of the law by refining cold solves: beta is affine in the past window, so column 1 + f =
     // beta(e_f) - beta(0).  nf + 1 launches of the refining kernel variant, once per data set -- ALWAYS: for every
@@ -1141,17 +1059,16 @@ int ddmpc_set_option(ddmpc_handle* h, int option, int value) {
         return fail(DDMPC_ERR_INVALID, "refinement mode must be DDMPC_REFINE_OFF, _AUTO or _ALWAYS");
       h->kp.refine = value;
       h->prepared = false;              // the affine law is formed from a refined solve of the offset column
-      h->flag_state = ddmpc_handle::FLAG_UNKNOWN;
       return DDMPC_OK;
     case DDMPC_OPT_REFINE_MAX:
       if (value < 1 || value > 10) return fail(DDMPC_ERR_INVALID, "refinement passes must be within [1, 10]");
       h->kp.refine_max = value;
       return DDMPC_OK;
-    case DDMPC_OPT_REFINE_COND_LOG10:
-      if (value < 0 || value > 3000) return fail(DDMPC_ERR_INVALID, "refinement threshold (tenths of a decade) must be within [0, 3000]");
-      h->kp.refine_cond = std::pow(10.0, 0.1 * (double)value);
+    case DDMPC_OPT_REFINE_RES_LOG10:
+      if (value < 0 || value > 3000)
+        return fail(DDMPC_ERR_INVALID, "refinement threshold (tenths of a decade below 1) must be within [0, 3000]");
+      h->kp.refine_res = std::pow(10.0, -0.1 * (double)value);
       h->prepared = false;
-      h->flag_state = ddmpc_handle::FLAG_UNKNOWN;
       return DDMPC_OK;
     default: return fail(DDMPC_ERR_INVALID, "unknown option %d", option);
   }
@@ -1221,12 +1138,14 @@ int ddmpc_get_solution(ddmpc_handle* h, int what, double* out, int mem) {
     if (rc) return rc;
     dst = (double*)h->d_out.p;
   }
-  // instances solved by the NOMINAL rescue kernel have no beta: ubar / ybar come from the z it exported, alpha is NaN
+  // instances solved by the NOMINAL rescue kernel have no beta: ubar / ybar come from the z it exported, alpha = H' x from
+  // the vector x it exported
   const bool resc = h->rescue_ran && h->d_resc.p && h->d_zws.p;
   if (h->large_nominal && !resc) return fail(DDMPC_ERR_NOT_READY, "no solve to read a solution from");
   hipLaunchKernelGGL(ddmpc_reconstruct_kernel, dim3((unsigned)h->batch), dim3(256), 0, h->stream, k, 16 * h->kc.NT, what, h->ud,
                      h->yd, h->last_up, h->last_yp, (const double*)h->d_beta.p, (const signed char*)h->d_act.p, dst,
-                     resc ? (const double*)h->d_zws.p : (const double*)nullptr, resc ? (const int*)h->d_resc.p : (const int*)nullptr);
+                     resc ? (const double*)h->d_zws.p : (const double*)nullptr, resc ? (const int*)h->d_resc.p : (const int*)nullptr,
+                     resc ? (const double*)h->d_xws.p : (const double*)nullptr);
   HIP_TRY(hipGetLastError());
   if (mem == DDMPC_MEM_HOST) {
     HIP_TRY(hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -1397,7 +1316,7 @@ int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps
   if (!warm) {
     if ((rc = h->d_beta.ensure(B * h->kp.rE * sizeof(double))) || (rc = h->d_act.ensure(B * h->kp.rE))) return rc;
     if (warm_box && (rc = h->d_need.ensure(B * sizeof(int)))) return rc;
-    if (h->v2 && !h->large) {       // AUTO refinement flags of launch_cold: sized (and cleared once) before a capture starts
+    if (!h->large) {       // AUTO refinement flags of launch_cold: sized (and cleared once) before a capture starts
       const bool fresh = h->d_rflag.bytes < (B + 1) * sizeof(int);
       if ((rc = h->d_rflag.ensure((B + 1) * sizeof(int)))) return rc;
       if (fresh) HIP_TRY(hipMemsetAsync(h->d_rflag.p, 0, (B + 1) * sizeof(int), h->stream));
@@ -1471,7 +1390,7 @@ int ddmpc_cost_model(ddmpc_handle* h, double* flops_per_solve, double* bytes_per
   return DDMPC_OK;
 }
 
-const char* ddmpc_kernel_name(ddmpc_handle* h) { return h ? (h->v2 ? h->kc.name2 : h->kc.name) : ""; }
+const char* ddmpc_kernel_name(ddmpc_handle* h) { return h ? h->kc.name2 : ""; }
 
 int ddmpc_debug_stamps(ddmpc_handle* h, int enable, uint64_t* out) {
   if (!h) return fail(DDMPC_ERR_INVALID, "null handle");

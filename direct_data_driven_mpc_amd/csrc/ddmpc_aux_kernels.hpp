@@ -36,17 +36,14 @@ __global__ void ddmpc_reconstruct_kernel(KParams P, int RPs, int what, const dou
                                          const double* __restrict__ y_d, const double* __restrict__ u_past,
                                          const double* __restrict__ y_past, const double* __restrict__ beta_ws,
                                          const signed char* __restrict__ act_ws, double* __restrict__ out,
-                                         const double* __restrict__ z_ws, const int* __restrict__ rescued) {
+                                         const double* __restrict__ z_ws, const int* __restrict__ rescued,
+                                         const double* __restrict__ x_ws) {
   const long long b = blockIdx.x;
   const int n = P.npu / P.m;
-  if (rescued != nullptr && rescued[b] != 0) {
-    // NOMINAL instance solved by the rank-revealing kernel (exact data): it exports z = [ubar; ybar] per component;
-    // alpha is not formed there (any alpha with H alpha = z is optimal; the kernel never picks one) -> NaN
-    const double nanv = __longlong_as_double(0x7ff8000000000000LL);
-    if (what == 0) {
-      for (int i = threadIdx.x; i < P.c; i += blockDim.x) out[b * (long long)P.c + i] = nanv;
-      return;
-    }
+  const bool resc = rescued != nullptr && rescued[b] != 0;
+  if (resc && what != 0) {
+    // NOMINAL instance solved by the rank-revealing kernel (exact data): it exports z = [ubar; ybar] per component and
+    // the vector x = L^-T w with z = H (H' x): alpha = H' x below, the minimum-norm alpha with H alpha = z (controller.py:434)
     for (int rho = threadIdx.x; rho < P.r; rho += blockDim.x) {
       const int k = rho / P.nch, ch = rho - k * P.nch;
       const double z = z_ws[b * (long long)P.rE + rho];
@@ -55,7 +52,7 @@ __global__ void ddmpc_reconstruct_kernel(KParams P, int RPs, int what, const dou
     }
     return;
   }
-  const double* bw = beta_ws + b * (long long)P.rE;
+  const double* bw = (resc ? x_ws : beta_ws) + b * (long long)P.rE;
   const signed char* aw = act_ws + b * (long long)P.rE;
   const double* up = u_past + b * (long long)P.npu;
   const double* yp = y_past + b * (long long)(n * P.p);
@@ -1327,7 +1324,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
                                                                double rank_tol, double feas_tol, double* scratch,
                                                                long long scratch_stride, double* w_ws,
                                                                unsigned long long* dbg, double* __restrict__ z_ws,
-                                                               int* __restrict__ rescued) {
+                                                               int* __restrict__ rescued, double* __restrict__ x_ws) {
   extern __shared__ __attribute__((aligned(16))) double rsm_lds[];
   const long long b = blockIdx.x;
   if (status[b] != 4) return;                           // uniform: only instances the fast path gave up on
@@ -1539,6 +1536,15 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
     if (z_ws) z_ws[b * (long long)P.rE + perm[k]] = fv[k];
   }
   if (rescued && tid == 0) rescued[b] = 1;
+  if (x_ws) {
+    // x = L_I^-T w of the final w (component order): z = H (H' x), so alpha = H' x is formed on demand by
+    // ddmpc_reconstruct_kernel (the `.alpha.value` stand-in of controller.py:434)
+    __syncthreads();
+    for (int k = tid; k < r; k += nthr) ra[k] = wk[k] + ((k < nF) ? rb[k] : vv[k - nF]);
+    __syncthreads();
+    packed_back_substitute(G, r, ra, col, skip);
+    for (int k = tid; k < r; k += nthr) x_ws[b * (long long)P.rE + perm[k]] = col[k];
+  }
   part = wave_sum(part);
   __syncthreads();
   if ((tid & 63) == 0) red[tid >> 6] = part;

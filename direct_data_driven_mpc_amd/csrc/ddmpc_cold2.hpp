@@ -1,8 +1,8 @@
-// ddmpc_cold2.hpp -- second-generation cold-solve kernel for gfx950: same mathematics, inputs and outputs as
-// ddmpc_cold_solve_kernel (ddmpc_kernels.hpp), with the factorisation restructured around 16-wide panels:
+// ddmpc_cold2.hpp -- the cold-solve kernel for gfx950: one workgroup per controller instance, the whole r x r system
+// in MFMA accumulator tiles, blocked Cholesky with 16-wide panels:
 //
-//   * tiles are kept K-MAJOR: register j of lane (l4, l15) of tile (I,J), I >= J, holds K[16J + l4 + 4j][16I + l15]
-//     (the transpose of what the first kernel keeps).  In this orientation an accumulator tile is directly the B
+//   * tiles are kept K-MAJOR: register j of lane (l4, l15) of tile (I,J), I >= J, holds K[16J + l4 + 4j][16I + l15].
+//     In this orientation an accumulator tile is directly the B
 //     operand of a LEFT multiplication, so the triangular solve of a whole tile is 4 MFMAs with no LDS round trip:
 //         U(J,I) = L_JJ^-1 K(J,I)          <-  D = (-M) * T,  M = L_JJ^-1 from LDS, T = the (negated) accumulator tile
 //     and a dumped tile (PB[k][16I + i], k-major) is both the A and the B operand of the trailing update
@@ -11,8 +11,8 @@
 //     4-wide sub-steps that never leave the wave (no workgroup barrier): 32 lanes = 16 tile rows + 16 rows of an
 //     identity block that ride along, so the same substitution that produces L_JJ also produces M = L_JJ^-1; the
 //     rank-4 updates inside the tile are 2 MFMAs per sub-step.  The other waves do nothing but MFMAs.
-//   * per 16 columns: 2 workgroup barriers (M ready -> TRSM; panel dumped -> trailing update) instead of 8, and the
-//     redundant per-thread 4x4 factorisations of the first kernel happen on one wave only.
+//   * per 16 columns: 3 workgroup barriers (M ready -> TRSM of the next diagonal tile's neighbour; panel dumped ->
+//     trailing update; next M ready).
 //   * L y = t rides along as column rE of the matrix; L' beta = y runs tile column by tile column, right to left, with
 //     ONE workgroup barrier per column: every wave sums its tiles' contributions (4 multiply-adds per tile + one 16-lane
 //     DPP reduction) into LDS, then every wave forms x_J = M_J' (y_J - parts) redundantly from the M tiles in LDS.
@@ -103,8 +103,8 @@ __device__ __forceinline__ d2 permlane16_swap_f64(double a, double b) {
 }
 
 // 1/sqrt(x) for the pivots of the in-tile factorisation: hardware seed (v_rsq_f64, ~2^-26) + ONE Newton step
-// y0 (1 + e/2), e = 1 - x y0^2: relative error 3/8 e^2 ~ 1e-16, two dependent operations shorter than the third-order
-// rsq_nr of the first kernel; the pivots sit on the workgroup's critical path.
+// y0 (1 + e/2), e = 1 - x y0^2: relative error 3/8 e^2 ~ 1e-16, two dependent operations shorter than a third-order
+// correction; the pivots sit on the workgroup's critical path.
 __device__ __forceinline__ double rsq_n2(double x) {
   const double y0 = __builtin_amdgcn_rsq(x);
   const double e = fma(-x * y0, y0, 1.0);
@@ -121,8 +121,11 @@ __device__ __forceinline__ double rows4_total(double v) {
   return __hiloint2double((int)hi2[0], (int)lo2[0]) + __hiloint2double((int)hi2[1], (int)lo2[1]);
 }
 
-// LDS carve-up (doubles) of the second kernel.
-template <int NT>
+// LDS carve-up (doubles).  Every offset is a compile-time function of (NT, W); the only runtime length is the trajectory
+// region at the end.  The host sizes the launch from the same struct (Lds2<NT, W>::total, ddmpc_api.hip), and every
+// aliasing / capacity assumption the kernel makes is a static_assert here: an overrun is a compile error, not a fault
+// that shows up in one instance only.
+template <int NT, int W>
 struct Lds2 {
   static constexpr int RP = 16 * NT;
   static constexpr int dvec = 0;
@@ -132,26 +135,53 @@ struct Lds2 {
   static constexpr int cd1 = cd0 + RP;                 //   D (inactive / bound active), target (past window folded in),
   static constexpr int ct0 = cd1 + RP;                 //   kind (ints, RP/2 doubles)
   static constexpr int ckk = ct0 + RP;
-  static constexpr int PARTW = NT > 9 ? 8 : 4;        // waves of the instance that uses this NT (ddmpc_instances.inc)
-  static constexpr int part = ckk + (RP + 1) / 2;      // back substitution: 2 x [waves][16] partial sums (alternating rounds)
-  static constexpr int red = part + 2 * 16 * PARTW;    // 32
-  static constexpr int ints = red + 32;                // int act[RP], int flags[8]
-  static constexpr int pt2 = (ints + (RP + 8 + 1) / 2 + 2) & ~1;   // in-tile panel, row-major: [32 rows][4]
+  static constexpr int PART_LEN = 2 * 16 * W;          // back substitution: 2 x [waves][16] partial sums (alternating rounds)
+  static constexpr int part = ckk + (RP + 1) / 2;
+  static constexpr int RED_LEN = 32;                   // block reductions: slots [w], [8 + w], [16 + w], w < W
+  static constexpr int red = part + PART_LEN;
+  static constexpr int ints = red + RED_LEN;           // int act[RP], int flags[8]
+  static constexpr int INTS_LEN = (RP + 8 + 1) / 2;
+  static constexpr int pt2 = (ints + INTS_LEN + 2) & ~1;   // in-tile panel, row-major: [32 rows][4]
+  static constexpr int PT2_LEN = 32 * 4;
   static constexpr int LRS = 36;                       // row stride of lt16: 32 rows + 4 (spreads the 4 k-rows of an operand read over the banks)
-  static constexpr int lt16 = pt2 + 128;               // in-tile factor, k-major: [16][LRS]: x < 16 -> L_JJ[x][k], 16 + x' -> M[k][x']
+  static constexpr int lt16 = pt2 + PT2_LEN;           // in-tile factor, k-major: [16][LRS]: x < 16 -> L_JJ[x][k], 16 + x' -> M[k][x']
+  static constexpr int LT_LEN = 16 * LRS;
   static constexpr int pastw = lt16;                   // prologue only (lt16 is first written two barriers later): [u_past; y_past],
-  static constexpr int cpp = lt16 + 16 * LRS / 2;      //   n (m+p) <= RP/2 entries, and each component's index into it (ints)
+  static constexpr int PASTW_CAP = LT_LEN / 2;         //   at most PASTW_CAP entries (checked at create time), and each
+  static constexpr int cpp = lt16 + PASTW_CAP;         //   component's index into it (RP ints)
   static constexpr int RSB = RP + 4;                   // row stride of the panel buffer
-  static constexpr int pb = lt16 + 16 * LRS;           // panel buffer, k-major: PB[k][16 I + i] = U(Jp, I)[k][i]
-  static constexpr int ctab = pb + 16 * RSB;           // lag blocks C[d][a][b], d < RP/4 (structured Gram)
-  static constexpr int xs = ctab + 4 * RP;             // trajectory, channel-interleaved
+  static constexpr int pb = lt16 + LT_LEN;             // panel buffer, k-major: PB[k][16 I + i] = U(Jp, I)[k][i]
+  static constexpr int PB_LEN = 16 * RSB;
+  static constexpr int ctab = pb + PB_LEN;             // lag blocks C[d][a][b], d < RP/4 (structured Gram)
+  static constexpr int CTAB_LEN = 4 * RP;
+  static constexpr int xs = ctab + CTAB_LEN;           // trajectory, channel-interleaved
+  // scratch of the residual check behind the solve (everything between pt2 and xs is free by then)
+  static constexpr int SCR = pt2;
+  static constexpr int SCR_LEN = xs - pt2;
   __host__ __device__ static constexpr int total(int xs_len) { return (xs + xs_len + 1) & ~1; }
+
+  static_assert(W >= 1 && W <= 8, "red[] keeps 8 per-wave slots per quantity; part[] is sized by W");
+  static_assert(16 + W <= RED_LEN, "red[16 + w] (output stage) must stay inside red[]");
+  static_assert(pt2 >= ints + INTS_LEN && (pt2 & 1) == 0, "act[RP] + flags[8] end before the in-tile panel; 16-byte aligned");
+  static_assert(cpp + (RP + 1) / 2 <= lt16 + LT_LEN, "prologue staging (past window + its index table) must fit inside lt16");
+  static_assert(NT * 256 <= PB_LEN, "back substitution keeps the NT inverse diagonal tiles M_J in the panel buffer");
+  static_assert(16 * (RP / 4) <= CTAB_LEN, "one 4x4 lag block per time step of the window");
+  static_assert((xs & 1) == 0 && (lt16 & 1) == 0 && (pb & 1) == 0, "16-byte alignment of the regions accessed with b128");
+};
+
+// Host-side mirror of the runtime capacity conditions (ddmpc_create refuses shapes that break them).
+template <int NT, int W>
+struct Lds2Limits {
+  static constexpr int max_past = Lds2<NT, W>::PASTW_CAP;     // n (m + p) entries of [u_past; y_past]
+  static constexpr int scratch = Lds2<NT, W>::SCR_LEN;        // doubles free for the residual check
 };
 
 // REF: compile the iterative-refinement loop in.  The plain variant (REF = false) is the fast one; when asked to
-// (refine_flag != nullptr) it records whether its pivots call for refinement, and the API re-solves exactly those
-// instances with the REF variant (DDMPC_REFINE_AUTO).  Keeping the loop out of the plain variant keeps its register
-// allocation free of spills on the factorisation's critical path.
+// (refine_flag != nullptr) it checks its own answer -- the residual t - (H (H' beta) + lam D beta) evaluated with exact
+// products with the implicit Hankel matrix, two small MFMA contractions from the trajectory already in LDS -- and
+// records whether it exceeds the threshold; the API re-solves exactly those instances with the REF variant
+// (DDMPC_REFINE_AUTO).  Keeping the loop out of the plain variant keeps its register allocation free of spills on the
+// factorisation's critical path.
 template <int NT, int W, int WAVE, bool REF>
 __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict__ sm,
                                            const double* __restrict__ up, const double* __restrict__ yp,
@@ -163,7 +193,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
                                            int* __restrict__ refine_count) {
   using TM = TileMap2<NT, W>;
   using WT = WaveTiles2<NT, W, WAVE>;
-  using LD = Lds2<NT>;
+  using LD = Lds2<NT, W>;
   constexpr int RP = 16 * NT;
   constexpr int NTHR = 64 * W;
   constexpr int LRS = LD::LRS, RSB = LD::RSB;
@@ -195,6 +225,8 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
   const int IR = rE >> 4;           // tile column holding the rhs column (column index rE)
   const int rr = rE & 15;
 
+  static_assert(8 * TM::MAXS + 40 <= 512 / DDMPC_MIN_WAVES(NT, W),
+                "the accumulator tiles of the busiest wave must leave a working set of 40 VGPRs at the occupancy of __launch_bounds__");
   d4 acc[TM::MAXS];
 
   constexpr int NE = (RP + NTHR - 1) / NTHR;
@@ -222,7 +254,6 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
   int iter = 0;
   int status = 0;
   int tid = tid0;
-  double imax = 0.0, kmax = 0.0;     // panel wave: largest 1/sqrt(pivot) and largest diagonal entry of K
   long long tphF = 0, tphB = 0, tphT = 0, tphA = 0, tphU = 0;
   const bool timing = (stamps != nullptr) && (WAVE == 0);
   auto now = [&]() __attribute__((always_inline)) -> long long { return timing ? (long long)__builtin_amdgcn_s_memtime() : 0; };
@@ -250,7 +281,6 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
     __syncthreads();   // trajectory staged (first pass), tables visible
     stamp();           // 1
 
-    imax = 0.0;
     bool f0_done = false;   // structured Gram: the panel wave has already factored diagonal tile 0 (beside the other waves' walks)
     // -(G + lam*D) of one raw Gram tile; -identity on dummy rows; rhs COLUMN rE := -t (mirrored into the diagonal tile);
     // dense weighting matrices: lam * W^-1 is a full symmetric matrix shared by the batch (L2)
@@ -261,7 +291,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
       if constexpr (I == J) {
         static_for<4>([&](auto j) __attribute__((always_inline)) {
           const int gr = 16 * J + l4 + 4 * j;
-          if (gr == gc && gr < r) { v[j()] -= P.lam * dvec[gr]; kmax = fmax(kmax, -v[j()]); }
+          if (gr == gc && gr < r) v[j()] -= P.lam * dvec[gr];
         });
       }
       if (16 * I + 15 >= r) {                             // wave-uniform: tile columns that touch the padding / rhs column
@@ -368,7 +398,6 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         const int k = l4 + 4 * j();
         const double mv = LT[k * LRS + 16 + l15];
         acc[SD][j()] = (k < 4 * nq) ? mv : 0.0;                     // register j of lane (l4, l15) = M[l4 + 4j][l15]
-        if (k == l15 && k < 4 * nq) imax = fmax(imax, mv);          // diag M = 1/sqrt(pivot): conditioning estimate (refinement trigger)
       });
       if (Jt == IR) {                                               // y of the last tile column = the substituted rhs row
         if (lane < 4 * nq) tvec[16 * Jt + lane] = LT[lane * LRS + rr];
@@ -744,7 +773,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
       static_for<NT>([&](auto JREV) __attribute__((always_inline)) {
         constexpr int J = NT - 1 - JREV;
         if (16 * J < rE) {                                            // workgroup-uniform
-          double* pr = part + (J & 1) * (16 * LD::PARTW);
+          double* pr = part + (J & 1) * (16 * W);
           if constexpr (TM::has_col(WAVE, J)) {
             d4 s = d4{0.0, 0.0, 0.0, 0.0};
             static_for<NT>([&](auto I) __attribute__((always_inline)) {
@@ -815,35 +844,16 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         }
       });
     };
-    if constexpr (WAVE == 0) {       // conditioning estimate for the refinement trigger: visible after the sweep's barriers
-      if ((REF && P.refine != 0) || refine_flag != nullptr) {
-        double km = kmax, im = imax;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { km = fmax(km, __shfl_xor(km, off, 64)); im = fmax(im, __shfl_xor(im, off, 64)); }
-        const double est = km * im * im;                              // max K_kk * max 1/d_k <= cond(K)
-        if (lane == 0) {
-          red[30] = est;
-          if (refine_flag != nullptr) {
-            // epoch stamps instead of counts: nothing has to be cleared between launches (P.epoch grows by one per launch)
-            const int f = (P.lam != 0.0 && !(est <= P.refine_cond)) ? P.epoch : 0;
-            *refine_flag = f;
-            if (f && refine_count != nullptr) atomicMax(refine_count, P.epoch);
-          }
-          if (stamps != nullptr) stamps[12] = (unsigned long long)__double_as_longlong(est);      // diagnostics
-        }
-      }
-    }
     back_substitute(beta);
 
     // ---- iterative refinement: residual with EXACT products with the implicit Hankel matrix,
     //        rho = t - ( H (H' beta) + lam D beta ),
     //      solved against the factor at hand.  The Gram route squares cond(H); the residual is evaluated through H
     //      itself (two products from the trajectory in LDS), so the corrected beta is accurate to cond(H)-level like a
-    //      full-space solve.  Auto mode: only when the pivots say the system is ill-conditioned.
+    //      full-space solve.  (AUTO mode launches this variant on the instances the plain variant's residual check flagged.)
     if constexpr (REF) {
     if (P.refine != 0 && P.lam != 0.0) {      // nominal scheme: z = t does not depend on beta, nothing to refine
-      const double cond_lb = red[30];
-      bool go = (P.refine >= 2) || !(cond_lb <= P.refine_cond);       // NaN (failed pivot): falls through harmlessly
+      bool go = true;
       double prev = 1e300;
       for (int pass = 0; go && pass < P.refine_max; ++pass) {
         // alpha = H' beta in chunks that fit the (now free) panel buffer, z += H[:, chunk] alpha[chunk]
@@ -940,6 +950,123 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
   if (flags[0] != 0) status = 4;
   const int lane = tid & 63;
 
+  // ---- AUTO refinement trigger (plain variant only): a-posteriori check of the solve just finished ------------------
+  //   res = | t - ( H (H' beta) + lam D beta ) |_inf / | t |_inf  with EXACT products with the implicit Hankel matrix.
+  // The Gram route's error (cond(H) squared) shows in this residual, a conditioning estimate read off the pivots does
+  // not tell it apart from harmless ill-conditioning (calibration: tools/auto_flag_calib_cpu.py, tools/refine_calib.py).
+  // Both products run on the matrix pipe as small dense contractions over a re-blocked Hankel operand; columns i = 16a+b:
+  //   alpha[a][b] = sum_k  X[a][k] T[k][b],   X[a][k] = x[16 nch a + k],  T[k][b] = beta[k - nch b]     (k < r + 15 nch)
+  //   P[m][b]     = sum_a  X[a][m] alpha[a][b],                           g[rho]  = sum_b P[nch b + rho][b]
+  // alpha and the rows of P (in chunks) live in the LDS between pt2 and xs, all free behind the factorisation.
+  if constexpr (!REF) {
+    if (refine_flag != nullptr) {                                      // kernel-uniform
+      int flag = 0;
+      if (P.lam != 0.0 && !P.res_fits) flag = P.epoch;                  // the check cannot be staged for this shape: refine
+      if (P.lam != 0.0 && P.res_fits) {
+        const int l15 = lane & 15, l4 = lane >> 4;
+        const int c = P.c;
+        const int nA = (c + 15) >> 4;                                   // a < nA
+        const int MTA = (nA + 15) >> 4;                                 // 16-row tiles of a
+        const int KA = r + 15 * nch;                                    // contraction length of the first product = rows of P
+        const int MTB = (KA + 15) >> 4;
+        const int xlast = P.xs_len - 1;
+        double* al = sm + LD::SCR;                                      // alpha[16 a + b], zero beyond c
+        double* Pt = al + 256 * MTA;                                    // chunk of P: [rows][17]
+        const int TC = ((LD::SCR_LEN - 256 * MTA) / 17) >> 4;           // tiles per chunk (>= 1: P.res_fits)
+        __syncthreads();                                                // beta complete, PB / LT / ctab no longer read
+        for (int mt = WAVE; mt < MTA; mt += W) {
+          d4 a1 = d4{0.0, 0.0, 0.0, 0.0};
+          const int a = 16 * mt + l15;
+          const bool aok = a < nA;
+          const int xa = 16 * nch * a + l4;
+          const int tb = l4 - nch * l15;
+#pragma nounroll
+          for (int k0 = 0; k0 < KA; k0 += 4) {
+            int xi = xa + k0; xi = xi < xlast ? xi : xlast;
+            const double xo = xs[xi];
+            int bi = tb + k0;
+            const bool bok = bi >= 0 && bi < r;
+            bi = bok ? bi : 0;
+            const double bo = beta[bi];
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aok ? xo : 0.0, bok ? bo : 0.0, a1, 0, 0, 0);
+          }
+          static_for<4>([&](auto j) __attribute__((always_inline)) {
+            const int i = 256 * mt + 16 * (l4 + 4 * j()) + l15;
+            al[i] = (i < c) ? a1[j()] : 0.0;
+          });
+        }
+        __syncthreads();
+        double g[NE];
+        static_for<NE>([&](auto e) __attribute__((always_inline)) { g[e()] = 0.0; });
+        const int KSB = (nA + 3) >> 2;
+        for (int m0 = 0; m0 < MTB; m0 += TC) {
+          const int m1 = (m0 + TC) < MTB ? (m0 + TC) : MTB;
+          for (int mt = m0 + WAVE; mt < m1; mt += W) {
+            d4 p1 = d4{0.0, 0.0, 0.0, 0.0};
+            const int xm = 16 * mt + l15;
+#pragma nounroll
+            for (int ks = 0; ks < KSB; ++ks) {
+              const int a = 4 * ks + l4;
+              int xi = 16 * nch * a + xm; xi = xi < xlast ? xi : xlast;
+              const double xo = xs[xi];
+              const double ao = al[16 * a + l15];                       // a < 16 MTA: inside the alpha tiles (zero beyond c)
+              p1 = __builtin_amdgcn_mfma_f64_16x16x4f64((a < nA) ? xo : 0.0, ao, p1, 0, 0, 0);
+            }
+            static_for<4>([&](auto j) __attribute__((always_inline)) {
+              Pt[(16 * (mt - m0) + l4 + 4 * j()) * 17 + l15] = p1[j()];
+            });
+          }
+          __syncthreads();
+          static_for<NE>([&](auto e) __attribute__((always_inline)) {
+            const int rho = tid + e * NTHR;
+            if (rho < r) {
+              double sacc = g[e()];
+#pragma unroll
+              for (int b = 0; b < 16; ++b) {
+                const int lm = nch * b + rho - 16 * m0;
+                if (lm >= 0 && lm < 16 * (m1 - m0)) sacc += Pt[lm * 17 + b];
+              }
+              g[e()] = sacc;
+            }
+          });
+          __syncthreads();
+        }
+        double rmx = 0.0, tmx = 0.0;
+        static_for<NE>([&](auto e) __attribute__((always_inline)) {
+          const int rho = tid + e * NTHR;
+          if (rho < r) {
+            const int s_act = act[rho];
+            const double D = s_act ? cD1[rho] : cD0[rho];
+            const double t = cT[rho] + s_act * P.bound;
+            double db = D * beta[rho];
+            if (P.dense_w) {
+              const double* dr = P.dmat + (long long)rho * RP;
+              for (int j = 0; j < r; ++j) db = fma(dr[j], beta[j], db);
+            }
+            const double rv = t - g[e()] - P.lam * db;
+            rmx = fmax(rmx, (rv == rv) ? fabs(rv) : 1e300);             // NaN (failed pivot) counts as "large"
+            tmx = fmax(tmx, fabs(t));
+          }
+        });
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { rmx = fmax(rmx, __shfl_xor(rmx, off, 64)); tmx = fmax(tmx, __shfl_xor(tmx, off, 64)); }
+        if (lane == 0) { red[tid >> 6] = rmx; red[8 + (tid >> 6)] = tmx; }
+        __syncthreads();
+        double rall = 0.0, tall = 0.0;
+        for (int w = 0; w < W; ++w) { rall = fmax(rall, red[w]); tall = fmax(tall, red[8 + w]); }
+        const double res = rall / fmax(tall, 1e-300);
+        flag = !(res <= P.refine_res) ? P.epoch : 0;
+        if (stamps != nullptr && tid == 0) stamps[12] = (unsigned long long)__double_as_longlong(res);      // diagnostics
+        __syncthreads();                                                // red[] is reused by the output stage
+      }
+      if (tid == 0) {
+        // epoch stamps instead of counts: nothing has to be cleared between launches (P.epoch grows by one per launch)
+        *refine_flag = flag;
+        if (flag && refine_count != nullptr) atomicMax(refine_count, P.epoch);
+      }
+    }
+  }
+
   // ---- outputs: z = t - lam*D*beta; cost = control cost + lam*beta'z + lamb_sigma*|sigma|^2 ----------------------
   double partc = 0.0;
   bool finite = true;
@@ -1023,7 +1150,7 @@ __global__ __launch_bounds__(64 * W, DDMPC_MIN_WAVES(NT, W)) void ddmpc_cold_sol
   if (only != nullptr && only[b] == 0) continue;
   unsigned long long* st = stamps ? stamps + b * 16 : nullptr;
   if (st && tid == 0) { st[0] = __builtin_amdgcn_s_memtime(); st[15] = __builtin_amdgcn_s_memrealtime(); }
-  double* xs = sm + Lds2<NT>::xs;
+  double* xs = sm + Lds2<NT, W>::xs;
   // component tables (L2) and past window: independent loads, issued BEFORE the trajectory staging so that the three
   // global round trips of the prologue (tables -> past-window gather -> trajectory) overlap instead of following each other
   constexpr int RPk = 16 * NT;
@@ -1074,9 +1201,9 @@ __global__ __launch_bounds__(64 * W, DDMPC_MIN_WAVES(NT, W)) void ddmpc_cold_sol
     for (int i = P.N * P.nch + tid; i < P.xs_len; i += NTHR) xs[i] = 0.0;
   }
   {
-    double* cD0 = sm + Lds2<NT>::cd0; double* cD1 = sm + Lds2<NT>::cd1; double* cT = sm + Lds2<NT>::ct0;
-    int* cK = reinterpret_cast<int*>(sm + Lds2<NT>::ckk); int* cP = reinterpret_cast<int*>(sm + Lds2<NT>::cpp);
-    double* pastw = sm + Lds2<NT>::pastw;
+    double* cD0 = sm + Lds2<NT, W>::cd0; double* cD1 = sm + Lds2<NT, W>::cd1; double* cT = sm + Lds2<NT, W>::ct0;
+    int* cK = reinterpret_cast<int*>(sm + Lds2<NT, W>::ckk); int* cP = reinterpret_cast<int*>(sm + Lds2<NT, W>::cpp);
+    double* pastw = sm + Lds2<NT, W>::pastw;
     static_for<NEk>([&](auto e) __attribute__((always_inline)) {
       const int rho = tid + e * NTHR;
       if (rho < RPk) { cD0[rho] = tD0[e()]; cD1[rho] = tD1[e()]; cT[rho] = tTb[e()]; cK[rho] = tK[e()]; cP[rho] = tP[e()]; }

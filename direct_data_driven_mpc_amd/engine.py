@@ -235,15 +235,15 @@ class BatchedDDMPC:
         """'auto' | 'cold' | 'warm' (DDMPC_OPT_CLOSED_LOOP_PATH)."""
         L.check(self._lib.ddmpc_set_option(self._h, L.OPT_CLOSED_LOOP_PATH, {"auto": 0, "cold": 1, "warm": 2}[path]))
 
-    def set_refinement(self, mode: str = "auto", max_passes: Optional[int] = None, cond_log10: Optional[float] = None) -> None:
+    def set_refinement(self, mode: str = "auto", max_passes: Optional[int] = None, res_log10: Optional[float] = None) -> None:
         """Iterative refinement of the cold solve with exact Hankel products (DDMPC_OPT_REFINE): 'off' | 'auto' |
-        'always'; `cond_log10`: auto mode refines when the pivots bound cond(K) from below by more than 10^cond_log10
-        (resolution 0.1; default 6.3)."""
+        'always'; `res_log10`: auto mode re-solves an instance with refinement when the relative exact-Hankel residual of
+        its plain solve exceeds 10^res_log10 (resolution 0.1; default -10.7)."""
         L.check(self._lib.ddmpc_set_option(self._h, L.OPT_REFINE, {"off": L.REFINE_OFF, "auto": L.REFINE_AUTO, "always": L.REFINE_ALWAYS}[mode]))
         if max_passes is not None:
             L.check(self._lib.ddmpc_set_option(self._h, L.OPT_REFINE_MAX, int(max_passes)))
-        if cond_log10 is not None:
-            L.check(self._lib.ddmpc_set_option(self._h, L.OPT_REFINE_COND_LOG10, int(round(10 * cond_log10))))
+        if res_log10 is not None:
+            L.check(self._lib.ddmpc_set_option(self._h, L.OPT_REFINE_RES_LOG10, int(round(-10 * res_log10))))
 
     def closed_loop(self, A, B, Cm, D, x0, u_past, y_past, w, n_mpc_step: int = 1):
         """Batched closed loop on the device (controller_operation.py:259-305 for every instance).

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DDMPC_ABI_VERSION 1
+#define DDMPC_ABI_VERSION 2
 
 /* return codes */
 #define DDMPC_OK                 0
@@ -91,7 +91,8 @@ extern "C" {
 
 #define DDMPC_OPT_REFINE 3            /* iterative refinement of the cold solve with exact Hankel products (residual
                                          t - (H(H'beta) + lam D beta) from the trajectory, correction through the factor at hand):
-                                         0 off, 1 auto (default: only when the pivots indicate an ill-conditioned system),
+                                         0 off, 1 auto (default: every solve is checked with that residual, relative to |t|,
+                                         and only the instances above the threshold are solved again with refinement),
                                          2 always.  Passes repeat until the correction is at rounding level or stops shrinking.
                                          ddmpc_prepare forms the affine law of ddmpc_step from refining solves as well
                                          (n(m+p)+1 launches, once per data set): with 2 for every instance, with 1 for the
@@ -100,8 +101,10 @@ extern "C" {
 #define DDMPC_REFINE_AUTO 1
 #define DDMPC_REFINE_ALWAYS 2
 #define DDMPC_OPT_REFINE_MAX 4        /* cap on refinement passes per factorisation (default 3) */
-#define DDMPC_OPT_REFINE_COND_LOG10 5 /* auto mode: refine when max K_kk * max 1/d_k (pivots d_k; a lower bound of cond K)
-                                         exceeds 10^(value/10), value in tenths of a decade (default 63: 2e6) */
+#define DDMPC_OPT_REFINE_RES_LOG10 5  /* auto mode: refine when |t - (H(H'beta) + lam D beta)|_inf / |t|_inf exceeds
+                                         10^(-value/10), value in tenths of a decade below 1 (default DDMPC_REFINE_RES_DEFAULT;
+                                         3000 refines everything, 0 only what comes out non-finite) */
+#define DDMPC_REFINE_RES_DEFAULT 107  /* 2e-11: benchmark data stays below ~2e-12, the parity bars are missed from ~1.3e-10 on */
 
 typedef struct ddmpc_handle ddmpc_handle;
 
@@ -149,7 +152,11 @@ int ddmpc_set_stream(ddmpc_handle* h, void* hip_stream);
 int ddmpc_synchronize(ddmpc_handle* h);
 
 /* Per-instance data trajectories u_d [batch,N,m], y_d [batch,N,p]
- * (controller.py:177-179).  HOST: copied; DEVICE: borrowed, must stay valid. */
+ * (controller.py:177-179).  HOST: copied.  DEVICE: borrowed -- the buffers must stay valid for as long as the handle
+ * uses them.  Their CONTENTS may be rewritten in place between calls: ddmpc_solve / ddmpc_closed_loop with the cold
+ * path read the trajectories anew in every call and keep nothing derived from them.  What IS derived from the data and
+ * kept is the affine law of the warm path (ddmpc_prepare, ddmpc_step, ddmpc_get_gain, the warm closed loop): after
+ * rewriting borrowed data call ddmpc_set_data again (it only re-registers the pointers and drops the law). */
 int ddmpc_set_data(ddmpc_handle* h, const double* u_d, const double* y_d, int mem);
 
 /* One control step for every instance = update_and_solve_data_driven_mpc +

@@ -56,3 +56,17 @@ def test_two_rank_shard_and_gather_matches_single_process():
     u, c, s = _solve_block(0, TOTAL)
     assert gu.shape == (TOTAL, 20)
     assert np.array_equal(gu, u.numpy()) and np.array_equal(gc, c.numpy()) and np.array_equal(gs, s.numpy())
+
+
+def test_bench_batch_defaults_name_the_baseline_configs():
+    # bench.py: --gpus 1 is BASELINE configs[1] (4096 on one GPU); --gpus N > 1 without --batch-per-gpu is configs[2]'s
+    # sharding, 32,768 per GPU = 262,144 over 8 -- what the driver's N = 2, 4, 8 runs measure
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.default_batch_per_gpu(1) == 4096
+    assert [mod.default_batch_per_gpu(g) * g for g in (2, 4, 8)] == [65536, 131072, 262144]
+    from direct_data_driven_mpc_amd.distributed import shard_bounds
+    assert shard_bounds(262144, 5, 8) == (5 * 32768, 6 * 32768)

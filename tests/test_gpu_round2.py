@@ -175,6 +175,29 @@ def test_bench_self_launches_two_ranks_and_gathers_bit_exactly(gpu, tmp_path):
     assert bad.returncode != 0 and "does not match WORLD_SIZE" in (bad.stderr + bad.stdout)
 
 
+def test_bench_rccl_branch_at_world_size_one(gpu, tmp_path):
+    # The branch an N-GPU run takes -- init_process_group("nccl", device_id=...), barrier(device_ids=...), the packed
+    # all_gather_into_tensor on DEVICE tensors (RCCL), all_reduce(MAX) of the step time -- executed on this one-GPU box:
+    # `bench.py --gpus 1 --force-dist` starts one rank through torch.distributed.run before anything touches the GPU.
+    # Its gathered block must equal the plain single-process run bit for bit.
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    gd, gp = tmp_path / "gd.npz", tmp_path / "gp.npz"
+    common = ["--gpus", "1", "--batch-per-gpu", "160", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-warm"]
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--dump-gathered", str(gd)] + common,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    rec = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["config"]["global_batch"] == 160 and rec["config"]["non_optimal_instances"] == 0
+    assert "RCCL branch forced" in rec["config"]["parallelism"]
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dump-gathered", str(gp)] + common,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    a, b = np.load(gd), np.load(gp)
+    assert a["u"].shape == (160, 60)
+    assert np.array_equal(a["u"], b["u"]) and np.array_equal(a["cost"], b["cost"]) and np.array_equal(a["status"], b["status"])
+
+
 # ------------------------------------------------------------------ nominal rescue behind every entry point
 def _exact_nominal(B=6):
     from direct_data_driven_mpc_amd.harness import FOUR_TANK, generate_batch
@@ -209,7 +232,7 @@ def test_pipelined_host_solve_runs_the_nominal_rescue(gpu):
 
 def test_variables_after_a_rescued_nominal_solve(gpu):
     # .ubar/.ybar after an exact-data nominal solve come from the rescue kernel's own z (not from the failed fast
-    # path's workspace); alpha is not formed by that kernel -> NaN, never garbage
+    # path's workspace); alpha = H' x from the vector x the kernel exports (z = H H' x): H alpha reproduces [ubar; ybar]
     from oracle.nominal_exact import solve_nominal_exact
     B = 4
     spec, d, up, yp = _exact_nominal(B)
@@ -224,10 +247,13 @@ def test_variables_after_a_rescued_nominal_solve(gpu):
     assert np.array_equal(ub[:, n * m:], u) and np.array_equal(ub2[:, n * m:], uw)
     assert np.array_equal(ub[:, :n * m], up) and np.array_equal(yb[:, :n * p], yp)             # internal-state constraint
     assert np.allclose(yb[:, Lh * p:], np.tile(spec.y_s, n), atol=1e-12)                      # terminal constraint
-    assert np.all(np.isnan(al))
+    assert al.shape == (B, 400 - spec.Ln + 1) and np.all(np.isfinite(al))
     for b in range(B):
         ref = solve_nominal_exact(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
         assert np.max(np.abs(ub[b, n * m:] - ref["optimal_u"])) / np.max(np.abs(ref["optimal_u"])) < 1e-8
+        Hu, Hy = orc.hankel_matrix(d["u_d"][b], spec.Ln), orc.hankel_matrix(d["y_d"][b], spec.Ln)
+        sc = max(np.max(np.abs(ub[b])), np.max(np.abs(yb[b])))
+        assert np.max(np.abs(Hu @ al[b] - ub[b])) < 1e-7 * sc and np.max(np.abs(Hy @ al[b] - yb[b])) < 1e-7 * sc
     # a noisy (full-rank) nominal batch right afterwards on the same handle: fast path, alpha is real again
     dn = harness.generate_batch(range(B))
     with _spec_engine(orc.spec_from_params(controller_type=0), 400, B) as eng:
@@ -258,8 +284,8 @@ def test_set_stream_is_idempotent_and_orders_streams(gpu):
 
 # ------------------------------------------------------------------ refinement with exact Hankel products (cold kernel)
 def test_auto_refinement_flags_ill_conditioned_instances_only(gpu):
-    # default (DDMPC_REFINE_AUTO): the plain kernel flags instances whose pivots bound cond(K) from below by more than
-    # the threshold and only those are solved again by the refining variant.  Benchmark data: nothing flagged, results
+    # default (DDMPC_REFINE_AUTO): the plain kernel checks every solve with the exact-Hankel residual, flags the instances
+    # above the threshold and only those are solved again by the refining variant.  Benchmark data: nothing flagged, results
     # bit-equal to refinement OFF.  An ill-conditioned plant (random, high output gain against the noise level): AUTO
     # equals ALWAYS and meets the standard bars, OFF does not.
     import test_gpu_parity as T
@@ -274,7 +300,7 @@ def test_auto_refinement_flags_ill_conditioned_instances_only(gpu):
         eng.set_refinement("always"); u2, c2, s2, _ = (x.copy() for x in eng.solve(up, yp))
     assert np.array_equal(u0, u1) and np.array_equal(c0, c1)
     assert np.max(np.abs(u2 - u0)) / np.max(np.abs(u0)) < 1e-10           # well-conditioned: refinement changes nothing visible
-    rng = np.random.default_rng(1017)                                       # case 17 of the random-plant sweep: cond_lb ~ 2e7
+    rng = np.random.default_rng(1017)                                       # case 17 of the random-plant sweep: cond(K) ~ 2e7
     m, p, ns = 2, 3, 4
     plant = T._random_plant(np.random.default_rng(1017), ns, m, p, 0.002)
     Lh, N = 16, 200
@@ -312,56 +338,53 @@ def test_auto_refinement_flags_ill_conditioned_instances_only(gpu):
 
 
 @pytest.mark.gpu
-def test_auto_refinement_decision_is_kept_per_data_set(gpu):
-    # without the slack box the AUTO flags depend on the data only, so the first solve's answer is kept: later solves are
-    # one launch (nothing flagged) or plain + filtered refining launch on the recorded flags.  Results must not depend on
-    # which of the paths ran, a changed past window must be honoured, and new data must void the recorded answer.
+def test_auto_refinement_is_decided_per_solve_and_borrowed_data_may_change_in_place(gpu):
+    # AUTO keeps nothing about a data set: every solve is checked with its own exact-Hankel residual.  Device trajectories are
+    # borrowed (include/ddmpc.h, ddmpc_set_data): rewriting them in place between two ddmpc_solve calls -- benign data first,
+    # then data whose Gram route misses the bars -- must give exactly what a fresh handle gives on the new contents.
     import torch
     import test_gpu_parity as T
     rng = np.random.default_rng(1017)
     m, p, ns = 2, 3, 4
     plant = T._random_plant(np.random.default_rng(1017), ns, m, p, 0.002)      # ill-conditioned: every instance gets flagged
+    benign = dict(plant); benign["C"] = 0.02 * plant["C"]; benign["eps_max"] = 0.002   # output gain ~ noise level: cond(H) small
     Lh, N, B = 16, 200, 6
     spec = orc.QPSpec(n=ns, m=m, p=p, L=Lh, Q=2.0 * np.eye(p * Lh), R=0.05 * np.eye(m * Lh), u_s=rng.uniform(-0.5, 0.5, m),
                       y_s=rng.uniform(-0.5, 0.5, p), robust=True, eps_max=0.002, lamb_alpha=20.0, lamb_sigma=500.0, c=1.0,
                       slack="none", tec=True)
-    d = harness.generate_batch(range(170, 170 + B), N=N, plant=plant)
-    d2 = harness.generate_batch(range(270, 270 + B), N=N, plant=plant)
-    up = d["u_d"][:, -ns:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -ns:, :].reshape(B, -1).copy()
-    up2 = d2["u_d"][:, -ns:, :].reshape(B, -1).copy(); yp2 = d2["y_d"][:, -ns:, :].reshape(B, -1).copy()
+    d_ill = harness.generate_batch(range(170, 170 + B), N=N, plant=plant)
+    d_ok = harness.generate_batch(range(270, 270 + B), N=N, plant=benign)
+    dev = torch.device("cuda", 0)
+
+    def past(d):
+        return d["u_d"][:, -ns:, :].reshape(B, -1).copy(), d["y_d"][:, -ns:, :].reshape(B, -1).copy()
+
+    def fresh(d, mode):
+        with _spec_engine(spec, N, B) as e2:
+            e2.set_refinement(mode)
+            e2.set_data(d["u_d"], d["y_d"])
+            return tuple(x.copy() for x in e2.solve(*past(d)))
+
+    ud = torch.from_numpy(d_ok["u_d"]).to(dev); yd = torch.from_numpy(d_ok["y_d"]).to(dev)
     with _spec_engine(spec, N, B) as eng:
-        eng.set_data(d["u_d"], d["y_d"])
-        runs = []
-        for k in range(4):                                    # 1st: flags recorded; later ones: recorded flags reused
-            runs.append(tuple(x.copy() for x in eng.solve(up, yp)))
-            torch.cuda.synchronize()
-        for r in runs[1:]:
-            assert np.array_equal(r[0], runs[0][0]) and np.array_equal(r[1], runs[0][1]) and np.array_equal(r[2], runs[0][2])
-        eng.set_refinement("always"); ref = tuple(x.copy() for x in eng.solve(up, yp))
-        assert np.max(np.abs(runs[0][0] - ref[0])) <= 1e-12 * np.max(np.abs(ref[0]))        # flagged instances were refined
-        eng.set_refinement("auto")
-        a_other = tuple(x.copy() for x in eng.solve(up2, yp2)); torch.cuda.synchronize()     # another past window, same data
-        b_other = tuple(x.copy() for x in eng.solve(up2, yp2))
-        eng.set_refinement("always"); r_other = eng.solve(up2, yp2)[0].copy()
-        assert np.array_equal(a_other[0], b_other[0]) and np.max(np.abs(a_other[0] - r_other)) <= 1e-12 * np.max(np.abs(r_other))
-    # benchmark data: nothing flagged -> every solve equals refinement OFF bit for bit, before and after the answer is known
-    specb = orc.spec_from_params()
-    Bb = 8
-    db = harness.generate_batch(range(Bb))
-    upb = db["u_d"][:, -4:, :].reshape(Bb, -1).copy(); ypb = db["y_d"][:, -4:, :].reshape(Bb, -1).copy()
-    with _spec_engine(specb, 400, Bb) as eng:
-        eng.set_data(db["u_d"], db["y_d"])
-        autos = []
-        for k in range(3):
-            autos.append(tuple(x.copy() for x in eng.solve(upb, ypb))); torch.cuda.synchronize()
-        eng.set_refinement("off"); off = eng.solve(upb, ypb)
-        for r in autos:
-            assert np.array_equal(r[0], off[0]) and np.array_equal(r[1], off[1])
-        # new (ill-scaled) data in the same handle: the recorded "nothing flagged" must not survive ddmpc_set_data
-        eng.set_refinement("auto")
-        eng.set_data(db["u_d"][::-1].copy(), db["y_d"][::-1].copy())
-        x1 = eng.solve(upb[::-1].copy(), ypb[::-1].copy())[0].copy()
-        assert np.array_equal(x1, autos[0][0][::-1])
+        eng.set_data(ud, yd)                                            # borrowed device tensors
+        r_ok = tuple(x.copy() for x in eng.solve(*past(d_ok)))
+        off_ok = fresh(d_ok, "off")
+        assert np.array_equal(r_ok[0], off_ok[0]) and np.array_equal(r_ok[1], off_ok[1])        # benign data: nothing flagged
+        ud.copy_(torch.from_numpy(d_ill["u_d"])); yd.copy_(torch.from_numpy(d_ill["y_d"]))      # in place, no ddmpc_set_data
+        torch.cuda.synchronize()
+        r_ill = tuple(x.copy() for x in eng.solve(*past(d_ill)))
+        again = tuple(x.copy() for x in eng.solve(*past(d_ill)))
+    auto_ill, always_ill, off_ill = fresh(d_ill, "auto"), fresh(d_ill, "always"), fresh(d_ill, "off")
+    assert np.array_equal(r_ill[0], auto_ill[0]) and np.array_equal(r_ill[1], auto_ill[1]) and np.array_equal(r_ill[2], auto_ill[2])
+    assert np.array_equal(r_ill[0], again[0]) and np.array_equal(r_ill[1], again[1])
+    scale = np.max(np.abs(always_ill[0]))
+    assert np.max(np.abs(r_ill[0] - always_ill[0])) <= 1e-12 * scale                            # the flagged instances were refined
+    assert np.max(np.abs(off_ill[0] - always_ill[0])) > 1e-10 * scale                           # ... and needed it
+    for b in range(B):
+        sol = orc.solve_fullspace(spec, d_ill["u_d"][b], d_ill["y_d"][b], past(d_ill)[0][b], past(d_ill)[1][b])
+        assert np.max(np.abs(r_ill[0][b] - sol.optimal_u)) / np.max(np.abs(sol.optimal_u)) < TOL_U
+        assert abs(r_ill[1][b] - sol.cost) <= TOL_COST * abs(sol.cost)
 
 
 @pytest.mark.gpu

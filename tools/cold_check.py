@@ -35,7 +35,7 @@ def parity(tag, B, N=400, **kw):
             uw, cw, sw, _ = eng.step(up, yp)
             print("    warm step vs cold: %.2e" % (np.max(np.abs(uw - u)) / np.max(np.abs(u))))
 
-def timing(B=4096, slack=0, stamps=True):
+def timing(B=4096, slack=0, stamps=True, refine="auto"):
     cfg = controller_params(dict(slack_var_constraint_type=slack))
     spec = orc.spec_from_params(slack_var_constraint_type=slack)
     d = generate_batch(range(B))
@@ -44,6 +44,7 @@ def timing(B=4096, slack=0, stamps=True):
     up = torch.from_numpy(d["u_d"][:, -4:, :].reshape(B, -1).copy()).to(dev)
     yp = torch.from_numpy(d["y_d"][:, -4:, :].reshape(B, -1).copy()).to(dev)
     with engine(spec, 400, B) as eng:
+        eng.set_refinement(refine)
         eng.set_data(ud, yd)
         out = eng.solve(up, yp)
         for _ in range(5): eng.solve(up, yp, *out)
@@ -67,20 +68,11 @@ def timing(B=4096, slack=0, stamps=True):
             print("   chol %-30s median %8.0f cycles (sum over steps, wave 0)" % (nm, np.median(st[:, 7 + i])))
 
 if __name__ == "__main__":
-    import os
     if len(sys.argv) > 1 and sys.argv[1] == "ref":         # refinement modes, in-process
         for rep in range(3):
-            for ref in ("0", "1"):
-                os.environ["DDMPC_REFINE"] = ref
-                print("DDMPC_REFINE=%s" % ref, end="  ")
-                timing(4096, 0, stamps=False)
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "gen":         # in-process A/B of the kernel generations (v1 = the clock reference of the box)
-        for rep in range(3):
-            for gen, ref in (("1", "0"), ("2", "0"), ("2", "1"), ("2", "2")):
-                os.environ["DDMPC_KERNEL"] = gen; os.environ["DDMPC_REFINE"] = ref
-                print("DDMPC_KERNEL=%s DDMPC_REFINE=%s" % (gen, ref), end="  ")
-                timing(4096, 0, stamps=False)
+            for ref in ("off", "auto", "always"):
+                print("refine=%-6s" % ref, end="  ")
+                timing(4096, 0, stamps=False, refine=ref)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "occ":         # phase stamps at 1, 2 and 3 workgroups per CU
         for B in (256, 512, 768, 4096):

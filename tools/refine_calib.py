@@ -1,14 +1,16 @@
-"""Dev tool: conditioning estimate (max K_kk * max 1/d_k from the pivots) and the effect of refinement passes,
-on the benchmark data and on the seeded random-plant sweep of tests/test_gpu_parity.py."""
+"""Dev tool: the AUTO refinement trigger (relative exact-Hankel residual of the plain solve, read from the kernel's
+diagnostic stamp) and the effect of refinement, on the benchmark data and on the seeded random-plant sweep of
+tests/test_gpu_parity.py: per case the errors with refinement off / auto (default threshold) / always."""
 import sys
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import test_gpu_parity as T
 from direct_data_driven_mpc_amd import _lib as L
 from oracle import ddmpc_oracle as orc
+DEFAULT = -10.7
 
-def run(eng, up, yp, mode, cond=None):
-    eng.set_refinement(mode, cond_log10=cond)
+def run(eng, up, yp, mode, res=None):
+    eng.set_refinement(mode, res_log10=res)
     eng.debug_stamps(True)
     u, c, s, it = eng.solve(up, yp)
     st = eng.debug_stamps(False, fetch=True)
@@ -31,9 +33,9 @@ for kw in (dict(), dict(slack_var_constraint_type=1), dict(tec=False)):
     d = dict(u_d=u_d, y_d=y_d)
     with T._engine(spec, 400, B) as eng:
         eng.set_data(u_d, y_d)
-        u0, c0, s0, est = run(eng, up, yp, "auto", 300)
+        u0, c0, s0, est = run(eng, up, yp, "auto", 0.0)
         u2, c2, s2, _ = run(eng, up, yp, "always")
-    print("four-tank %-36s cond_lb min %.2e max %.2e   err off %.1e/%.1e   always %.1e/%.1e" % (
+    print("four-tank %-36s res min %.2e max %.2e   err off %.1e/%.1e   always %.1e/%.1e" % (
         kw, est.min(), est.max(), *errs(spec, d, up, yp, u0[:8], c0[:8]), *errs(spec, d, up, yp, u2[:8], c2[:8])), flush=True)
 
 # the random-plant sweep: rebuild each case's inputs the way the test does
@@ -52,15 +54,15 @@ for case in range(ncases):
     try:
         with T._engine(spec, N, B) as eng:
             eng.set_data(d["u_d"], d["y_d"])
-            u0, c0, s0, est = run(eng, up, yp, "auto", 300)
-            u1, c1, s1, _ = run(eng, up, yp, "auto", 6.3)
+            u0, c0, s0, est = run(eng, up, yp, "auto", 0.0)
+            u1, c1, s1, _ = run(eng, up, yp, "auto", DEFAULT)
             u2, c2, s2, _ = run(eng, up, yp, "always")
             name = eng.kernel_name()
     except L.DDMPCError as e:
         print("case %3d rejected: %s" % (case, str(e)[:80])); continue
     e0, e1, e2 = errs(spec, d, up, yp, u0, c0), errs(spec, d, up, yp, u1, c1), errs(spec, d, up, yp, u2, c2)
     worst_off = max(worst_off, e0[0]); worst_on = max(worst_on, e1[0])
-    print("case %3d %-28s r=%3d robust=%d slack=%-6s cond_lb %.1e..%.1e  off %.1e/%.1e  auto %.1e/%.1e  always %.1e/%.1e%s" % (
+    print("case %3d %-28s r=%3d robust=%d slack=%-6s res %.1e..%.1e  off %.1e/%.1e  auto %.1e/%.1e  always %.1e/%.1e%s" % (
         case, name, (spec.m + spec.p) * (spec.L + spec.n), spec.robust, spec.slack, est.min(), est.max(), *e0, *e1, *e2,
         "   <-- over 1e-8" if e1[0] > 1e-8 or e1[1] > 1e-9 else ""), flush=True)
 print("worst u error: off %.2e, auto %.2e" % (worst_off, worst_on))

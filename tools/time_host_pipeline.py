@@ -1,5 +1,5 @@
 """Dev tool: PCIe-inclusive time of one batch from host pointers -- ddmpc_solve_from_host (chunked upload on a copy stream
-overlapped with the solves) against ddmpc_set_data + ddmpc_solve, for both kernel generations, in one process."""
+overlapped with the solves) against ddmpc_set_data + ddmpc_solve, per refinement mode, in one process."""
 import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -11,15 +11,15 @@ B = 4096
 cfg = controller_params()
 d = generate_batch(range(B))
 up = d["u_d"][:, -4:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -4:, :].reshape(B, -1).copy()
-for gen, ref in (("1", "0"), ("2", "0"), ("2", "1"), ("2", "0"), ("1", "0")):
-    os.environ["DDMPC_KERNEL"] = gen; os.environ["DDMPC_REFINE"] = ref
+for ref in ("off", "auto", "off", "auto"):
     eng = BatchedDDMPC(n=4, m=2, p=2, L_=30, N=400, Q=cfg["Q"], R=cfg["R"], u_s=cfg["u_s"], y_s=cfg["y_s"], batch=B,
                        controller_type=L.ROBUST, slack_type=L.SLACK_NONE, eps_max=cfg["eps_max"], lamb_alpha=cfg["lamb_alpha"],
                        lamb_sigma=cfg["lamb_sigma"], c=cfg["c"])
+    eng.set_refinement(ref)
     eng.solve_from_host(d["u_d"], d["y_d"], up, yp)
     ts = []
     for _ in range(8):
         t0 = time.perf_counter(); eng.solve_from_host(d["u_d"], d["y_d"], up, yp); ts.append(time.perf_counter() - t0)
     t0 = time.perf_counter(); eng.set_data(d["u_d"], d["y_d"]); eng.solve(up, yp); t1 = time.perf_counter() - t0
-    print("KERNEL=%s REFINE=%s pipelined: %s ms; set_data+solve %.2f ms" % (gen, ref, " ".join("%.2f" % (t * 1e3) for t in ts), t1 * 1e3), flush=True)
+    print("refine=%s pipelined: %s ms; set_data+solve %.2f ms" % (ref, " ".join("%.2f" % (t * 1e3) for t in ts), t1 * 1e3), flush=True)
     eng.close()
