@@ -497,10 +497,11 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
     delete h;
     return fail(DDMPC_ERR_UNSUPPORTED, "past window of n (m+p) = %d entries exceeds the %d the kernel stages", p.n * k.nch, h->kc.max_past);
   }
-  {   // AUTO refinement's residual check keeps alpha (16-column tiles) and at least one 16-row chunk of the second product
-      // in the LDS scratch region; shapes where it does not fit are refined unconditionally
-    const int nA = (k.c + 15) / 16, MTA = (nA + 15) / 16;
-    k.res_fits = (h->kc.scratch - 256 * MTA) / 17 >= 16 ? 1 : 0;
+  {   // AUTO refinement's residual check keeps alpha (c doubles) and, with four channels, at least one chunk of partial
+      // sums (16 per block of four time offsets) in the LDS scratch region; shapes where that does not fit are refined
+      // unconditionally
+    const int cpad = (k.c + 1) & ~1, FB = (k.Ln + 3) / 4;
+    k.res_fits = (h->kc.scratch >= cpad + (k.nch == 4 ? 16 * FB : 0)) ? 1 : 0;
   }
 
   if (hipSetDevice(device) != hipSuccess) { delete h; return fail(DDMPC_ERR_HIP, "hipSetDevice(%d) failed", device); }

@@ -176,17 +176,6 @@ __device__ __forceinline__ const double* lfac_row(const double* __restrict__ Lb,
   return Lb + ((I * (I + 1) / 2 + J) << 8) + ((i & 15) << 4);
 }
 
-// Tile-wise transpose of the exported factor (lfacT tile (I,J) = L(I,J)'), so that the back
-// substitution below also reads contiguous rows.  One workgroup (256 threads) per tile.
-__global__ void ddmpc_transpose_tiles_kernel(const double* __restrict__ in, double* __restrict__ out) {
-  __shared__ double t[16][17];
-  const long long base = (long long)blockIdx.x * 256;
-  const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
-  t[r][c] = in[base + threadIdx.x];
-  __syncthreads();
-  out[base + threadIdx.x] = t[c][r];
-}
-
 // Sum over the 16 lanes of a DPP row (all 16 lanes receive the total): four rotate-and-add steps.
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {

@@ -121,6 +121,19 @@ __device__ __forceinline__ double rows4_total(double v) {
   return __hiloint2double((int)hi2[0], (int)lo2[0]) + __hiloint2double((int)hi2[1], (int)lo2[1]);
 }
 
+// Maximum of one value per lane over the wave (every lane receives it): row rotations, then the two row exchanges.
+__device__ __forceinline__ double wave_max(double v) {
+  v = fmax(v, dpp_mov_f64<0x128>(v));   // row_ror:8
+  v = fmax(v, dpp_mov_f64<0x124>(v));   // row_ror:4
+  v = fmax(v, dpp_mov_f64<0x122>(v));   // row_ror:2
+  v = fmax(v, dpp_mov_f64<0x121>(v));   // row_ror:1
+  const d2 s1 = permlane16_swap_f64(v, v);
+  v = fmax(s1[0], s1[1]);
+  const auto lo2 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+  const auto hi2 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+  return fmax(__hiloint2double((int)hi2[0], (int)lo2[0]), __hiloint2double((int)hi2[1], (int)lo2[1]));
+}
+
 // LDS carve-up (doubles).  Every offset is a compile-time function of (NT, W); the only runtime length is the trajectory
 // region at the end.  The host sizes the launch from the same struct (Lds2<NT, W>::total, ddmpc_api.hip), and every
 // aliasing / capacity assumption the kernel makes is a static_assert here: an overrun is a compile error, not a fault
@@ -137,7 +150,7 @@ struct Lds2 {
   static constexpr int ckk = ct0 + RP;
   static constexpr int PART_LEN = 2 * 16 * W;          // back substitution: 2 x [waves][16] partial sums (alternating rounds)
   static constexpr int part = ckk + (RP + 1) / 2;
-  static constexpr int RED_LEN = 32;                   // block reductions: slots [w], [8 + w], [16 + w], w < W
+  static constexpr int RED_LEN = 34;                   // block reductions: slots [w], [8 + w], [16 + w], [24 + w], w < W; [32]
   static constexpr int red = part + PART_LEN;
   static constexpr int ints = red + RED_LEN;           // int act[RP], int flags[8]
   static constexpr int INTS_LEN = (RP + 8 + 1) / 2;
@@ -161,7 +174,7 @@ struct Lds2 {
   __host__ __device__ static constexpr int total(int xs_len) { return (xs + xs_len + 1) & ~1; }
 
   static_assert(W >= 1 && W <= 8, "red[] keeps 8 per-wave slots per quantity; part[] is sized by W");
-  static_assert(16 + W <= RED_LEN, "red[16 + w] (output stage) must stay inside red[]");
+  static_assert(24 + W <= 32 && RED_LEN >= 33, "red[24 + w] and red[32] (output stage) must stay inside red[]");
   static_assert(pt2 >= ints + INTS_LEN && (pt2 & 1) == 0, "act[RP] + flags[8] end before the in-tile panel; 16-byte aligned");
   static_assert(cpp + (RP + 1) / 2 <= lt16 + LT_LEN, "prologue staging (past window + its index table) must fit inside lt16");
   static_assert(NT * 256 <= PB_LEN, "back substitution keeps the NT inverse diagonal tiles M_J in the panel buffer");
@@ -254,6 +267,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
   int iter = 0;
   int status = 0;
   int tid = tid0;
+  double kmax = 0.0;                 // panel wave: largest diagonal entry of G = H H' (scale of the residual bound of AUTO refinement)
   long long tphF = 0, tphB = 0, tphT = 0, tphA = 0, tphU = 0;
   const bool timing = (stamps != nullptr) && (WAVE == 0);
   auto now = [&]() __attribute__((always_inline)) -> long long { return timing ? (long long)__builtin_amdgcn_s_memtime() : 0; };
@@ -291,7 +305,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
       if constexpr (I == J) {
         static_for<4>([&](auto j) __attribute__((always_inline)) {
           const int gr = 16 * J + l4 + 4 * j;
-          if (gr == gc && gr < r) v[j()] -= P.lam * dvec[gr];
+          if (gr == gc && gr < r) { kmax = fmax(kmax, raw[j()]); v[j()] -= P.lam * dvec[gr]; }
         });
       }
       if (16 * I + 15 >= r) {                             // wave-uniform: tile columns that touch the padding / rhs column
@@ -950,125 +964,9 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
   if (flags[0] != 0) status = 4;
   const int lane = tid & 63;
 
-  // ---- AUTO refinement trigger (plain variant only): a-posteriori check of the solve just finished ------------------
-  //   res = | t - ( H (H' beta) + lam D beta ) |_inf / | t |_inf  with EXACT products with the implicit Hankel matrix.
-  // The Gram route's error (cond(H) squared) shows in this residual, a conditioning estimate read off the pivots does
-  // not tell it apart from harmless ill-conditioning (calibration: tools/auto_flag_calib_cpu.py, tools/refine_calib.py).
-  // Both products run on the matrix pipe as small dense contractions over a re-blocked Hankel operand; columns i = 16a+b:
-  //   alpha[a][b] = sum_k  X[a][k] T[k][b],   X[a][k] = x[16 nch a + k],  T[k][b] = beta[k - nch b]     (k < r + 15 nch)
-  //   P[m][b]     = sum_a  X[a][m] alpha[a][b],                           g[rho]  = sum_b P[nch b + rho][b]
-  // alpha and the rows of P (in chunks) live in the LDS between pt2 and xs, all free behind the factorisation.
-  if constexpr (!REF) {
-    if (refine_flag != nullptr) {                                      // kernel-uniform
-      int flag = 0;
-      if (P.lam != 0.0 && !P.res_fits) flag = P.epoch;                  // the check cannot be staged for this shape: refine
-      if (P.lam != 0.0 && P.res_fits) {
-        const int l15 = lane & 15, l4 = lane >> 4;
-        const int c = P.c;
-        const int nA = (c + 15) >> 4;                                   // a < nA
-        const int MTA = (nA + 15) >> 4;                                 // 16-row tiles of a
-        const int KA = r + 15 * nch;                                    // contraction length of the first product = rows of P
-        const int MTB = (KA + 15) >> 4;
-        const int xlast = P.xs_len - 1;
-        double* al = sm + LD::SCR;                                      // alpha[16 a + b], zero beyond c
-        double* Pt = al + 256 * MTA;                                    // chunk of P: [rows][17]
-        const int TC = ((LD::SCR_LEN - 256 * MTA) / 17) >> 4;           // tiles per chunk (>= 1: P.res_fits)
-        __syncthreads();                                                // beta complete, PB / LT / ctab no longer read
-        for (int mt = WAVE; mt < MTA; mt += W) {
-          d4 a1 = d4{0.0, 0.0, 0.0, 0.0};
-          const int a = 16 * mt + l15;
-          const bool aok = a < nA;
-          const int xa = 16 * nch * a + l4;
-          const int tb = l4 - nch * l15;
-#pragma nounroll
-          for (int k0 = 0; k0 < KA; k0 += 4) {
-            int xi = xa + k0; xi = xi < xlast ? xi : xlast;
-            const double xo = xs[xi];
-            int bi = tb + k0;
-            const bool bok = bi >= 0 && bi < r;
-            bi = bok ? bi : 0;
-            const double bo = beta[bi];
-            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aok ? xo : 0.0, bok ? bo : 0.0, a1, 0, 0, 0);
-          }
-          static_for<4>([&](auto j) __attribute__((always_inline)) {
-            const int i = 256 * mt + 16 * (l4 + 4 * j()) + l15;
-            al[i] = (i < c) ? a1[j()] : 0.0;
-          });
-        }
-        __syncthreads();
-        double g[NE];
-        static_for<NE>([&](auto e) __attribute__((always_inline)) { g[e()] = 0.0; });
-        const int KSB = (nA + 3) >> 2;
-        for (int m0 = 0; m0 < MTB; m0 += TC) {
-          const int m1 = (m0 + TC) < MTB ? (m0 + TC) : MTB;
-          for (int mt = m0 + WAVE; mt < m1; mt += W) {
-            d4 p1 = d4{0.0, 0.0, 0.0, 0.0};
-            const int xm = 16 * mt + l15;
-#pragma nounroll
-            for (int ks = 0; ks < KSB; ++ks) {
-              const int a = 4 * ks + l4;
-              int xi = 16 * nch * a + xm; xi = xi < xlast ? xi : xlast;
-              const double xo = xs[xi];
-              const double ao = al[16 * a + l15];                       // a < 16 MTA: inside the alpha tiles (zero beyond c)
-              p1 = __builtin_amdgcn_mfma_f64_16x16x4f64((a < nA) ? xo : 0.0, ao, p1, 0, 0, 0);
-            }
-            static_for<4>([&](auto j) __attribute__((always_inline)) {
-              Pt[(16 * (mt - m0) + l4 + 4 * j()) * 17 + l15] = p1[j()];
-            });
-          }
-          __syncthreads();
-          static_for<NE>([&](auto e) __attribute__((always_inline)) {
-            const int rho = tid + e * NTHR;
-            if (rho < r) {
-              double sacc = g[e()];
-#pragma unroll
-              for (int b = 0; b < 16; ++b) {
-                const int lm = nch * b + rho - 16 * m0;
-                if (lm >= 0 && lm < 16 * (m1 - m0)) sacc += Pt[lm * 17 + b];
-              }
-              g[e()] = sacc;
-            }
-          });
-          __syncthreads();
-        }
-        double rmx = 0.0, tmx = 0.0;
-        static_for<NE>([&](auto e) __attribute__((always_inline)) {
-          const int rho = tid + e * NTHR;
-          if (rho < r) {
-            const int s_act = act[rho];
-            const double D = s_act ? cD1[rho] : cD0[rho];
-            const double t = cT[rho] + s_act * P.bound;
-            double db = D * beta[rho];
-            if (P.dense_w) {
-              const double* dr = P.dmat + (long long)rho * RP;
-              for (int j = 0; j < r; ++j) db = fma(dr[j], beta[j], db);
-            }
-            const double rv = t - g[e()] - P.lam * db;
-            rmx = fmax(rmx, (rv == rv) ? fabs(rv) : 1e300);             // NaN (failed pivot) counts as "large"
-            tmx = fmax(tmx, fabs(t));
-          }
-        });
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { rmx = fmax(rmx, __shfl_xor(rmx, off, 64)); tmx = fmax(tmx, __shfl_xor(tmx, off, 64)); }
-        if (lane == 0) { red[tid >> 6] = rmx; red[8 + (tid >> 6)] = tmx; }
-        __syncthreads();
-        double rall = 0.0, tall = 0.0;
-        for (int w = 0; w < W; ++w) { rall = fmax(rall, red[w]); tall = fmax(tall, red[8 + w]); }
-        const double res = rall / fmax(tall, 1e-300);
-        flag = !(res <= P.refine_res) ? P.epoch : 0;
-        if (stamps != nullptr && tid == 0) stamps[12] = (unsigned long long)__double_as_longlong(res);      // diagnostics
-        __syncthreads();                                                // red[] is reused by the output stage
-      }
-      if (tid == 0) {
-        // epoch stamps instead of counts: nothing has to be cleared between launches (P.epoch grows by one per launch)
-        *refine_flag = flag;
-        if (flag && refine_count != nullptr) atomicMax(refine_count, P.epoch);
-      }
-    }
-  }
-
   // ---- outputs: z = t - lam*D*beta; cost = control cost + lam*beta'z + lamb_sigma*|sigma|^2 ----------------------
   double partc = 0.0;
+  double bmx = 0.0, tmx = 0.0;                      // max |beta|, max |t|: the residual bound of AUTO refinement
   bool finite = true;
   static_for<NE>([&](auto e) __attribute__((always_inline)) {
     const int rho = tid + e * NTHR;
@@ -1077,6 +975,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
       const double b = beta[rho];
       const double D = s_act ? cD1[rho] : cD0[rho];
       const double t = cT[rho] + s_act * P.bound;
+      bmx = fmax(bmx, fabs(b)); tmx = fmax(tmx, fabs(t));
       double z = t - P.lam * D * b;
       if (P.dense_w) {                              // z = t - lam (W^-1 beta): one row of the dense matrix
         const double* dr = P.dmat + (long long)rho * RP;
@@ -1110,9 +1009,17 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
       if (act_ws) act_ws[rho] = (signed char)s_act;
     }
   });
-  partc = wave_sum(partc);
+  partc = rows4_total(row16_total(partc));
   const unsigned long long okmask = __ballot(finite);
-  if (lane == 0) { red[tid >> 6] = partc; red[16 + (tid >> 6)] = (okmask == ~0ull) ? 0.0 : 1.0; }
+  const bool auto_check = !REF && refine_flag != nullptr && P.lam != 0.0;      // kernel-uniform
+  if (auto_check) {
+    bmx = wave_max(bmx); tmx = wave_max(tmx);
+    if constexpr (WAVE == 0) kmax = wave_max(kmax);
+  }
+  if (lane == 0) {
+    red[tid >> 6] = partc; red[16 + (tid >> 6)] = (okmask == ~0ull) ? 0.0 : 1.0;
+    if (auto_check) { red[8 + (tid >> 6)] = bmx; red[24 + (tid >> 6)] = tmx; if (WAVE == 0) red[32] = kmax; }
+  }
   __syncthreads();
   if (tid == 0) {
     double tot = 0.0, bad = 0.0;
@@ -1121,6 +1028,197 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
     *cost_out = tot;
     *status_out = status;
     if (iters_out) *iters_out = iter;
+  }
+
+  // ---- AUTO refinement trigger (plain variant only): a-posteriori check of the solve just finished ------------------
+  // Two stages.  (i) The a-priori residual bound of the Gram route,  q = eps max G_kk |beta|_inf / |t|_inf  (the solve's
+  // residual is E beta with |E| ~ eps |G|: rounding of the Gram sums and of the factorisation), from maxima the output
+  // stage collected on its way.  On the calibration sweep (profiles/r03_refine_calib.log: 72 robust random-plant cases + the
+  // benchmark batch) the true residual is 0.1 .. 10 times q wherever q <= 1e-12 and at most ~50 times q anywhere, so q is
+  // only used to DISMISS: an instance with q <= threshold / 20 is far below the threshold -- the benchmark's instances
+  // (q <= 9e-13, residual <= 4e-12): nothing more to do.  (ii) Everything else is CHECKED, not guessed:
+  //   res = | t - ( H (H' beta) + lam D beta ) |_inf / | t |_inf  with EXACT products with the implicit Hankel matrix
+  // (a conditioning estimate read off the pivots does not tell the Gram route's error apart from harmless
+  // ill-conditioning: tools/auto_flag_calib_cpu.py, tools/refine_calib.py), and res > threshold flags the instance.
+  // 2 r c multiply-adds on the vector pipe, straight from the trajectory in LDS; with four channels (the benchmark) both
+  // products walk the trajectory in quads x[4 j .. 4 j + 3] (one time step) that slide through registers:
+  //   alpha_i      = sum_f < Q(i + f), beta[4 f ..] >           lane = (4 columns, half of the f range):  16 FMAs per 4 loads
+  //   g[4 f + ch]  = sum_i Q(i + f)[ch] alpha_i                  lane = (4 time offsets, a chunk of i):    16 FMAs per 3 loads
+  // alpha and the per-chunk partial sums live in the LDS between pt2 and xs, all free behind the factorisation.
+  if constexpr (!REF) {
+    if (auto_check) {
+      double kall = red[32], ball = 0.0, tall = 0.0;
+      for (int w = 0; w < W; ++w) { ball = fmax(ball, red[8 + w]); tall = fmax(tall, red[24 + w]); }
+      const double q = 1.1102230246251565e-16 * kall * ball / fmax(tall, 1e-300);
+      int flag = 0;
+      double shown = q;
+      if (!(q <= 0.05 * P.refine_res)) {                                // workgroup-uniform (NaN: checked, and flagged there)
+        if (!P.res_fits) flag = P.epoch;                                // the check cannot be staged for this shape: refine
+        else {
+        const int c = P.c;
+          const int xlast = P.xs_len - 1;
+          double* al = sm + LD::SCR;                                      // alpha[i], i < c
+          double* pp = al + ((c + 1) & ~1);                               // nch == 4: partial sums [i-chunk][16 FB]
+          double g[NE];
+          static_for<NE>([&](auto e) __attribute__((always_inline)) { g[e()] = 0.0; });
+          __syncthreads();                                                // beta complete, PB / LT / ctab no longer read
+          if (nch == 4) {
+            const d2* xq = reinterpret_cast<const d2*>(xs);               // Q(j) = (xq[2 j], xq[2 j + 1])
+            const d2* bq = reinterpret_cast<const d2*>(beta);
+            const int jmax = (xlast - 3) >> 2;                            // last quad inside the region
+            auto quad = [&](int j, d2& lo2, d2& hi2) __attribute__((always_inline)) {
+              j = j < jmax ? j : jmax;
+              lo2 = xq[2 * j]; hi2 = xq[2 * j + 1];
+            };
+            // (1) alpha
+            {
+              const int Ln = r >> 2;
+              const int Lh = (Ln + 1) >> 1;
+              const int ntask = 2 * ((c + 3) >> 2);
+              for (int t0 = 0; t0 < ntask; t0 += NTHR) {
+                const int task = t0 + tid;
+                const int i0 = 4 * (task >> 1), h = task & 1;
+                const int fa = h ? Lh : 0, fb = h ? Ln : Lh;
+                double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+                d2 q0l, q0h, q1l, q1h, q2l, q2h, q3l, q3h;
+                quad(i0 + fa, q0l, q0h); quad(i0 + fa + 1, q1l, q1h); quad(i0 + fa + 2, q2l, q2h);
+                auto stepA = [&](int f, const d2& al_, const d2& ah_, const d2& bl_, const d2& bh_, const d2& cl_, const d2& ch_,
+                                 d2& nl_, d2& nh_) __attribute__((always_inline)) {
+                  quad(i0 + f + 3, nl_, nh_);
+                  const d2 b0 = bq[2 * f], b1 = bq[2 * f + 1];
+                  acc0 = fma(al_[0], b0[0], acc0); acc0 = fma(al_[1], b0[1], acc0); acc0 = fma(ah_[0], b1[0], acc0); acc0 = fma(ah_[1], b1[1], acc0);
+                  acc1 = fma(bl_[0], b0[0], acc1); acc1 = fma(bl_[1], b0[1], acc1); acc1 = fma(bh_[0], b1[0], acc1); acc1 = fma(bh_[1], b1[1], acc1);
+                  acc2 = fma(cl_[0], b0[0], acc2); acc2 = fma(cl_[1], b0[1], acc2); acc2 = fma(ch_[0], b1[0], acc2); acc2 = fma(ch_[1], b1[1], acc2);
+                  acc3 = fma(nl_[0], b0[0], acc3); acc3 = fma(nl_[1], b0[1], acc3); acc3 = fma(nh_[0], b1[0], acc3); acc3 = fma(nh_[1], b1[1], acc3);
+                };
+                int f = fa;
+#pragma nounroll
+                for (; f + 4 <= fb; f += 4) {                             // the window rotates through the four register quads
+                  stepA(f, q0l, q0h, q1l, q1h, q2l, q2h, q3l, q3h);
+                  stepA(f + 1, q1l, q1h, q2l, q2h, q3l, q3h, q0l, q0h);
+                  stepA(f + 2, q2l, q2h, q3l, q3h, q0l, q0h, q1l, q1h);
+                  stepA(f + 3, q3l, q3h, q0l, q0h, q1l, q1h, q2l, q2h);
+                }
+                if (f < fb) { stepA(f, q0l, q0h, q1l, q1h, q2l, q2h, q3l, q3h); ++f;
+                  if (f < fb) { stepA(f, q1l, q1h, q2l, q2h, q3l, q3h, q0l, q0h); ++f;
+                    if (f < fb) { stepA(f, q2l, q2h, q3l, q3h, q0l, q0h, q1l, q1h); } } }
+                // the two halves of the f range sit in neighbouring lanes
+                acc0 += __shfl_xor(acc0, 1, 64); acc1 += __shfl_xor(acc1, 1, 64);
+                acc2 += __shfl_xor(acc2, 1, 64); acc3 += __shfl_xor(acc3, 1, 64);
+                if (h == 0 && task < ntask) {
+                  if (i0 < c) al[i0] = acc0;
+                  if (i0 + 1 < c) al[i0 + 1] = acc1;
+                  if (i0 + 2 < c) al[i0 + 2] = acc2;
+                  if (i0 + 3 < c) al[i0 + 3] = acc3;
+                }
+              }
+            }
+            __syncthreads();
+            // (2) g: lane = (block of 4 time offsets, chunk of columns); the partial sums of the chunks meet in LDS
+            {
+              const int Ln = r >> 2;
+              const int FB = (Ln + 3) >> 2;                               // blocks of time offsets
+              int NC = NTHR / FB;                                         // column chunks: one task per thread at most,
+              const int ncap = (LD::SCR_LEN - ((c + 1) & ~1)) / (16 * FB);  //   partial sums inside the scratch region (>= 1: P.res_fits)
+              NC = NC < ncap ? NC : ncap;
+              const int CL = (c + NC - 1) / NC;
+              if (tid < FB * NC) {
+                const int fbk = tid / NC, ic = tid - fbk * NC;
+                const int f0 = 4 * fbk;
+                const int ia = ic * CL;
+                const int ib = (ia + CL) < c ? (ia + CL) : c;
+                d2 a0l = d2{0.0, 0.0}, a0h = a0l, a1l = a0l, a1h = a0l, a2l = a0l, a2h = a0l, a3l = a0l, a3h = a0l;
+                d2 q0l, q0h, q1l, q1h, q2l, q2h, q3l, q3h;
+                quad(ia + f0, q0l, q0h); quad(ia + f0 + 1, q1l, q1h); quad(ia + f0 + 2, q2l, q2h);
+                auto stepB = [&](int i, const d2& al_, const d2& ah_, const d2& bl_, const d2& bh_, const d2& cl_, const d2& ch_,
+                                 d2& nl_, d2& nh_) __attribute__((always_inline)) {
+                  quad(i + f0 + 3, nl_, nh_);
+                  const double av = al[i];
+                  a0l[0] = fma(al_[0], av, a0l[0]); a0l[1] = fma(al_[1], av, a0l[1]); a0h[0] = fma(ah_[0], av, a0h[0]); a0h[1] = fma(ah_[1], av, a0h[1]);
+                  a1l[0] = fma(bl_[0], av, a1l[0]); a1l[1] = fma(bl_[1], av, a1l[1]); a1h[0] = fma(bh_[0], av, a1h[0]); a1h[1] = fma(bh_[1], av, a1h[1]);
+                  a2l[0] = fma(cl_[0], av, a2l[0]); a2l[1] = fma(cl_[1], av, a2l[1]); a2h[0] = fma(ch_[0], av, a2h[0]); a2h[1] = fma(ch_[1], av, a2h[1]);
+                  a3l[0] = fma(nl_[0], av, a3l[0]); a3l[1] = fma(nl_[1], av, a3l[1]); a3h[0] = fma(nh_[0], av, a3h[0]); a3h[1] = fma(nh_[1], av, a3h[1]);
+                };
+                int i = ia;
+#pragma nounroll
+                for (; i + 4 <= ib; i += 4) {
+                  stepB(i, q0l, q0h, q1l, q1h, q2l, q2h, q3l, q3h);
+                  stepB(i + 1, q1l, q1h, q2l, q2h, q3l, q3h, q0l, q0h);
+                  stepB(i + 2, q2l, q2h, q3l, q3h, q0l, q0h, q1l, q1h);
+                  stepB(i + 3, q3l, q3h, q0l, q0h, q1l, q1h, q2l, q2h);
+                }
+                if (i < ib) { stepB(i, q0l, q0h, q1l, q1h, q2l, q2h, q3l, q3h); ++i;
+                  if (i < ib) { stepB(i, q1l, q1h, q2l, q2h, q3l, q3h, q0l, q0h); ++i;
+                    if (i < ib) { stepB(i, q2l, q2h, q3l, q3h, q0l, q0h, q1l, q1h); } } }
+                d2* po = reinterpret_cast<d2*>(pp + (ic * FB + fbk) * 16);
+                po[0] = a0l; po[1] = a0h; po[2] = a1l; po[3] = a1h; po[4] = a2l; po[5] = a2h; po[6] = a3l; po[7] = a3h;
+              }
+                __syncthreads();
+              static_for<NE>([&](auto e) __attribute__((always_inline)) {
+                const int rho = tid + e * NTHR;
+                if (rho < r) {
+                  double sacc = 0.0;
+                  for (int ic = 0; ic < NC; ++ic) sacc += pp[ic * FB * 16 + rho];
+                  g[e()] = sacc;
+                }
+              });
+            }
+          } else {
+            // any other channel count: one column per lane, then one row per lane (no operand reuse; these shapes are not
+            // the benchmark's)
+            for (int i = tid; i < c; i += NTHR) {
+              const double* xp = xs + (long long)i * nch;
+              double sacc = 0.0;
+              for (int rho = 0; rho < r; ++rho) sacc = fma(xp[rho], beta[rho], sacc);
+              al[i] = sacc;
+            }
+            __syncthreads();
+            static_for<NE>([&](auto e) __attribute__((always_inline)) {
+              const int rho = tid + e * NTHR;
+              if (rho < r) {
+                const double* xq1 = xs + rho;
+                double sacc = 0.0;
+                for (int i = 0; i < c; ++i) sacc = fma(xq1[(long long)i * nch], al[i], sacc);
+                g[e()] = sacc;
+              }
+            });
+          }
+          double rmx = 0.0;
+          static_for<NE>([&](auto e) __attribute__((always_inline)) {
+            const int rho = tid + e * NTHR;
+            if (rho < r) {
+              const int s_act = act[rho];
+              const double D = s_act ? cD1[rho] : cD0[rho];
+              const double t = cT[rho] + s_act * P.bound;
+              double db = D * beta[rho];
+              if (P.dense_w) {
+                const double* dr = P.dmat + (long long)rho * RP;
+                for (int j = 0; j < r; ++j) db = fma(dr[j], beta[j], db);
+              }
+              const double rv = t - g[e()] - P.lam * db;
+              rmx = fmax(rmx, (rv == rv) ? fabs(rv) : 1e300);           // NaN (failed pivot) counts as "large"
+            }
+          });
+          rmx = wave_max(rmx);
+          __syncthreads();                                              // red[] was read above
+          if (lane == 0) red[8 + (tid >> 6)] = rmx;
+          __syncthreads();
+          double rall = 0.0;
+          for (int w = 0; w < W; ++w) rall = fmax(rall, red[8 + w]);
+          const double res = rall / fmax(tall, 1e-300);
+          flag = !(res <= P.refine_res) ? P.epoch : 0;
+          shown = res;
+        }
+      }
+      if (tid == 0) {
+        // epoch stamps instead of counts: nothing has to be cleared between launches (P.epoch grows by one per launch)
+        *refine_flag = flag;
+        if (flag && refine_count != nullptr) atomicMax(refine_count, P.epoch);
+        if (stamps != nullptr) stamps[12] = (unsigned long long)__double_as_longlong(shown);      // diagnostics: res if checked, else q
+      }
+    }
+  }
+  if (tid == 0) {
     if (stamps) { stamps[14] = __builtin_amdgcn_s_memtime(); stamps[13] = __builtin_amdgcn_s_memrealtime(); }
   }
 }

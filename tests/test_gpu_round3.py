@@ -115,7 +115,9 @@ def test_config5_at_a_quarter_of_its_stated_batch(gpu):
 # ------------------------------------------------------------------ the residual check at the edges of what it can stage
 def test_auto_refinement_where_the_residual_check_does_not_fit(gpu):
     # a short horizon with a long trajectory: the smallest kernel instance (NT = 2) cannot stage alpha (c ~ 1900 entries)
-    # in its LDS scratch, so AUTO refines every instance unconditionally: results equal refinement ALWAYS bit for bit
+    # in its LDS scratch, so an instance whose a-priori bound does not decide is refined unconditionally.  With a threshold
+    # so low that the bound never decides, AUTO must equal refinement ALWAYS bit for bit; with the default threshold every
+    # instance equals either its OFF or its ALWAYS result and meets the parity bars.
     rng = np.random.default_rng(5)
     m = p = 1; ns = n = 2; Lh = 6; N = 1900
     import test_gpu_parity as T
@@ -129,19 +131,21 @@ def test_auto_refinement_where_the_residual_check_does_not_fit(gpu):
     with _spec_engine(spec, N, B) as eng:
         assert "<2,1>" in eng.kernel_name()
         eng.set_data(d["u_d"], d["y_d"])
-        for mode in ("auto", "always"):
-            eng.set_refinement(mode)
-            res[mode] = tuple(x.copy() for x in eng.solve(up, yp))
-    assert np.array_equal(res["auto"][0], res["always"][0]) and np.array_equal(res["auto"][1], res["always"][1])
+        for tag, mode, thr in (("off", "off", None), ("auto", "auto", -10.7), ("auto_low", "auto", -14.0), ("always", "always", None)):
+            eng.set_refinement(mode, res_log10=thr)
+            res[tag] = tuple(x.copy() for x in eng.solve(up, yp))
+    assert np.array_equal(res["auto_low"][0], res["always"][0]) and np.array_equal(res["auto_low"][1], res["always"][1])
     for b in range(B):
+        assert np.array_equal(res["auto"][0][b], res["off"][0][b]) or np.array_equal(res["auto"][0][b], res["always"][0][b])
         sol = orc.solve_fullspace(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
         assert np.max(np.abs(res["auto"][0][b] - sol.optimal_u)) / max(np.max(np.abs(sol.optimal_u)), 1e-3) < TOL_U
         assert abs(res["auto"][1][b] - sol.cost) <= TOL_COST * max(abs(sol.cost), 1e-6)
 
 
 def test_auto_refinement_threshold_extremes(gpu):
-    # DDMPC_OPT_REFINE_RES_LOG10: threshold 1 (value 0) never refines -> equals OFF; threshold 1e-300 (value 3000) refines
-    # everything -> equals ALWAYS; on the benchmark data the default flags nothing -> equals OFF bit for bit
+    # DDMPC_OPT_REFINE_RES_LOG10: threshold 1 (value 0) never refines -> equals OFF; threshold 1e-300 (value 3000): the bound
+    # never decides, every instance is checked exactly and flagged -> equals ALWAYS; on the benchmark data the default flags
+    # nothing (bound or exact check) -> equals OFF bit for bit
     spec = orc.spec_from_params()
     B = 24
     d = harness.generate_batch(range(300, 300 + B))

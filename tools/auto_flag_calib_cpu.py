@@ -56,7 +56,7 @@ for kw in (dict(), dict(tec=False), dict(L=60, N=1000)):
     show("four-tank %s" % kw, [one(spec, u_d[b], y_d[b], up[b], yp[b]) for b in range(6)])
 
 src = inspect.getsource(T.test_random_systems_against_oracle)
-body = src.split("    B = 3\n")[0].split("\n", 2)[2]
+body = src.split("    B = 3\n")[0].split("(gpu, case, refine):\n", 1)[1]
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 for case in range(ncases):
     env = dict(T.__dict__); env["case"] = case

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collect the per-round evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh <tag>         e.g. r02_final
+#   bash tools/collect_profiles.sh <tag>         e.g. r03_final
 # Writes everything under gpurun_out/<tag>/; copy the summaries into profiles/ afterwards.
 # Counter passes are separate runs with --pmc only (no trace domains), as the pool requires.
 set -e -o pipefail
-TAG=${1:-r02_final}
+TAG=${1:-r03_final}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf "$OUT"
@@ -30,6 +30,17 @@ pass write WRITE_SIZE
 pass sq SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES SQ_WAVE_CYCLES
 pass sq2 GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_F64 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 
+# warm step at 32,768 instances (the HBM figure of bench.py's warm_step.roofline): the same bench run WITH its warm section
+passw() {  # name, counters...
+    local name=$1; shift
+    timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_warm_$name" -- \
+        python bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_warm_$name.log" 2>&1
+    echo "[collect] pmc warm $name done"
+}
+passw fetch FETCH_SIZE
+passw write WRITE_SIZE
+timeout -k 10 200 python tools/cold_check.py ref > "$OUT/refine_modes.log" 2>&1
+
 timeout -k 10 120 python tools/phase_stamps.py > "$OUT/phase_stamps.log" 2>&1
 timeout -k 10 300 python tools/bench_configs.py > "$OUT/other_configs.log" 2>&1
 echo "[collect] other configs done"
@@ -53,6 +64,6 @@ timeout -k 10 400 python tools/config5_check.py --check 512 > "$OUT/cfg5_parity.
 timeout -k 10 600 python tools/config5_check.py --robust --check 512 > "$OUT/cfg5size_robust_parity.log" 2>&1
 timeout -k 10 400 python tools/large_fuzz.py --cases 12 > "$OUT/large_kernel_fuzz.log" 2>&1
 echo "[collect] cfg5 done"
-# refinement modes on the benchmark data and on the 96-case random-plant sweep (conditioning estimate, off / auto / always)
+# the AUTO refinement trigger on the benchmark batch and on the 96-case random-plant sweep (bound q, exact residual, off / auto / always)
 timeout -k 10 900 python tools/refine_calib.py 96 > "$OUT/refine_calib.log" 2>&1
 echo "[collect] all done"

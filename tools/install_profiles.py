@@ -11,7 +11,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
 KERNEL = "ddmpc_cold_solve_kernel2"         # bench.py looks traffic up under this name
@@ -32,7 +32,7 @@ shutil.copy(os.path.join(src, "phase_stamps.log"), os.path.join(dst, tag + "_pha
 shutil.copy(os.path.join(src, "other_configs.log"), os.path.join(dst, tag + "_other_configs.log"))
 
 for name in ("cfg5_time.log", "cfg5_phase_stamps.log", "cfg5_parity.log", "cfg5size_robust_parity.log", "large_kernel_fuzz.log",
-             "refine_calib.log"):
+             "refine_calib.log", "refine_modes.log"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, tag.replace("_final", "") + "_" + name))
 if glob.glob(os.path.join(src, "cfg5_stats/*/*_kernel_stats.csv")):
@@ -93,5 +93,26 @@ if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
     path = os.path.join(dst, "traffic.json")
     tab = json.load(open(path)) if os.path.exists(path) else {"entries": []}
     tab["entries"] = [e for e in tab["entries"] if not (e["kernel"] == KERNEL and e["batch"] == entry["batch"] and e.get("slack") == "none")] + [entry]
+    # warm step at 32,768 instances (launches with that many workgroups only: the 4096-instance ones are cache-resident)
+    wt = {}
+    for name in ("fetch", "write"):
+        files = sorted(glob.glob(os.path.join(src, "pmc_warm_%s/*/*_counter_collection.csv" % name)), key=os.path.getmtime)
+        if not files:
+            continue
+        rows = [r for r in csv.DictReader(open(files[-1])) if "ddmpc_warm_step_kernel" in r["Kernel_Name"]
+                and int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1) == 32768]
+        if rows:
+            with open(os.path.join(dst, "%s_warm_step_pmc_%s.csv" % (tag.replace("_final", ""), name)), "w", newline="") as out:
+                wr = csv.DictWriter(out, fieldnames=list(rows[0].keys()))
+                wr.writeheader()
+                wr.writerows(rows)
+            vals = [float(r["Counter_Value"]) for r in rows]
+            wt[rows[0]["Counter_Name"]] = sum(vals) / len(vals)
+    if "FETCH_SIZE" in wt and "WRITE_SIZE" in wt:
+        wentry = dict(kernel="ddmpc_warm_step_kernel", code_hash=b["config"]["kernel_source_hash"], batch=32768, slack="none",
+                      fetch_kb=wt["FETCH_SIZE"], write_kb=wt["WRITE_SIZE"],
+                      traffic_bytes=int((2 * wt["FETCH_SIZE"] + wt["WRITE_SIZE"]) * 1024), source=tag.replace("_final", "") + "_warm_step_pmc_*.csv")
+        tab["entries"] = [e for e in tab["entries"] if e["kernel"] != "ddmpc_warm_step_kernel"] + [wentry]
+        print("traffic.json: ddmpc_warm_step_kernel (32,768 instances) -> %.1f MB per launch" % (wentry["traffic_bytes"] / 1e6))
     json.dump(tab, open(path, "w"), indent=1)
     print("traffic.json: %s -> %.1f MB per launch (hash %s)" % (KERNEL, entry["traffic_bytes"] / 1e6, entry["code_hash"]))

@@ -28,6 +28,7 @@ print("kernel", eng.kernel_name(), "B", B, "gram_mode", gram)
 for i, nm in enumerate(names[:5]):
     col = dt[:, i]
     print("%-38s median %8.0f  p10 %8.0f  p90 %8.0f cycles" % (nm, np.median(col), np.percentile(col, 10), np.percentile(col, 90)))
+print("%-38s median %8.0f cycles" % ("outputs + AUTO refinement trigger", np.median(st[:, 14] - st[:, 6])))
 print("%-16s median %8.0f cycles; real time median %.1f us; clock %.2f GHz" % ("total", np.median(tot), np.median(real) / 1e3, np.median(tot / np.maximum(real, 1))))
 ph = st[:, 7:12]
 for i, nm in enumerate(["chol: panel wave in-tile factorisation (+ its diag updates)", "chol: wait at barrier B", "chol: TRSM (panel wave: none)", "chol: wait at barriers A1+A2", "chol: next-diagonal update"]):

@@ -1,6 +1,10 @@
-"""Dev tool: the AUTO refinement trigger (relative exact-Hankel residual of the plain solve, read from the kernel's
-diagnostic stamp) and the effect of refinement, on the benchmark data and on the seeded random-plant sweep of
-tests/test_gpu_parity.py: per case the errors with refinement off / auto (default threshold) / always."""
+"""Dev tool: the two stages of the AUTO refinement trigger -- q = eps max G_kk |beta|_inf / |t|_inf (the free a-priori bound)
+and res = |t - (H (H' beta) + lam D beta)|_inf / |t|_inf (the exact-Hankel residual), both read from the kernel's
+diagnostic stamp -- and the effect of refinement, on the benchmark data and on the seeded random-plant sweep of
+tests/test_gpu_parity.py: per case q, res, and the errors with refinement off / auto (default threshold) / always.
+
+    python tools/refine_calib.py [ncases]
+"""
 import sys
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -28,20 +32,22 @@ def errs(spec, d, up, yp, u, c):
 # benchmark data
 for kw in (dict(), dict(slack_var_constraint_type=1), dict(tec=False)):
     spec = orc.spec_from_params(**kw)
-    B = 64
+    B = 4096 if not kw else 64                 # the benchmark configuration: the whole batch
     u_d, y_d, up, yp = T._instances(B)
     d = dict(u_d=u_d, y_d=y_d)
     with T._engine(spec, 400, B) as eng:
         eng.set_data(u_d, y_d)
-        u0, c0, s0, est = run(eng, up, yp, "auto", 0.0)
+        u0, c0, s0, q = run(eng, up, yp, "auto", 0.0)              # threshold 1: never checked exactly, stamp = q, nothing flagged
+        _, _, _, est = run(eng, up, yp, "auto", -300.0)            # threshold 1e-300: always checked exactly, stamp = res
         u2, c2, s2, _ = run(eng, up, yp, "always")
-    print("four-tank %-36s res min %.2e max %.2e   err off %.1e/%.1e   always %.1e/%.1e" % (
-        kw, est.min(), est.max(), *errs(spec, d, up, yp, u0[:8], c0[:8]), *errs(spec, d, up, yp, u2[:8], c2[:8])), flush=True)
+    print("four-tank %-36s q %.2e..%.2e  res %.2e..%.2e  res/q %.2f..%.2f   err off %.1e/%.1e   always %.1e/%.1e" % (
+        kw, q.min(), q.max(), est.min(), est.max(), (est / q).min(), (est / q).max(),
+        *errs(spec, d, up, yp, u0[:8], c0[:8]), *errs(spec, d, up, yp, u2[:8], c2[:8])), flush=True)
 
 # the random-plant sweep: rebuild each case's inputs the way the test does
 import inspect
 src = inspect.getsource(T.test_random_systems_against_oracle)
-body = src.split("    B = 3\n")[0].split("\n", 2)[2]          # everything up to the engine part
+body = src.split("    B = 3\n")[0].split("(gpu, case, refine):\n", 1)[1]          # everything up to the engine part
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 worst_off = worst_on = 0.0
 for case in range(ncases):
@@ -54,7 +60,8 @@ for case in range(ncases):
     try:
         with T._engine(spec, N, B) as eng:
             eng.set_data(d["u_d"], d["y_d"])
-            u0, c0, s0, est = run(eng, up, yp, "auto", 0.0)
+            u0, c0, s0, q = run(eng, up, yp, "auto", 0.0)
+            _, _, _, est = run(eng, up, yp, "auto", -300.0)
             u1, c1, s1, _ = run(eng, up, yp, "auto", DEFAULT)
             u2, c2, s2, _ = run(eng, up, yp, "always")
             name = eng.kernel_name()
@@ -62,7 +69,10 @@ for case in range(ncases):
         print("case %3d rejected: %s" % (case, str(e)[:80])); continue
     e0, e1, e2 = errs(spec, d, up, yp, u0, c0), errs(spec, d, up, yp, u1, c1), errs(spec, d, up, yp, u2, c2)
     worst_off = max(worst_off, e0[0]); worst_on = max(worst_on, e1[0])
-    print("case %3d %-28s r=%3d robust=%d slack=%-6s res %.1e..%.1e  off %.1e/%.1e  auto %.1e/%.1e  always %.1e/%.1e%s" % (
-        case, name, (spec.m + spec.p) * (spec.L + spec.n), spec.robust, spec.slack, est.min(), est.max(), *e0, *e1, *e2,
+    if not spec.robust:
+        q = est = np.ones(1)
+    print("case %3d %-28s r=%3d robust=%d slack=%-6s q %.1e..%.1e res %.1e..%.1e res/q %.2f..%.2f  off %.1e/%.1e  auto %.1e/%.1e  always %.1e/%.1e%s" % (
+        case, name, (spec.m + spec.p) * (spec.L + spec.n), spec.robust, spec.slack, q.min(), q.max(), est.min(), est.max(),
+        (est / q).min(), (est / q).max(), *e0, *e1, *e2,
         "   <-- over 1e-8" if e1[0] > 1e-8 or e1[1] > 1e-9 else ""), flush=True)
 print("worst u error: off %.2e, auto %.2e" % (worst_off, worst_on))
