@@ -1,15 +1,18 @@
 #!/bin/bash
 # Collect the per-round evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh <tag>         e.g. r03_final
+#   bash tools/collect_profiles.sh <tag> [headline|cfg5|all]        e.g. r03_final headline
+# (two parts so that each fits one gpurun call)
 # Writes everything under gpurun_out/<tag>/; copy the summaries into profiles/ afterwards.
 # Counter passes are separate runs with --pmc only (no trace domains), as the pool requires.
 set -e -o pipefail
 TAG=${1:-r03_final}
+PART=${2:-all}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
-rm -rf "$OUT"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+
+if [ "$PART" = "headline" ] || [ "$PART" = "all" ]; then
 
 timeout -k 10 300 python bench.py --steps 50 --warmup 5 > "$OUT/bench.log" 2>&1
 tail -1 "$OUT/bench.log" > "$OUT/bench.json"
@@ -45,6 +48,8 @@ timeout -k 10 120 python tools/phase_stamps.py > "$OUT/phase_stamps.log" 2>&1
 timeout -k 10 300 python tools/bench_configs.py > "$OUT/other_configs.log" 2>&1
 echo "[collect] other configs done"
 
+fi
+if [ "$PART" = "cfg5" ] || [ "$PART" = "all" ]; then
 # BASELINE configs[4] (nominal, m=p=8, r=608, exact data) and the robust scheme at that size: the global-workspace kernels
 timeout -k 10 200 python tools/cfg5_time.py > "$OUT/cfg5_time.log" 2>&1
 timeout -k 10 200 python tools/cfg5_time.py --robust >> "$OUT/cfg5_time.log" 2>&1
@@ -66,4 +71,5 @@ timeout -k 10 400 python tools/large_fuzz.py --cases 12 > "$OUT/large_kernel_fuz
 echo "[collect] cfg5 done"
 # the AUTO refinement trigger on the benchmark batch and on the 96-case random-plant sweep (bound q, exact residual, off / auto / always)
 timeout -k 10 900 python tools/refine_calib.py 96 > "$OUT/refine_calib.log" 2>&1
-echo "[collect] all done"
+fi
+echo "[collect] $PART done"

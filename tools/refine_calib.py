@@ -74,5 +74,5 @@ for case in range(ncases):
     print("case %3d %-28s r=%3d robust=%d slack=%-6s q %.1e..%.1e res %.1e..%.1e res/q %.2f..%.2f  off %.1e/%.1e  auto %.1e/%.1e  always %.1e/%.1e%s" % (
         case, name, (spec.m + spec.p) * (spec.L + spec.n), spec.robust, spec.slack, q.min(), q.max(), est.min(), est.max(),
         (est / q).min(), (est / q).max(), *e0, *e1, *e2,
-        "   <-- over 1e-8" if e1[0] > 1e-8 or e1[1] > 1e-9 else ""), flush=True)
+        "   <-- over the bars" if spec.robust and (e1[0] > 1e-8 or e1[1] > 1e-9) else ""), flush=True)
 print("worst u error: off %.2e, auto %.2e" % (worst_off, worst_on))
