@@ -720,7 +720,14 @@ __device__ __forceinline__ void psd_tile_factor(double* Dg, double* Ms, double* 
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-__device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol_abs, int* skip, double* pan, int ncols = -1) {
+// `early` (full factorisations only): when a whole panel comes out without a pivot, the diagonal of the Schur complement
+// behind it is formed (one pass over the rows below); if none of its entries exceeds tol_abs either, every remaining
+// pivot would be skipped as well (the diagonal of a PSD Schur complement only shrinks): the remaining columns are
+// marked skipped, the trailing block is zeroed and the factorisation stops.  Returns the number of columns in front of
+// that point (n when it ran to the end): all columns >= the return value are zero.  With the dependent rows ordered last
+// (exact data: the rank-revealing kernel) this saves the factorisation of the dead half of the matrix.
+__device__ __forceinline__ int packed_psd_cholesky(double* A, int n, double tol_abs, int* skip, double* pan, int ncols = -1,
+                                                   bool early = false) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = (int)(blockDim.x >> 6);
@@ -873,7 +880,49 @@ __device__ __forceinline__ void packed_psd_cholesky(double* A, int n, double tol
       }
     }
     __syncthreads();                                                      // panel stored before the next update reads it; LDS tiles free
+    if (early && ncols == n && k0 + 32 < n) {
+      bool alldead = true;
+      for (int q = 0; q < 32; ++q) alldead = alldead && (skip[k0 + q] != 0);      // LDS, the same for every thread
+      if (alldead) {
+        const int i1 = k0 + 32;
+        const int hw = tid >> 5, t32 = tid & 31, nhw = (int)(blockDim.x >> 5);
+        double dm = 0.0;
+        for (int ib = i1; ib < n; ib += nhw) {
+          const int i = ib + hw;
+          double s0 = 0.0, s1 = 0.0;
+          if (i < n) {
+            const double* Li = A + (size_t)i * (i + 1) / 2;
+            int j = t32;
+            for (; j + 32 < k0; j += 64) { const double l0 = Li[j], l1 = Li[j + 32]; s0 += l0 * l0; s1 += l1 * l1; }
+            if (j < k0) { const double l0 = Li[j]; s0 += l0 * l0; }
+          }
+          double sacc = s0 + s1;
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 32);
+          if (i < n) dm = fmax(dm, A[(size_t)i * (i + 1) / 2 + i] - sacc);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dm = fmax(dm, __shfl_xor(dm, off, 64));
+        double* dred = pan + 1312;                                        // (behind the 1312 doubles the panels use)
+        if ((tid & 63) == 0) dred[tid >> 6] = dm;
+        __syncthreads();
+        double dall = 0.0;
+        for (int w = 0; w < nwave; ++w) dall = fmax(dall, dred[w]);
+        __syncthreads();
+        if (dall <= tol_abs) {
+          for (int k = i1 + tid; k < n; k += (int)blockDim.x) skip[k] = 1;
+          const size_t e0 = (size_t)i1 * (i1 + 1) / 2, e1 = (size_t)n * (n + 1) / 2;
+          for (size_t e = e0 + tid; e < e1; e += blockDim.x) {             // rows >= i1: their entries in columns >= i1
+            const int i = tri_row((int)e), j = (int)(e - (size_t)i * (i + 1) / 2);
+            if (j >= i1) A[e] = 0.0;
+          }
+          __syncthreads();
+          return k0;
+        }
+      }
+    }
   }
+  return n;
 }
 
 // Back substitution L' x = y for a packed lower factor, 16 rows at a time: the 16x16 diagonal block is solved by the
@@ -1031,11 +1080,13 @@ __device__ __forceinline__ void packed_cols_times(const double* Lm, int row0, in
 // triangle of T by v_mfma_f64_16x16x4, the row index i as the contraction index (4 rows per instruction; both operands
 // are 128-byte pieces of packed rows).  A skipped pivot (skipd[a] != 0) has a zero column in L: its row and column of T
 // come out zero and the diagonal entry is set to one.  Work items = (tile row A, group of up to four tile columns).
+// `ncol` <= nR: only the leading ncol columns of C (rows / columns of T) are formed -- the rest are known to be zero columns.
 __device__ __forceinline__ void packed_weighted_gram_mfma(const double* Lm, int row0, int nR, const double* w,
-                                                          const int* skipd, double* T) {
+                                                          const int* skipd, double* T, int ncol = -1) {
   const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwave = (int)(blockDim.x >> 6);
-  const int nt = (nR + 15) >> 4;
+  if (ncol < 0) ncol = nR;
+  const int nt = (ncol + 15) >> 4;
   int item = 0;
   for (int A = nt - 1; A >= 0; --A) {                  // longest rows first
     for (int B0 = 0; B0 <= A; B0 += 4, ++item) {
@@ -1048,12 +1099,12 @@ __device__ __forceinline__ void packed_weighted_gram_mfma(const double* Lm, int 
         const int i = i0 + l4;
         const size_t ri = (size_t)(row0 + (i < nR ? i : nR - 1));
         const double* Li = Lm + ri * (ri + 1) / 2 + row0;
-        const double av = (i < nR && a <= i) ? Li[a] * w[i] : 0.0;
+        const double av = (i < nR && a <= i && a < ncol) ? Li[a] * w[i] : 0.0;
         double bv[4];                                    // all loads of the step before the first MFMA
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int bcol = 16 * ((B0 + g <= A) ? B0 + g : A) + l15;
-          bv[g] = (i < nR && bcol <= i) ? Li[bcol] : 0.0;
+          bv[g] = (i < nR && bcol <= i && bcol < ncol) ? Li[bcol] : 0.0;
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -1066,7 +1117,7 @@ __device__ __forceinline__ void packed_weighted_gram_mfma(const double* Lm, int 
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int ar = 16 * A + l4 + 4 * q;
-            if (ar < nR && bcol <= ar) T[(size_t)ar * (ar + 1) / 2 + bcol] = (ar == bcol && skipd[ar]) ? 1.0 : acc[g][q];
+            if (ar < ncol && bcol <= ar) T[(size_t)ar * (ar + 1) / 2 + bcol] = (ar == bcol && skipd[ar]) ? 1.0 : acc[g][q];
           }
         }
       }
@@ -1349,27 +1400,33 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   const double* up = u_past + b * (long long)P.npu;
   const double* yp = y_past + b * (long long)(n * p);
   // ---- components, fixed first ------------------------------------------------------------
+  // Inside the fixed block and inside the free block the INPUT components come first (time order), the outputs behind
+  // them: with exact data the outputs are the dependent rows (beyond the few that pin the state), so the rows without a
+  // pivot gather at the end of each block -- the tail of the free block is then one dead stretch at which the
+  // factorisation stops early (packed_psd_cholesky), and everything downstream works on the leading `nlive` columns.
   if (tid == 0) {
     int nF = 0;
-    for (int rho = 0; rho < r; ++rho) {
-      const int kind = P.tabi[0 * RPs + rho];
-      if (kind == K_UFIX || kind == K_YFIX) {
-        const int pidx = P.tabi[1 * RPs + rho];
-        perm[nF] = rho;
-        fv[nF] = (pidx >= 0) ? ((pidx < P.npu) ? up[pidx] : yp[pidx - P.npu]) : P.tabd[2 * RPs + rho];
-        ++nF;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int rho = 0; rho < r; ++rho) {
+        const int kind = P.tabi[0 * RPs + rho];
+        if (kind == (pass == 0 ? K_UFIX : K_YFIX)) {
+          const int pidx = P.tabi[1 * RPs + rho];
+          perm[nF] = rho;
+          fv[nF] = (pidx >= 0) ? ((pidx < P.npu) ? up[pidx] : yp[pidx - P.npu]) : P.tabd[2 * RPs + rho];
+          ++nF;
+        }
       }
-    }
     int nR = 0;
-    for (int rho = 0; rho < r; ++rho) {
-      const int kind = P.tabi[0 * RPs + rho];
-      if (kind == K_UFREE || kind == K_YFREE) {
-        perm[nF + nR] = rho;
-        wv[nR] = P.tabd[3 * RPs + rho];
-        zs[nR] = P.tabd[2 * RPs + rho];
-        ++nR;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int rho = 0; rho < r; ++rho) {
+        const int kind = P.tabi[0 * RPs + rho];
+        if (kind == (pass == 0 ? K_UFREE : K_YFREE)) {
+          perm[nF + nR] = rho;
+          wv[nR] = P.tabd[3 * RPs + rho];
+          zs[nR] = P.tabd[2 * RPs + rho];
+          ++nR;
+        }
       }
-    }
     cnt[0] = nF; cnt[1] = nR;
   }
   __syncthreads();
@@ -1411,7 +1468,8 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   double dmax = 0.0;
   for (int w = 0; w < (nthr >> 6); ++w) dmax = fmax(dmax, red[w]);
   __syncthreads();
-  packed_psd_cholesky(G, r, rank_tol * dmax, skip, pan);
+  const int nlive = packed_psd_cholesky(G, r, rank_tol * dmax, skip, pan, -1, true);      // columns >= nlive are zero
+  const int nRl = (nlive > nF) ? ((nlive - nF) < nR ? (nlive - nF) : nR) : 0;                 // live columns of the free block
   if (dbg && tid == 0) dbg[b * 8 + 2] = __builtin_amdgcn_s_memrealtime();
   // ---- hard constraints: L_FF w = f (skipped pivots carry no unknown); residual of the dependent rows ----
   packed_forward_substitute(G, nF, fv, col, skip, red);
@@ -1425,21 +1483,22 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   __syncthreads();
   if (dbg && tid == 0) dbg[b * 8 + 3] = __builtin_amdgcn_s_memrealtime();
   // ---- reduced normal equations T = C' W C, rhs = C' W (zs - z0), C(i,a) = L(nF+i, nF+a), i >= a ----
-  packed_weighted_gram_mfma(G, nF, nR, wv, skip + nF, T);
+  packed_weighted_gram_mfma(G, nF, nR, wv, skip + nF, T, nRl);
   for (int i = tid; i < nR; i += nthr) ra[i] = wv[i] * (zs[i] - z0[i]);
+  for (int a = nRl + tid; a < nR; a += nthr) { vv[a] = 0.0; skipT[a] = 1; }                  // dead tail of the free block
   __syncthreads();
-  packed_cols_times(G, nF, nR, nF, nR, [&](int a) { return a; }, [&](int i) { return ra[i]; },
+  packed_cols_times(G, nF, nR, nF, nRl, [&](int a) { return a; }, [&](int i) { return ra[i]; },
                     [&](int a, double sacc) { vv[a] = skip[nF + a] ? 0.0 : sacc; });
   __syncthreads();
   if (dbg && tid == 0) dbg[b * 8 + 4] = __builtin_amdgcn_s_memrealtime();
   double tmx = 0.0;
-  for (int a = 0; a < nR; ++a) tmx = fmax(tmx, T[a * (a + 1) / 2 + a]);
-  packed_psd_cholesky(T, nR, 1e-14 * tmx, skipT, pan);
+  for (int a = 0; a < nRl; ++a) tmx = fmax(tmx, T[a * (a + 1) / 2 + a]);
+  packed_psd_cholesky(T, nRl, 1e-14 * tmx, skipT, pan);
   if (dbg && tid == 0) dbg[b * 8 + 5] = __builtin_amdgcn_s_memrealtime();
   // ---- T v = rhs by the factor ------------------------------------------------------------------------------
-  packed_forward_substitute(T, nR, vv, rb, skipT, red);
-  packed_back_substitute(T, nR, rb, ra, skipT);           // w2; col keeps w1 for the refinement step
-  for (int a = tid; a < nR; a += nthr) vv[a] = ra[a];
+  packed_forward_substitute(T, nRl, vv, rb, skipT, red);
+  packed_back_substitute(T, nRl, rb, ra, skipT);          // w2; col keeps w1 for the refinement step
+  for (int a = tid; a < nR; a += nthr) vv[a] = (a < nRl) ? ra[a] : 0.0;
   __syncthreads();
   if (dbg && tid == 0) dbg[b * 8 + 6] = __builtin_amdgcn_s_memrealtime();
   // ---- one step of iterative refinement on the KKT system of the problem in the coordinates w of
@@ -1458,15 +1517,15 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   for (int pass = 0;; ++pass) {
   for (int a = tid; a < nR; a += nthr) vv[a] = wk[nF + a];             // w2 of this pass ((b) below reads it)
   // (a) z_ex = B w:  w (position order) -> x = L^-T w (zero on rows without a pivot) -> H' x -> H (H' x)
-  for (int k = tid; k < r; k += nthr) ra[k] = wk[k];
+  for (int k = tid; k < r; k += nthr) { ra[k] = wk[k]; if (k >= nlive) rb[k] = 0.0; }
   __syncthreads();
-  packed_back_substitute(G, r, ra, rb, skip);
+  packed_back_substitute(G, nlive, ra, rb, skip);                     // (rows without a pivot carry no unknown: zero)
   for (int k = tid; k < r; k += nthr) ra[perm[k]] = rb[k];           // component order
   __syncthreads();
   hankel_normal_times(P, ud, yd, ra, rd, pan);
   for (int k = tid; k < r; k += nthr) rz[k] = rd[perm[k]];           // z_ex in position order
   // (b) multipliers of the starting point: L_FF' mu = -L_RF' W (z_R - zs), z_R = z0 + C w2 (the unrefined solution)
-  packed_rows_times(G, nF, nR, nF, vv, [&](int i) { return nF + i + 1; },
+  packed_rows_times(G, nF, nR, nF, vv, [&](int i) { return (nF + i + 1) < nlive ? (nF + i + 1) : nlive; },
                     [&](int i, double sacc) { rb[nF + i] = wv[i] * (z0[i] + sacc - zs[i]); });
   __syncthreads();
   packed_cols_times(G, nF, nR, 0, nF, [&](int) { return 0; }, [&](int i) { return rb[nF + i]; },
@@ -1481,18 +1540,21 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   hankel_normal_times(P, ud, yd, ra, rd, pan);
   for (int k = tid; k < r; k += nthr) rb[k] = rd[perm[k]];
   __syncthreads();
-  packed_forward_substitute(G, r, rb, ra, skip, red);                    // ra = L_I^-1 (H_I H' v) = -rw
+  for (int k = nlive + tid; k < r; k += nthr) ra[k] = 0.0;
+  packed_forward_substitute(G, nlive, rb, ra, skip, red);                // ra = L_I^-1 (H_I H' v) = -rw
   // (d) correction with the factors at hand:  dw1 = L_FF^-1 (f - z_ex,F);  T dw2 = rw2 - C' W L_RF dw1
   for (int k = tid; k < nF; k += nthr) rd[k] = fv[k] - rz[k];
   __syncthreads();
   packed_forward_substitute(G, nF, rd, rb, skip, red);                   // dw1 -> rb[0..nF)
   packed_rows_times(G, nF, nR, 0, rb, [&](int) { return nF; }, [&](int i, double sacc) { rd[nF + i] = sacc; });   // L_RF dw1
   __syncthreads();
-  packed_cols_times(G, nF, nR, nF, nR, [&](int a) { return a; }, [&](int i) { return wv[i] * rd[nF + i]; },
+  packed_cols_times(G, nF, nR, nF, nRl, [&](int a) { return a; }, [&](int i) { return wv[i] * rd[nF + i]; },
                     [&](int a, double sacc) { vv[a] = skip[nF + a] ? 0.0 : -ra[nF + a] - sacc; });              // rhs of the T system
   __syncthreads();
-  packed_forward_substitute(T, nR, vv, col, skipT, red);                 // col: work vector (w lives in wk)
-  packed_back_substitute(T, nR, col, vv, skipT);                         // dw2 -> vv
+  packed_forward_substitute(T, nRl, vv, col, skipT, red);                // col: work vector (w lives in wk)
+  packed_back_substitute(T, nRl, col, vv, skipT);                        // dw2 -> vv
+  for (int a = nRl + tid; a < nR; a += nthr) vv[a] = 0.0;
+  __syncthreads();
   // size of this correction relative to w; decide whether another pass pays
   double dmx = 0.0, wmx = 0.0;
   for (int k = tid; k < r; k += nthr) {
@@ -1511,7 +1573,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   // ---- z_R = z_ex,R + L_RF dw1 + C dw2; outputs ------------------------------------------------------
   double part = 0.0;
   double* uo = u_opt + b * (long long)((P.Ln - n) * m);
-  packed_rows_times(G, nF, nR, nF, vv, [&](int i) { return nF + i + 1; }, [&](int i, double sacc) {
+  packed_rows_times(G, nF, nR, nF, vv, [&](int i) { return (nF + i + 1) < nlive ? (nF + i + 1) : nlive; }, [&](int i, double sacc) {
     const double z = rz[nF + i] + rd[nF + i] + sacc;
     const double dlt = z - zs[i];
     part += wv[i] * dlt * dlt;
@@ -1531,7 +1593,9 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
     __syncthreads();
     for (int k = tid; k < r; k += nthr) ra[k] = wk[k] + ((k < nF) ? rb[k] : vv[k - nF]);
     __syncthreads();
-    packed_back_substitute(G, r, ra, col, skip);
+    for (int k = nlive + tid; k < r; k += nthr) col[k] = 0.0;
+    __syncthreads();
+    packed_back_substitute(G, nlive, ra, col, skip);
     for (int k = tid; k < r; k += nthr) x_ws[b * (long long)P.rE + perm[k]] = col[k];
   }
   part = wave_sum(part);
