@@ -167,10 +167,19 @@ struct Lds2 {
   static constexpr int PB_LEN = 16 * RSB;
   static constexpr int ctab = pb + PB_LEN;             // lag blocks C[d][a][b], d < RP/4 (structured Gram)
   static constexpr int CTAB_LEN = 4 * RP;
-  static constexpr int xs = ctab + CTAB_LEN;           // trajectory, channel-interleaved
+  // one 16x16 tile on its way from a helper wave to the panel wave (the deferred updates of the next-but-one diagonal
+  // tile, see wave_body2): two halves of 128 doubles.  During the factorisation dvec (consumed by the fix-up) and beta
+  // (written by the back substitution) are idle, so from 8 tile rows on the halves live there -- the benchmark instance
+  // sits 2.4 KB below the LDS size at which a CU holds three workgroups; smaller instances get their own 2 KB.
+  static constexpr bool DST_ALIAS = RP >= 128;
+  static constexpr int dst = ctab + CTAB_LEN;
+  static constexpr int DST_LEN = (W > 1 && !DST_ALIAS) ? 256 : 0;
+  static constexpr int dst_lo = DST_ALIAS ? dvec : dst;
+  static constexpr int dst_hi = DST_ALIAS ? beta : dst + 128;
+  static constexpr int xs = dst + DST_LEN;             // trajectory, channel-interleaved
   // scratch of the residual check behind the solve (everything between pt2 and xs is free by then)
   static constexpr int SCR = pt2;
-  static constexpr int SCR_LEN = xs - pt2;
+  static constexpr int SCR_LEN = dst - pt2;
   __host__ __device__ static constexpr int total(int xs_len) { return (xs + xs_len + 1) & ~1; }
 
   static_assert(W >= 1 && W <= 8, "red[] keeps 8 per-wave slots per quantity; part[] is sized by W");
@@ -238,9 +247,23 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
   const int IR = rE >> 4;           // tile column holding the rhs column (column index rE)
   const int rr = rE & 15;
 
-  static_assert(8 * TM::MAXS + 40 <= 512 / DDMPC_MIN_WAVES(NT, W),
+  // Deferred diagonal updates (W > 1).  The trailing updates of the main-diagonal tiles J >= 2 with the panels Jb <= J - 2
+  // are NOT executed by the panel wave (every MFMA in its instruction stream delays its pivot chain, the critical path of
+  // the workgroup; measured: with those 112 MFMAs in the chain's gaps the kernel takes 7 % longer than without them): a
+  // helper wave accumulates  Delta_J = sum_{Jb <= J-2} U(Jb,J)' U(Jb,J)  in its own registers from the operands it loads
+  // for its off-diagonal updates anyway, and hands the finished tile over through LDS (`dst`) behind barrier B of step
+  // J - 2; the panel wave adds it (4 vector adds) and applies the last panel, J - 1, itself as before.
+  constexpr int NHELP = (W > 1) ? W - 1 : 1;
+  constexpr int DFIRST = 3;     // tiles J >= Jb + DFIRST are deferred to the helpers; the panel wave itself applies panels J-2 and J-1
+  constexpr int NDSLOT = (W > 1 && NT > DFIRST) ? (NT - DFIRST + NHELP - 1) / NHELP : 1;
+  auto downer = [](int J) constexpr { return 1 + (J - DFIRST) % NHELP; };
+  auto dslot = [](int J) constexpr { return (J - DFIRST) / NHELP; };
+  static_assert(8 * (TM::MAXS + (W > 1 ? NDSLOT : 0)) + 40 <= 512 / DDMPC_MIN_WAVES(NT, W),
                 "the accumulator tiles of the busiest wave must leave a working set of 40 VGPRs at the occupancy of __launch_bounds__");
   d4 acc[TM::MAXS];
+  d4 dlt[NDSLOT];
+  double* DSTlo = sm + LD::dst_lo;    // registers 0, 1 of the tile in flight
+  double* DSThi = sm + LD::dst_hi;    // registers 2, 3
 
   constexpr int NE = (RP + NTHR - 1) / NTHR;
   double* cD0 = sm + LD::cd0;
@@ -296,6 +319,8 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
     stamp();           // 1
 
     bool f0_done = false;   // structured Gram: the panel wave has already factored diagonal tile 0 (beside the other waves' walks)
+    static_for<NDSLOT>([&](auto S) __attribute__((always_inline)) { dlt[S] = d4{0.0, 0.0, 0.0, 0.0}; });
+    bool dst_valid = false;  // a finished Delta tile waits in `dst` (workgroup-uniform)
     // -(G + lam*D) of one raw Gram tile; -identity on dummy rows; rhs COLUMN rE := -t (mirrored into the diagonal tile);
     // dense weighting matrices: lam * W^-1 is a full symmetric matrix shared by the batch (L2)
     auto fix_tile = [&](auto II, auto JJ, const d4& raw) __attribute__((always_inline)) -> d4 {
@@ -640,6 +665,14 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         const bool more = 16 * (Jb + 1) < rE + 1;                   // live columns to the right of this panel
         const int nqn = (NS - 4 * (Jb + 1)) < 4 ? (NS - 4 * (Jb + 1)) : 4;   // pivot groups of the next tile column
         const long long t0 = now();
+        if constexpr (WAVE == 0 && W > 1 && Jb >= 1 && Jb + DFIRST - 1 < NT) {
+          if (dst_valid) {                                         // Delta of tile Jb + DFIRST - 1 (panels 0 .. Jb - 1), written before barrier B
+            constexpr int SDn = TM::slot(Jb + DFIRST - 1, Jb + DFIRST - 1);
+            acc[SDn][0] += DSTlo[lane]; acc[SDn][1] += DSTlo[64 + lane];
+            acc[SDn][2] += DSThi[lane]; acc[SDn][3] += DSThi[64 + lane];
+          }
+        }
+        dst_valid = false;
         // M operand of the triangular solves: read before A1, the panel wave overwrites LT after it
         double am[4];
         static_for<4>([&](auto ks) __attribute__((always_inline)) { am[ks()] = -LT[l15 * LRS + 16 + 4 * ks() + l4]; });
@@ -695,7 +728,8 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
             constexpr int q = QM + 1;
             // diagonal tiles Jb+2+QM, +3, +6, ...: 4 MFMAs each, issued k-step-major (consecutive MFMAs hit different tiles)
             constexpr int first = Jb + 2 + QM;
-            constexpr int ntl = first < NT ? (NT - 1 - first) / 3 + 1 : 0;
+            constexpr int last = (W > 1) ? ((Jb + DFIRST - 1 < NT - 1) ? Jb + DFIRST - 1 : NT - 1) : NT - 1;   // helpers take the rest
+            constexpr int ntl = first <= last ? (last - first) / 3 + 1 : 0;
             auto pend = [&](auto H) __attribute__((always_inline)) {
               constexpr int h0 = H;
               static_for<(4 * ntl + 11) / 12>([&](auto R) __attribute__((always_inline)) {   // more than 12 pending: several per hook
@@ -728,7 +762,26 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
                 }
               }
             });
+            if constexpr (WAVE != 0 && W > 1) {                     // deferred diagonal updates of this wave's tiles
+              static_for<NT>([&](auto JD) __attribute__((always_inline)) {
+                constexpr int J = JD;
+                if constexpr (J >= Jb + DFIRST) {
+                  if constexpr (downer(J) == WAVE) {
+                    if (16 * J < rE + 1) dlt[dslot(J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[J], op[J], dlt[dslot(J)], 0, 0, 0);
+                  }
+                }
+              });
+            }
           });
+          if constexpr (W > 1 && Jb + DFIRST < NT) {
+            if constexpr (WAVE != 0) {
+              if constexpr (downer(Jb + DFIRST) == WAVE) {          // Delta of tile Jb + DFIRST is complete: hand it over
+                const d4 dv = dlt[dslot(Jb + DFIRST)];
+                DSTlo[lane] = dv[0]; DSTlo[64 + lane] = dv[1]; DSThi[lane] = dv[2]; DSThi[64 + lane] = dv[3];
+              }
+            }
+            dst_valid = true;
+          }
         }
         const long long t5 = now();
         __syncthreads();                                            // (B) M_{Jb+1} is in LT
