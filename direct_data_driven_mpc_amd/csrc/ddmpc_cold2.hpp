@@ -482,18 +482,32 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
       //      (the Hankel sliding-window recurrence in matrix form, see ddmpc_kernels.hpp) -- k-major tiles.
       const int c = P.c, Ln = P.Ln;
       {
-        constexpr int MAXG = (NT + W - 1) / W;             // lag groups per wave
+        // Every wave takes ALL lag groups (a half of them with 8 waves) over a quarter of the time range: the A operand
+        // of a k-step is shared by the groups (x[t + 4 g + blk], g + u = const), so a trip of 4 k-steps needs
+        // 4 + (MAXG + 3) LDS loads for 4 MAXG MFMAs -- 16 loads per 36 MFMAs for the benchmark instead of the 10 per 12 of
+        // a split by groups (this phase is bound by LDS operand delivery), and the waves carry equal shares (9 groups
+        // over 4 waves used to leave one wave idle and three with 3 groups each).  The partial sums meet in LDS.
+        constexpr int TS = (W >= 4) ? 4 : W;                // time slices
+        constexpr int GS = W / TS;                          // group slices (8 waves: 2)
+        constexpr int MAXG = (NT + GS - 1) / GS;            // lag groups per wave
+        static_assert(TS * GS == W, "waves = time slices x group slices");
+        static_assert(TS * GS * MAXG * 64 <= LD::PT2_LEN + LD::LT_LEN + LD::PB_LEN, "partial lag blocks fit between pt2 and ctab");
         const int ngroups = (Ln + 3) >> 2;
         const int kq = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
-        if (iter == 1 && WAVE * MAXG < ngroups) {
+        double* PP = sm + LD::pt2;                          // partial lag blocks [time slice][group][lane] (PT2 / LT / PB are idle)
+        constexpr int tsl = WAVE % TS, gsl = WAVE / TS;
+        if (iter == 1) {
           double cacc[MAXG];
           static_for<MAXG>([&](auto gi) __attribute__((always_inline)) { cacc[gi()] = 0.0; });
-          const double* pB = xs + 4 * kq + ij;                                   // B[k][j] = x_j[t0 + k]
-          const double* pA = xs + 4 * (kq + blk) + ij + 16 * (WAVE * MAXG);      // A[i][k] = x_i[t0 + k + 4g + blk]
           const int cfull = c & ~3;
-          int t0 = 0;
-          // 4 k-steps per trip, software-pipelined over two operand sets: the loads of trip i+1 are in flight while the
-          // MFMAs of trip i issue (the phase is bound by LDS latency, not by the matrix pipe)
+          const int nks = cfull >> 2;                       // full k-steps (4 time steps each)
+          const int kw = (nks + TS - 1) / TS;
+          const int ks0 = tsl * kw;
+          const int ks1 = (ks0 + kw) < nks ? (ks0 + kw) : nks;
+          const double* pB = xs + 4 * (kq + 4 * ks0) + ij;                               // B[k][j] = x_j[t0 + k]
+          const double* pA = xs + 4 * (kq + blk + 4 * ks0) + ij + 16 * (gsl * MAXG);     // A[i][k] = x_i[t0 + k + 4g + blk]
+          // 4 k-steps per trip: 4 + (MAXG + 3) loads, then 4 MAXG MFMAs (a second operand set in flight under the MFMAs
+          // costs 60 spilled VGPRs in the Cholesky that follows: slower overall)
           auto ld = [&](double (&bv)[4], double (&av)[MAXG + 3]) __attribute__((always_inline)) {
             static_for<4>([&](auto u) __attribute__((always_inline)) { bv[u()] = pB[16 * u]; });
             static_for<MAXG + 3>([&](auto q) __attribute__((always_inline)) { av[q()] = pA[16 * q]; });
@@ -506,26 +520,22 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
               });
             });
           };
-          const int ntrip = cfull >> 4;
-          double bv0[4], av0[MAXG + 3], bv1[4], av1[MAXG + 3];
-          if (ntrip > 0) ld(bv0, av0);
-          int it = 0;
-          for (; it + 2 <= ntrip; it += 2) {
-            ld(bv1, av1);
+          const int nk = ks1 > ks0 ? ks1 - ks0 : 0;
+          const int ntrip = nk >> 2;
+          double bv0[4], av0[MAXG + 3];
+#pragma nounroll
+          for (int it = 0; it < ntrip; ++it) {
+            ld(bv0, av0);
             mm(bv0, av0);
-            if (it + 2 < ntrip) ld(bv0, av0);
-            mm(bv1, av1);
           }
-          if (it < ntrip) mm(bv0, av0);
-          t0 = 16 * ntrip;
-          for (; t0 < cfull; t0 += 4) {
+          for (int k = 4 * ntrip; k < nk; ++k) {
             const double bv = pB[0];
             static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
               cacc[gi()] = __builtin_amdgcn_mfma_f64_4x4x4f64(pA[16 * gi], bv, cacc[gi()], 0, 0, 0);
             });
             pA += 16; pB += 16;
           }
-          if (cfull < c) {
+          if (tsl == TS - 1 && cfull < c) {                  // the ragged last k-step: the last time slice (pA / pB stand at cfull)
             const bool kok = (cfull + kq) < c;
             const double bv = kok ? pB[0] : 0.0;
             static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
@@ -534,10 +544,18 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
             });
           }
           static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
-            constexpr int g = WAVE * MAXG + gi;
-            const int d = 4 * g + blk;                     // D layout: i = lane>>4, j = lane&3
-            if (g < ngroups && d < Ln) ctab[d * 16 + kq * 4 + ij] = cacc[gi()];
+            PP[((tsl * GS + gsl) * MAXG + gi()) * 64 + lane] = cacc[gi()];
           });
+        }
+        __syncthreads();
+        if (iter == 1) {
+          for (int e = tid; e < GS * MAXG * 64; e += NTHR) {
+            const int g = e >> 6, ln = e & 63;              // (group slice, group in slice) = (g / MAXG, g % MAXG): g is the group
+            double sacc = 0.0;
+            static_for<TS>([&](auto t) __attribute__((always_inline)) { sacc += PP[(t() * GS * MAXG + g) * 64 + ln]; });
+            const int d = 4 * g + ((ln >> 2) & 3);          // D layout: i = lane>>4, j = lane&3
+            if (g < ngroups && d < Ln) ctab[d * 16 + (ln >> 4) * 4 + (ln & 3)] = sacc;
+          }
         }
       }
       __syncthreads();
