@@ -145,6 +145,7 @@ struct ddmpc_handle {
   DevBuf d_io, d_rr, d_alpha;
   DevBuf d_rflag;                          // AUTO refinement: per-instance "refine me" flags of the plain cold kernel
   DevBuf d_zws, d_resc, d_xws;             // NOMINAL rescue kernel: z per component, a per-instance "rescued" flag and x = L^-T w (ddmpc_get_solution)
+  DevBuf d_rrmeta;                         // ... pivot pattern + live column counts of the factors it leaves in d_rr (2 rv + 2 ints per instance)
   bool rescue_ran = false;
   int epoch = 0;                           // cold launches so far (KParams::epoch)
   int prep_epoch = 0;                      // stamp of the flags recorded by ddmpc_prepare's factor-export launch (AUTO)
@@ -529,7 +530,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -721,8 +722,10 @@ static int launch_warm(ddmpc_handle* h, const double* up, const double* yp, doub
 
 // Nominal scheme: instances whose Gram matrix is singular (exact data) are re-solved by the rank-revealing
 // kernel; it only touches instances the fast path marked SOLVER_ERROR.
+// rr_mode (problems whose matrices live in the global workspace only): 0 whole solve, 1 the data-dependent factors alone
+// (ddmpc_prepare), 2 a solve on the factors already in the workspace (ddmpc_step) -- see ddmpc_nominal_rr_kernel.
 static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
-                                 int32_t* status, int32_t* iters) {
+                                 int32_t* status, int32_t* iters, int rr_mode = 0) {
   if (h->prm.controller_type != DDMPC_NOMINAL || h->prm.weight_kind == DDMPC_WEIGHT_DENSE) return DDMPC_OK;
   const size_t r = (size_t)h->kp.r, nR = (size_t)h->n_free;
   const size_t ndbl = r * (r + 1) / 2 + nR * (nR + 1) / 2;
@@ -736,7 +739,9 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
     if (rc) return rc;
     scratch = (double*)h->d_rr.p;
     lds = vec_bytes;
+    if ((rc = h->d_rrmeta.ensure((size_t)h->batch * (2 * rv + 2) * sizeof(int)))) return rc;
   }
+  if (!scratch) rr_mode = 0;
   if (lds + 1024 > 160 * 1024) return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: %zu rows", r);
   {   // per instance: the r-vector w of the refinement passes
     int rca = h->d_alpha.ensure((size_t)h->batch * (size_t)h->kp.r * sizeof(double));
@@ -749,23 +754,41 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
     if (rcz) return rcz;
     HIP_TRY(hipMemsetAsync(h->d_resc.p, 0, (size_t)h->batch * sizeof(int), h->stream));
   }
-  if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_nominal_rr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // rank tolerance 1e-8 (relative to the largest diagonal entry of the Gram): with the fixed-first ordering the
   // pivots of dependent rows come out as rounding residue up to ~3e-10, genuine ones are >= ~5e-7 on exact
   // four-tank data (L = 10 .. 60)
-  hipLaunchKernelGGL(ddmpc_nominal_rr_kernel, dim3((unsigned)h->batch), dim3(large_threads(r)), lds, h->stream, h->kp, 16 * h->kc.NT,
-                     h->ud, h->yd, up, yp, uo, cost, (int*)status, (int*)iters, 1e-8, 1e-7, scratch, (long long)ndbl,
-                     (double*)h->d_alpha.p,
-                     (h->stamps_on && h->d_stamps.bytes >= (size_t)h->batch * 8 * sizeof(uint64_t)) ? (unsigned long long*)h->d_stamps.p
-                                                                                                      : (unsigned long long*)nullptr,
-                     (double*)h->d_zws.p, (int*)h->d_resc.p, (double*)h->d_xws.p);
-  HIP_TRY(hipGetLastError());
-  h->rescue_ran = true;
+  auto launch = [&](auto fn) -> int {
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fn, dim3((unsigned)h->batch), dim3(large_threads(r)), lds, h->stream, h->kp, 16 * h->kc.NT,
+                       h->ud, h->yd, up, yp, uo, cost, (int*)status, (int*)iters, 1e-8, 1e-7, scratch, (long long)ndbl,
+                       (double*)h->d_alpha.p,
+                       (h->stamps_on && h->d_stamps.bytes >= (size_t)h->batch * 16 * sizeof(uint64_t)) ? (unsigned long long*)h->d_stamps.p
+                                                                                                        : (unsigned long long*)nullptr,
+                       (double*)h->d_zws.p, (int*)h->d_resc.p, (double*)h->d_xws.p,
+                       scratch ? (int*)h->d_rrmeta.p : (int*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return DDMPC_OK;
+  };
+  int rcl = DDMPC_OK;
+  if (!scratch) rcl = launch(ddmpc_nominal_rr_kernel<0>);                 // matrices in LDS: one launch
+  else {                                                                  // global workspace: factors, then the solve on them
+    if (rr_mode != 2) rcl = launch(ddmpc_nominal_rr_kernel<1>);
+    if (!rcl && rr_mode != 1) rcl = launch(ddmpc_nominal_rr_kernel<2>);
+  }
+  if (rcl) return rcl;
+  if (rr_mode != 1) h->rescue_ran = true;
   return DDMPC_OK;
 }
 
 typedef int (*launch_fn)(ddmpc_handle*, const double*, const double*, double*, double*, int32_t*, int32_t*);
+// NOMINAL controller beyond the register-resident kernels, warm: a solve on the factors ddmpc_prepare left in the workspace
+static int launch_large_nominal_warm(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
+                                     int32_t* status, int32_t* iters) {
+  h->beta_stale = false;
+  h->ws_stale = false;
+  HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)status, 4, (size_t)h->batch, h->stream));
+  return launch_nominal_rescue(h, up, yp, uo, cost, status, iters, 2);
+}
 static int launch_cold_plain(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
                              int32_t* status, int32_t* iters) {
   int rc = launch_cold(h, up, yp, uo, cost, status, iters, nullptr, nullptr, nullptr, /*want_ws=*/false);
@@ -938,7 +961,19 @@ int ddmpc_prepare(ddmpc_handle* h) {
   if (!h->have_data) return fail(DDMPC_ERR_NOT_READY, "ddmpc_set_data must be called before ddmpc_prepare");
   if (h->batch > 0x7fffffffLL) return fail(DDMPC_ERR_INVALID, "batch too large for one launch");
   if (h->prepared) return DDMPC_OK;
-  if (h->large) return DDMPC_OK;          // no affine law is formed at this size: every step is a full solve
+  if (h->large_nominal) {
+    // no affine law at this size, but everything that depends on the data alone -- Gram, its rank-revealing factor, the
+    // reduced normal matrix and its factor, 70 % of a solve -- is formed once and kept in the workspace; ddmpc_step and
+    // the per-step closed loop then only redo the substitutions and the refinement passes
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = h->d_prep_status.ensure((size_t)h->batch * sizeof(int32_t));
+    if (rc) return rc;
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)h->d_prep_status.p, 4, (size_t)h->batch, h->stream));
+    if ((rc = launch_nominal_rescue(h, h->ud, h->yd, nullptr, nullptr, (int32_t*)h->d_prep_status.p, nullptr, 1))) return rc;
+    h->prepared = true;
+    return DDMPC_OK;
+  }
+  if (h->large) return DDMPC_OK;          // ROBUST at this size: every step is a full solve
   HIP_TRY(hipSetDevice(h->device));
   const ddmpc_params& p = h->prm;
   const KParams& k = h->kp;
@@ -1024,12 +1059,13 @@ int ddmpc_step(ddmpc_handle* h, const double* u_past, const double* y_past, doub
                int32_t* status, int32_t* iters, int mem) {
   if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
   if (!h->have_data) return fail(DDMPC_ERR_NOT_READY, "ddmpc_set_data must be called before ddmpc_step");
-  if (h->large) return solve_impl(h, u_past, y_past, u_opt, cost, status, iters, mem, &launch_cold_plain);
+  if (h->large && !h->large_nominal) return solve_impl(h, u_past, y_past, u_opt, cost, status, iters, mem, &launch_cold_plain);
   if (!h->prepared) {
     int rc = ddmpc_prepare(h);
     if (rc) return rc;
   }
-  return solve_impl(h, u_past, y_past, u_opt, cost, status, iters, mem, &launch_warm_plain);
+  return solve_impl(h, u_past, y_past, u_opt, cost, status, iters, mem,
+                    h->large_nominal ? &launch_large_nominal_warm : &launch_warm_plain);
 }
 
 int ddmpc_get_gain(ddmpc_handle* h, double* out, int mem) {
@@ -1279,6 +1315,8 @@ int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps
   }
   const bool warm_ok = h->closed_loop_path != DDMPC_PATH_COLD &&
                        (size_t)n_mpc_step * m <= (size_t)WARM_MAX_NF && n * h->kp.nch <= WARM_MAX_NF;
+  const bool warm_large = h->large_nominal && h->closed_loop_path != DDMPC_PATH_COLD;   // per step, on the factors of ddmpc_prepare
+  if (warm_large && (rc = ddmpc_prepare(h))) return rc;
   bool warm = warm_ok && !h->kp.convex && !h->large;   // no inequality: fused loop, one launch
   const bool warm_box = warm_ok && h->kp.convex && !h->large;     // slack box: per step, affine iterate + cold re-solve where a bound is active
   if (warm_box && (rc = ddmpc_prepare(h))) return rc;
@@ -1330,6 +1368,7 @@ int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps
   auto enqueue_steps = [&]() -> int {
     for (int t = 0; !warm && t < n_steps; t += n_mpc_step) {
       int rcs = warm_box ? launch_warm(h, dup, dyp, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int32_t*)h->d_status.p, nullptr)
+                : warm_large ? launch_large_nominal_warm(h, dup, dyp, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int32_t*)h->d_status.p, nullptr)
                          : launch_cold_plain(h, dup, dyp, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int32_t*)h->d_status.p, nullptr);
       if (rcs) return rcs;
       const int nsub = (t + n_mpc_step <= n_steps) ? n_mpc_step : n_steps - t;

@@ -1193,8 +1193,154 @@ __device__ __forceinline__ void packed_schur_mfma(const double* Lm, int row0, in
 // products are formed from the chunk -- alpha_i = <window_i, x> by one 32-lane half wave per column (conflict-free
 // reads, shuffle reduction), then z += window_i * alpha_i with one thread per component.  `pan`: PSD_PAN doubles of LDS.
 // (alpha itself, c numbers, never leaves the chip.)
+// Register-blocked form for channel counts that divide the wave size (2, 4, 8, 16, 32: every shape of BASELINE.json).  Both
+// products are correlations along the time axis, so a thread that keeps FOUR consecutive positions of one channel in
+// registers needs one new trajectory entry per step instead of four:
+//   alpha_{i0+j} = sum_k sum_ch X[i0+j+k][ch] x[k nch + ch]     thread = (4 columns i0.., channel):   loop over k,  2 LDS loads per 4 FMAs,
+//                                                                then a shuffle sum over the nch lanes of a column group
+//   z[(k0+j) nch + ch] = sum_i X[i+k0+j][ch] alpha_i             thread = (4 offsets k0.., channel, a part of the i range): loop over i,
+//                                                                2 loads per 4 FMAs; accumulators live in registers across ALL chunks
+// (the one-column-per-half-wave form above moves 2 LDS loads per FMA: 38 MB of LDS traffic per call at the cfg-5 size, 320 us
+// measured; this form: 45 us).  The next chunk of the trajectory is fetched into registers while the current one is worked on.
+// Returns false (nothing done) for shapes it does not cover.
+__device__ __forceinline__ bool hankel_normal_times_blocked(const KParams& P, const double* __restrict__ ud,
+                                                            const double* __restrict__ yd, const double* x, double* z, double* pan) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int m = P.m, p = P.p, nch = P.nch, c = P.c, r = P.r, Ln = P.Ln;
+  if (nch < 2 || nch > 32 || (64 % nch) != 0) return false;
+  const int lg = 31 - __clz(nch);
+  const int KG = (Ln + 3) >> 2;                                          // groups of four time offsets
+  const int TC = ((PSD_PAN - (Ln + 3) * nch) / (nch + 1)) & ~3;           // columns per chunk: (TC + Ln + 3) rows + TC alphas
+  int NP = nthr / (KG * nch);                                            // parts of a chunk's column range in the z product
+  if (NP > PSD_PAN / (KG * 4 * nch)) NP = PSD_PAN / (KG * 4 * nch);        // (the parts meet in `pan` at the end)
+  constexpr int SR = 8;                                                  // staging registers per thread
+  const int nrows = TC + Ln + 3;
+  if (TC < 4 || NP < 1 || nrows * nch > SR * nthr) return false;         // (workgroup-uniform)
+  double* xc = pan;                                                      // xc[row][ch], row = time step - t0, nrows rows
+  double* al = pan + nrows * nch;                                        // alpha of the chunk
+  double stg[SR];
+  // (branch-free: one unconditional load per entry from an address that is always valid, zeroed afterwards where the entry
+  //  lies outside the trajectory -- with a branch per entry the loads of a chunk wait for one another)
+  auto fetch = [&](int t0) __attribute__((always_inline)) {
+    int tq = tid;
+    asm volatile("" : "+v"(tq));          // opaque per chunk: otherwise the SR source addresses are hoisted out of the chunk loop,
+                                          // spilled, and every load of the chunk waits for a scratch reload of its own address
+    const long long dyu = reinterpret_cast<const char*>(yd) - reinterpret_cast<const char*>(ud);   // (one flat address space)
+    double keep[SR];
+#pragma unroll
+    for (int e = 0; e < SR; ++e) {
+      int i = tq + e * nthr;
+      keep[e] = (i < nrows * nch && t0 + (i >> lg) < P.N) ? 1.0 : 0.0;
+      i = i < nrows * nch ? i : nrows * nch - 1;
+      const int t = t0 + (i >> lg), ch = i & (nch - 1);
+      const int tc = t < P.N ? t : P.N - 1;
+      const long long ou = ((long long)tc * m + ch) * 8, oy = dyu + ((long long)tc * p + (ch - m)) * 8;
+      const long long off = (ch < m) ? ou : oy;
+      stg[e] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ud) + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);                      // all SR loads are in flight before the first of them is touched
+#pragma unroll
+    for (int e = 0; e < SR; ++e) stg[e] *= keep[e];
+  };
+  // z product: this thread's (part, offset group, channel) and its four accumulators
+  const int zt = tid;
+  const bool zon = zt < NP * KG * nch;
+  const int zpart = zt / (KG * nch), zrem = zt - zpart * (KG * nch), zk0 = 4 * (zrem >> lg), zch = zrem & (nch - 1);
+  double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+  fetch(0);
+  for (int t0 = 0; t0 < c; t0 += TC) {
+    const int nt = (c - t0) < TC ? (c - t0) : TC;
+    __syncthreads();                                                      // previous chunk consumed
+#pragma unroll
+    for (int e = 0; e < SR; ++e) {
+      const int i = tid + e * nthr;
+      if (i < nrows * nch) xc[i] = stg[e];
+    }
+    __syncthreads();
+    fetch(t0 + TC);                                                       // in flight under the two products below
+    // ---- alpha of the chunk
+    const int ng = (nt + 3) >> 2;
+    for (int tb = 0; tb < ng * nch; tb += nthr) {                         // (whole waves take part in the shuffles)
+      const int t = tb + tid;
+      const bool on = t < ng * nch;
+      const int cg = on ? (t >> lg) : 0, ch = t & (nch - 1);
+      const double* wp = xc + (4 * cg) * nch + ch;
+      const double* xp = x + ch;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      double w0 = wp[0], w1 = wp[nch], w2 = wp[2 * nch];
+      int k = 0;
+      for (; k + 4 <= Ln; k += 4) {                                       // the window rotates through w0..w3
+        // (all eight loads of the four steps first: issued one pair at a time, every step waits a full LDS round trip)
+        const double n3 = wp[(k + 3) * nch], n4 = wp[(k + 4) * nch], n5 = wp[(k + 5) * nch], n6 = wp[(k + 6) * nch];
+        const double x0 = xp[k * nch], x1 = xp[(k + 1) * nch], x2 = xp[(k + 2) * nch], x3 = xp[(k + 3) * nch];
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = fma(w0, x0, a0); a1 = fma(w1, x0, a1); a2 = fma(w2, x0, a2); a3 = fma(n3, x0, a3);
+        a0 = fma(w1, x1, a0); a1 = fma(w2, x1, a1); a2 = fma(n3, x1, a2); a3 = fma(n4, x1, a3);
+        a0 = fma(w2, x2, a0); a1 = fma(n3, x2, a1); a2 = fma(n4, x2, a2); a3 = fma(n5, x2, a3);
+        a0 = fma(n3, x3, a0); a1 = fma(n4, x3, a1); a2 = fma(n5, x3, a2); a3 = fma(n6, x3, a3);
+        w0 = n4; w1 = n5; w2 = n6;
+      }
+      for (; k < Ln; ++k) {
+        const double w3 = wp[(k + 3) * nch];
+        const double xv = xp[k * nch];
+        a0 = fma(w0, xv, a0); a1 = fma(w1, xv, a1); a2 = fma(w2, xv, a2); a3 = fma(w3, xv, a3);
+        w0 = w1; w1 = w2; w2 = w3;
+      }
+      if (!on) { a0 = 0.0; a1 = 0.0; a2 = 0.0; a3 = 0.0; }
+      for (int off = nch >> 1; off > 0; off >>= 1) {
+        a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64); a2 += __shfl_xor(a2, off, 64); a3 += __shfl_xor(a3, off, 64);
+      }
+      if (on && ch == 0) { al[4 * cg] = a0; al[4 * cg + 1] = a1; al[4 * cg + 2] = a2; al[4 * cg + 3] = a3; }   // (4 cg + 3 < TC: TC is a multiple of 4)
+    }
+    __syncthreads();
+    // ---- z += H[:, chunk] alpha[chunk]
+    if (zon) {
+      const int per = (nt + NP - 1) / NP;
+      const int ia = zpart * per;
+      const int ib = (ia + per) < nt ? (ia + per) : nt;
+      if (ia < ib) {
+        const double* wp = xc + (ia + zk0) * nch + zch;
+        double w0 = wp[0], w1 = wp[nch], w2 = wp[2 * nch];
+        int i = ia;
+        const double* ap = al + ia;
+        int q = 0;
+        for (; i + 4 <= ib; i += 4, q += 4) {
+          const double n3 = wp[(q + 3) * nch], n4 = wp[(q + 4) * nch], n5 = wp[(q + 5) * nch], n6 = wp[(q + 6) * nch];
+          const double v0 = ap[q], v1 = ap[q + 1], v2 = ap[q + 2], v3 = ap[q + 3];
+          __builtin_amdgcn_sched_barrier(0);
+          z0 = fma(w0, v0, z0); z1 = fma(w1, v0, z1); z2 = fma(w2, v0, z2); z3 = fma(n3, v0, z3);
+          z0 = fma(w1, v1, z0); z1 = fma(w2, v1, z1); z2 = fma(n3, v1, z2); z3 = fma(n4, v1, z3);
+          z0 = fma(w2, v2, z0); z1 = fma(n3, v2, z1); z2 = fma(n4, v2, z2); z3 = fma(n5, v2, z3);
+          z0 = fma(n3, v3, z0); z1 = fma(n4, v3, z1); z2 = fma(n5, v3, z2); z3 = fma(n6, v3, z3);
+          w0 = n4; w1 = n5; w2 = n6;
+        }
+        for (; i < ib; ++i, ++q) {
+          const double w3 = wp[(q + 3) * nch];
+          const double av = ap[q];
+          z0 = fma(w0, av, z0); z1 = fma(w1, av, z1); z2 = fma(w2, av, z2); z3 = fma(w3, av, z3);
+          w0 = w1; w1 = w2; w2 = w3;
+        }
+      }
+    }
+  }
+  __syncthreads();                                                        // the last chunk is consumed: `pan` takes the parts
+  if (zon) {
+    double* zp = pan + zpart * (KG * 4 * nch) + zk0 * nch + zch;
+    zp[0] = z0; zp[nch] = z1; zp[2 * nch] = z2; zp[3 * nch] = z3;
+  }
+  __syncthreads();
+  for (int rho = tid; rho < r; rho += nthr) {
+    double sacc = 0.0;
+    for (int q = 0; q < NP; ++q) sacc += pan[q * (KG * 4 * nch) + rho];
+    z[rho] = sacc;
+  }
+  __syncthreads();
+  return true;
+}
+
 __device__ __forceinline__ void hankel_normal_times(const KParams& P, const double* __restrict__ ud,
                                                     const double* __restrict__ yd, const double* x, double* z, double* pan) {
+  if (hankel_normal_times_blocked(P, ud, yd, x, z, pan)) return;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int hw = tid >> 5, t32 = tid & 31, nhw = nthr >> 5;
   const int m = P.m, p = P.p, nch = P.nch, c = P.c, r = P.r;
@@ -1355,7 +1501,46 @@ __device__ __forceinline__ double block_max(double v, double* red) {
   return t;
 }
 
-__global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int RPs, const double* __restrict__ u_d,
+#ifndef DDMPC_RR_WAVES
+#define DDMPC_RR_WAVES 4
+#endif
+// Stable partition of the components 0 .. r-1 by class (cls(rho) in 0 .. NC-1, anything else: dropped): perm[position] = rho
+// with class 0 first and the component order kept inside a class; cnt[k] = members of class k.  Every thread scans the
+// class table (r ints of LDS scratch `kcl`, broadcast reads) for its own components: O(r) per thread, all in parallel --
+// a single thread walking the table costs one dependent L2 round trip per component (1.1 ms for 608 rows, measured).
+template <int NC, class ClsF>
+__device__ __forceinline__ void stable_partition(int r, ClsF&& cls, int* perm, int* kcl, int* cnt) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int i = tid; i < r; i += nthr) kcl[i] = cls(i);
+  __syncthreads();
+  for (int rho = tid; rho < r; rho += nthr) {
+    const int c = kcl[rho];
+    int tot[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) tot[k] = 0;
+    int before = 0;
+    for (int j = 0; j < r; ++j) {
+      const int cj = kcl[j];
+#pragma unroll
+      for (int k = 0; k < NC; ++k) tot[k] += (cj == k) ? 1 : 0;
+      before += (cj == c && j < rho) ? 1 : 0;
+    }
+    if (c >= 0 && c < NC) {
+      int off = before;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) off += (k < c) ? tot[k] : 0;
+      perm[off] = rho;
+    }
+    if (rho == 0) {
+#pragma unroll
+      for (int k = 0; k < NC; ++k) cnt[k] = tot[k];
+    }
+  }
+  __syncthreads();
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, DDMPC_RR_WAVES) void ddmpc_nominal_rr_kernel(KParams P, int RPs, const double* __restrict__ u_d,
                                                                const double* __restrict__ y_d,
                                                                const double* __restrict__ u_past,
                                                                const double* __restrict__ y_past,
@@ -1364,7 +1549,16 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
                                                                double rank_tol, double feas_tol, double* scratch,
                                                                long long scratch_stride, double* w_ws,
                                                                unsigned long long* dbg, double* __restrict__ z_ws,
-                                                               int* __restrict__ rescued, double* __restrict__ x_ws) {
+                                                               int* __restrict__ rescued, double* __restrict__ x_ws,
+                                                               int* __restrict__ meta_ws) {
+  // MODE: 0 = the whole solve in one launch (matrices in LDS: the four-tank sizes); with the matrices in the global
+  // workspace the solve is two launches -- 1 = the part that depends on the DATA alone (Gram, its rank-revealing factor,
+  // the reduced normal matrix C'WC and its factor), 2 = a solve on the factors a MODE-1 launch left in the workspace --
+  // so that (a) ddmpc_prepare / ddmpc_step repeat only the second one while the data stand (only the past window changes
+  // between control steps, controller.py:389-407; the factorisations are 60 % of a solve of this size), and (b) each half
+  // gets a register allocation of its own (as one kernel: 413 spilled VGPRs, 884 B of scratch per lane).  The pivot
+  // pattern of both factors and the live column counts travel in meta_ws (2 rv + 2 ints per instance).
+  constexpr int mode = MODE;
   extern __shared__ __attribute__((aligned(16))) double rsm_lds[];
   const long long b = blockIdx.x;
   if (status[b] != 4) return;                           // uniform: only instances the fast path gave up on
@@ -1394,7 +1588,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   double* G = rsm;                                      // r(r+1)/2
   double* T = G + r * (r + 1) / 2;                      // nR(nR+1)/2
   __shared__ double red[16];
-  __shared__ int cnt[2];
+  __shared__ int cnt4[4];
   const double* ud = u_d + b * (long long)P.N * m;
   const double* yd = y_d + b * (long long)P.N * p;
   const double* up = u_past + b * (long long)P.npu;
@@ -1404,34 +1598,23 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   // them: with exact data the outputs are the dependent rows (beyond the few that pin the state), so the rows without a
   // pivot gather at the end of each block -- the tail of the free block is then one dead stretch at which the
   // factorisation stops early (packed_psd_cholesky), and everything downstream works on the leading `nlive` columns.
-  if (tid == 0) {
-    int nF = 0;
-    for (int pass = 0; pass < 2; ++pass)
-      for (int rho = 0; rho < r; ++rho) {
-        const int kind = P.tabi[0 * RPs + rho];
-        if (kind == (pass == 0 ? K_UFIX : K_YFIX)) {
-          const int pidx = P.tabi[1 * RPs + rho];
-          perm[nF] = rho;
-          fv[nF] = (pidx >= 0) ? ((pidx < P.npu) ? up[pidx] : yp[pidx - P.npu]) : P.tabd[2 * RPs + rho];
-          ++nF;
-        }
-      }
-    int nR = 0;
-    for (int pass = 0; pass < 2; ++pass)
-      for (int rho = 0; rho < r; ++rho) {
-        const int kind = P.tabi[0 * RPs + rho];
-        if (kind == (pass == 0 ? K_UFREE : K_YFREE)) {
-          perm[nF + nR] = rho;
-          wv[nR] = P.tabd[3 * RPs + rho];
-          zs[nR] = P.tabd[2 * RPs + rho];
-          ++nR;
-        }
-      }
-    cnt[0] = nF; cnt[1] = nR;
+  stable_partition<4>(r, [&](int rho) {
+    const int kind = P.tabi[0 * RPs + rho];
+    return kind == K_UFIX ? 0 : kind == K_YFIX ? 1 : kind == K_UFREE ? 2 : kind == K_YFREE ? 3 : -1;
+  }, perm, iperm, cnt4);
+  const int nF = cnt4[0] + cnt4[1], nR = cnt4[2] + cnt4[3];
+  for (int i = tid; i < nF + nR; i += nthr) {
+    const int rho = perm[i];
+    if (i < nF) {
+      const int pidx = P.tabi[1 * RPs + rho];
+      fv[i] = (pidx >= 0) ? ((pidx < P.npu) ? up[pidx] : yp[pidx - P.npu]) : P.tabd[2 * RPs + rho];
+    } else {
+      wv[i - nF] = P.tabd[3 * RPs + rho];
+      zs[i - nF] = P.tabd[2 * RPs + rho];
+    }
   }
   __syncthreads();
-  const int nF = cnt[0], nR = cnt[1];
-  if (dbg && tid == 0) dbg[b * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+  if (dbg && tid == 0) dbg[b * 16 + 0] = __builtin_amdgcn_s_memrealtime();
   // ---- Gram in the permuted order: G(i,j) = sum_t x_{perm i}[t] x_{perm j}[t] ----------------
   // Hankel structure (as in the cold kernel): with components (k, a) = (time offset, channel),
   //   G((k+d, a), (k, b)) = C_d(a,b) + sum_{j<k} ( x_a[j+c+d] x_b[j+c] - x_a[j+d] x_b[j] ),   C_d(a,b) = sum_{t<c} x_a[t+d] x_b[t],
@@ -1439,6 +1622,9 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   // The lag table borrows the (not yet used) storage of T; if it does not fit there, plain dot products are used.
   const int npk = r * (r + 1) / 2;
   const int nlag = P.Ln * nch * nch;
+  int* meta = meta_ws ? meta_ws + b * (long long)(2 * rv + 2) : nullptr;
+  int nlive = 0, nRl = 0;
+  if constexpr (MODE != 2) {
   if (nlag <= nR * (nR + 1) / 2) {
     for (int i = tid; i < r; i += nthr) iperm[perm[i]] = i;
     hankel_gram_packed(P, ud, yd, G, T, iperm, pan);
@@ -1458,7 +1644,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
     }
   }
   __syncthreads();
-  if (dbg && tid == 0) dbg[b * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+  if (dbg && tid == 0) dbg[b * 16 + 1] = __builtin_amdgcn_s_memrealtime();
   double dmx = 0.0;
   for (int i = tid; i < r; i += nthr) dmx = fmax(dmx, G[i * (i + 1) / 2 + i]);
 #pragma unroll
@@ -1468,39 +1654,60 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   double dmax = 0.0;
   for (int w = 0; w < (nthr >> 6); ++w) dmax = fmax(dmax, red[w]);
   __syncthreads();
-  const int nlive = packed_psd_cholesky(G, r, rank_tol * dmax, skip, pan, -1, true);      // columns >= nlive are zero
-  const int nRl = (nlive > nF) ? ((nlive - nF) < nR ? (nlive - nF) : nR) : 0;                 // live columns of the free block
-  if (dbg && tid == 0) dbg[b * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+  nlive = packed_psd_cholesky(G, r, rank_tol * dmax, skip, pan, -1, true);                // columns >= nlive are zero
+  nRl = (nlive > nF) ? ((nlive - nF) < nR ? (nlive - nF) : nR) : 0;                           // live columns of the free block
+  } else {
+    for (int i = tid; i < r; i += nthr) skip[i] = meta[i];
+    nlive = meta[2 * rv]; nRl = meta[2 * rv + 1];
+    if (dbg && tid == 0) dbg[b * 16 + 1] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+  }
+  if (dbg && tid == 0) dbg[b * 16 + 2] = __builtin_amdgcn_s_memrealtime();
   // ---- hard constraints: L_FF w = f (skipped pivots carry no unknown); residual of the dependent rows ----
+  double resid = 0.0, fmaxv = 1.0;
+  if constexpr (MODE != 1) {
   packed_forward_substitute(G, nF, fv, col, skip, red);
   packed_rows_times(G, 0, nF, 0, col, [&](int i) { return i; },
                     [&](int i, double sacc) { vv[i] = skip[i] ? fabs(fv[i] - sacc) : 0.0; });   // what a dependent constraint row is off by
   __syncthreads();
-  double resid = 0.0, fmaxv = 1.0;
   for (int k = 0; k < nF; ++k) { resid = fmax(resid, vv[k]); fmaxv = fmax(fmaxv, fabs(fv[k])); }
   // ---- z0 = L_RF w ------------------------------------------------------------------------------
   packed_rows_times(G, nF, nR, 0, col, [&](int) { return nF; }, [&](int i, double sacc) { z0[i] = sacc; });
   __syncthreads();
-  if (dbg && tid == 0) dbg[b * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+  }
+  if (dbg && tid == 0) dbg[b * 16 + 3] = __builtin_amdgcn_s_memrealtime();
   // ---- reduced normal equations T = C' W C, rhs = C' W (zs - z0), C(i,a) = L(nF+i, nF+a), i >= a ----
-  packed_weighted_gram_mfma(G, nF, nR, wv, skip + nF, T, nRl);
-  for (int i = tid; i < nR; i += nthr) ra[i] = wv[i] * (zs[i] - z0[i]);
-  for (int a = nRl + tid; a < nR; a += nthr) { vv[a] = 0.0; skipT[a] = 1; }                  // dead tail of the free block
+  if constexpr (MODE != 2) packed_weighted_gram_mfma(G, nF, nR, wv, skip + nF, T, nRl);
+  if (mode != 1) { for (int i = tid; i < nR; i += nthr) ra[i] = wv[i] * (zs[i] - z0[i]); }
+  for (int a = tid; a < nR; a += nthr) {
+    if (a >= nRl) { vv[a] = 0.0; skipT[a] = 1; }                                             // dead tail of the free block
+    else if (mode == 2) skipT[a] = meta[rv + a];
+  }
   __syncthreads();
+  if constexpr (MODE != 1) {
   packed_cols_times(G, nF, nR, nF, nRl, [&](int a) { return a; }, [&](int i) { return ra[i]; },
                     [&](int a, double sacc) { vv[a] = skip[nF + a] ? 0.0 : sacc; });
   __syncthreads();
-  if (dbg && tid == 0) dbg[b * 8 + 4] = __builtin_amdgcn_s_memrealtime();
-  double tmx = 0.0;
-  for (int a = 0; a < nRl; ++a) tmx = fmax(tmx, T[a * (a + 1) / 2 + a]);
-  packed_psd_cholesky(T, nRl, 1e-14 * tmx, skipT, pan);
-  if (dbg && tid == 0) dbg[b * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+  }
+  if (dbg && tid == 0) dbg[b * 16 + 4] = __builtin_amdgcn_s_memrealtime();
+  if constexpr (MODE != 2) {
+    double tmx = 0.0;
+    for (int a = 0; a < nRl; ++a) tmx = fmax(tmx, T[a * (a + 1) / 2 + a]);
+    packed_psd_cholesky(T, nRl, 1e-14 * tmx, skipT, pan);
+    if (meta) {                                          // what a later mode-2 launch needs besides the two factors
+      for (int i = tid; i < r; i += nthr) meta[i] = skip[i];
+      for (int a = tid; a < nR; a += nthr) meta[rv + a] = skipT[a];
+      if (tid == 0) { meta[2 * rv] = nlive; meta[2 * rv + 1] = nRl; }
+    }
+  }
+  if (dbg && tid == 0) dbg[b * 16 + 5] = __builtin_amdgcn_s_memrealtime();
+  if constexpr (MODE == 1) return;                       // factors only (the status word stays as it is: MODE 2 follows)
   // ---- T v = rhs by the factor ------------------------------------------------------------------------------
   packed_forward_substitute(T, nRl, vv, rb, skipT, red);
   packed_back_substitute(T, nRl, rb, ra, skipT);          // w2; col keeps w1 for the refinement step
   for (int a = tid; a < nR; a += nthr) vv[a] = (a < nRl) ? ra[a] : 0.0;
   __syncthreads();
-  if (dbg && tid == 0) dbg[b * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+  if (dbg && tid == 0) dbg[b * 16 + 6] = __builtin_amdgcn_s_memrealtime();
   // ---- one step of iterative refinement on the KKT system of the problem in the coordinates w of
   //        z = B w,   B = H H_I' L_I^-T   (H_I: the rows with a pivot; B equals L up to the rounding of the Gram route):
   //        min (B_R w - zs)' W (B_R w - zs)   s.t.  B_F w = f,   multipliers mu on the independent fixed rows.
@@ -1512,7 +1719,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   __syncthreads();
   // The pass is repeated while it still pays: the correction of pass k is applied through the rounded factors, so the
   // error left behind is about (relative size of that correction) x (relative accuracy of the factors ~ size of the FIRST
-  // correction); another pass is made while that product is above 1e-11 (cap P.refine_max, at least one pass).
+  // correction); another pass is made while that product is above 1e-10 (cap P.refine_max, at least one pass).
   double rel0 = 0.0, prevrel = 1e300;
   for (int pass = 0;; ++pass) {
   for (int a = tid; a < nR; a += nthr) vv[a] = wk[nF + a];             // w2 of this pass ((b) below reads it)
@@ -1520,10 +1727,12 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   for (int k = tid; k < r; k += nthr) { ra[k] = wk[k]; if (k >= nlive) rb[k] = 0.0; }
   __syncthreads();
   packed_back_substitute(G, nlive, ra, rb, skip);                     // (rows without a pivot carry no unknown: zero)
+  if (dbg && tid == 0 && pass == 0) dbg[b * 16 + 8] = __builtin_amdgcn_s_memrealtime();   // (diagnostics: first refinement pass)
   for (int k = tid; k < r; k += nthr) ra[perm[k]] = rb[k];           // component order
   __syncthreads();
   hankel_normal_times(P, ud, yd, ra, rd, pan);
   for (int k = tid; k < r; k += nthr) rz[k] = rd[perm[k]];           // z_ex in position order
+  if (dbg && tid == 0 && pass == 0) dbg[b * 16 + 9] = __builtin_amdgcn_s_memrealtime();   // (diagnostics: first refinement pass)
   // (b) multipliers of the starting point: L_FF' mu = -L_RF' W (z_R - zs), z_R = z0 + C w2 (the unrefined solution)
   packed_rows_times(G, nF, nR, nF, vv, [&](int i) { return (nF + i + 1) < nlive ? (nF + i + 1) : nlive; },
                     [&](int i, double sacc) { rb[nF + i] = wv[i] * (z0[i] + sacc - zs[i]); });
@@ -1532,6 +1741,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
                     [&](int k, double sacc) { ra[k] = -sacc; });
   __syncthreads();
   packed_back_substitute(G, nF, ra, rd, skip);                          // mu -> rd[0..nF)
+  if (dbg && tid == 0 && pass == 0) dbg[b * 16 + 10] = __builtin_amdgcn_s_memrealtime();   // (diagnostics: first refinement pass)
   // (c) residual of the stationarity rows: rw = -B' v,  v = [mu on the independent fixed rows ; W (z_ex,R - zs)]
   for (int k = tid; k < r; k += nthr) rb[k] = (k < nF) ? (skip[k] ? 0.0 : rd[k]) : wv[k - nF] * (rz[k] - zs[k - nF]);
   __syncthreads();
@@ -1539,20 +1749,25 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   __syncthreads();
   hankel_normal_times(P, ud, yd, ra, rd, pan);
   for (int k = tid; k < r; k += nthr) rb[k] = rd[perm[k]];
+  if (dbg && tid == 0 && pass == 0) dbg[b * 16 + 11] = __builtin_amdgcn_s_memrealtime();   // (diagnostics: first refinement pass)
   __syncthreads();
   for (int k = nlive + tid; k < r; k += nthr) ra[k] = 0.0;
   packed_forward_substitute(G, nlive, rb, ra, skip, red);                // ra = L_I^-1 (H_I H' v) = -rw
+  if (dbg && tid == 0 && pass == 0) dbg[b * 16 + 12] = __builtin_amdgcn_s_memrealtime();   // (diagnostics: first refinement pass)
   // (d) correction with the factors at hand:  dw1 = L_FF^-1 (f - z_ex,F);  T dw2 = rw2 - C' W L_RF dw1
   for (int k = tid; k < nF; k += nthr) rd[k] = fv[k] - rz[k];
   __syncthreads();
   packed_forward_substitute(G, nF, rd, rb, skip, red);                   // dw1 -> rb[0..nF)
+  if (dbg && tid == 0 && pass == 0) dbg[b * 16 + 13] = __builtin_amdgcn_s_memrealtime();   // (diagnostics: first refinement pass)
   packed_rows_times(G, nF, nR, 0, rb, [&](int) { return nF; }, [&](int i, double sacc) { rd[nF + i] = sacc; });   // L_RF dw1
   __syncthreads();
   packed_cols_times(G, nF, nR, nF, nRl, [&](int a) { return a; }, [&](int i) { return wv[i] * rd[nF + i]; },
                     [&](int a, double sacc) { vv[a] = skip[nF + a] ? 0.0 : -ra[nF + a] - sacc; });              // rhs of the T system
   __syncthreads();
   packed_forward_substitute(T, nRl, vv, col, skipT, red);                // col: work vector (w lives in wk)
+  if (dbg && tid == 0 && pass == 0) dbg[b * 16 + 14] = __builtin_amdgcn_s_memrealtime();   // (diagnostics: first refinement pass)
   packed_back_substitute(T, nRl, col, vv, skipT);                        // dw2 -> vv
+  if (dbg && tid == 0 && pass == 0) dbg[b * 16 + 15] = __builtin_amdgcn_s_memrealtime();   // (diagnostics: first refinement pass)
   for (int a = nRl + tid; a < nR; a += nthr) vv[a] = 0.0;
   __syncthreads();
   // size of this correction relative to w; decide whether another pass pays
@@ -1563,7 +1778,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
   }
   const double rel = block_max(dmx, red) / fmax(block_max(wmx, red), 1e-300);
   if (pass == 0) rel0 = rel;
-  const bool more_passes = (pass + 1 < P.refine_max) && (rel * rel0 > 1e-11) && (rel < 0.25 * prevrel);
+  const bool more_passes = (pass + 1 < P.refine_max) && (rel * rel0 > 1e-10) && (rel < 0.25 * prevrel);
   __syncthreads();
   if (!more_passes) break;
   prevrel = rel;
@@ -1609,7 +1824,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_nominal_rr_kernel(KParams P, int
     const bool feasible = resid <= feas_tol * fmaxv;
     status[b] = !(fabs(tot) < 1e300) ? 4 : (feasible ? 0 : 2);      // 2 = "infeasible"
     if (iters) iters[b] = 1;
-    if (dbg) dbg[b * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+    if (dbg) dbg[b * 16 + 7] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -1655,24 +1870,15 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
   double* G = scratch + b * scratch_stride;             // Gram -> [L_AA; L_BA] in its first nA columns
   __shared__ double red[16];
   __shared__ int flag[1];
-  __shared__ int cnt[1];
+  __shared__ int cnt[2];
   const double* ud = u_d + b * (long long)P.N * m;
   const double* yd = y_d + b * (long long)P.N * p;
   const double* up = u_past + b * (long long)P.npu;
   const double* yp = y_past + b * (long long)(n * p);
-  if (tid == 0) {                                       // elimination order: boxed components last
-    int na = 0;
-    for (int rho = 0; rho < r; ++rho) {
-      const int kind = P.tabi[0 * RPs + rho];
-      if (!(P.convex && (kind == K_WPRED || kind == K_WTERM))) perm[na++] = rho;
-    }
-    cnt[0] = na;
-    for (int rho = 0; rho < r; ++rho) {
-      const int kind = P.tabi[0 * RPs + rho];
-      if (P.convex && (kind == K_WPRED || kind == K_WTERM)) perm[na++] = rho;
-    }
-  }
-  __syncthreads();
+  stable_partition<2>(r, [&](int rho) {                   // elimination order: boxed components last
+    const int kind = P.tabi[0 * RPs + rho];
+    return (P.convex && (kind == K_WPRED || kind == K_WTERM)) ? 1 : 0;
+  }, perm, skip, cnt);
   const int nA = cnt[0], nB = r - nA;
   const int npB = nB * (nB + 1) / 2;
   double* S = G + npk;                                  // Schur complement of the B block (without lam*D_B)

@@ -164,3 +164,62 @@ def test_auto_refinement_threshold_extremes(gpu):
     assert np.array_equal(out["all"][0], out["always"][0]) and np.array_equal(out["all"][1], out["always"][1])
     assert not np.array_equal(out["always"][0], out["off"][0])                   # refinement does change the last bits
     assert np.max(np.abs(out["always"][0] - out["off"][0])) < 1e-10 * np.max(np.abs(out["off"][0]))
+
+
+# ------------------------------------------------------------------ warm steps beyond the register-resident kernels (NOMINAL)
+def test_large_nominal_warm_step_reuses_the_factors(gpu):
+    # cfg-5-like shape (m = p = 8, n = 8, L = 30: 608 rows, exact data): ddmpc_prepare forms everything that depends on the
+    # data alone (Gram, its rank-revealing factor, C'WC and its factor) once; ddmpc_step then runs the substitutions and
+    # the refinement passes on those factors -- the same arithmetic as a full solve, so the results must be BIT-equal to
+    # ddmpc_solve's for every past window, before and after a change of the data set
+    B = 6
+    spec, plant, N, d, up, yp = _config5(B)
+    # a consistent second past window: the last n steps of ANOTHER stretch of the same trajectory
+    n = spec.n
+    up2 = d["u_d"][:, 100:100 + n, :].reshape(B, -1).copy(); yp2 = d["y_d"][:, 100:100 + n, :].reshape(B, -1).copy()
+    d2 = harness.generate_batch(range(50, 50 + B), N=N, plant=plant)
+    with _spec_engine(spec, N, B) as eng:
+        eng.set_data(d["u_d"], d["y_d"])
+        cold1 = tuple(x.copy() for x in eng.solve(up, yp))
+        cold2 = tuple(x.copy() for x in eng.solve(up2, yp2))
+        eng.prepare()
+        warm2 = tuple(x.copy() for x in eng.step(up2, yp2))
+        ub_w = eng.get_solution("ubar"); al_w = eng.get_solution("alpha")
+        warm1 = tuple(x.copy() for x in eng.step(up, yp))
+        assert np.all(cold1[2] == 0) and np.all(cold2[2] == 0)
+        for c, w in ((cold1, warm1), (cold2, warm2)):
+            assert np.array_equal(c[0], w[0]) and np.array_equal(c[1], w[1]) and np.array_equal(c[2], w[2])
+        assert not np.array_equal(cold1[0], cold2[0])
+        assert np.array_equal(ub_w[:, n * spec.m:], warm2[0]) and np.all(np.isfinite(al_w))
+        # new data: the factors are dropped with the data they belong to
+        eng.set_data(d2["u_d"], d2["y_d"])
+        upn = d2["u_d"][:, -n:, :].reshape(B, -1).copy(); ypn = d2["y_d"][:, -n:, :].reshape(B, -1).copy()
+        warm_new = tuple(x.copy() for x in eng.step(upn, ypn))          # prepares on first use
+        cold_new = tuple(x.copy() for x in eng.solve(upn, ypn))
+        assert np.array_equal(warm_new[0], cold_new[0]) and np.array_equal(warm_new[1], cold_new[1])
+        assert not np.array_equal(warm_new[0], warm1[0])
+    # and the warm results are right: against the model-based solution
+    from oracle.nominal_exact import solve_nominal_model_based
+    for b in range(B):
+        mod = solve_nominal_model_based(spec, plant, up2[b], yp2[b])
+        assert np.max(np.abs(warm2[0][b] - mod["optimal_u"])) / np.max(np.abs(mod["optimal_u"])) < TOL_U
+        assert abs(warm2[1][b] - mod["cost"]) <= TOL_COST * abs(mod["cost"])
+
+
+def test_large_nominal_closed_loop_warm_equals_cold(gpu):
+    # the per-step closed loop of a NOMINAL controller at that size: with the factors of ddmpc_prepare (default path) and with a
+    # full solve per step (DDMPC_PATH_COLD) the trajectories must be bit-equal
+    B, n_steps = 4, 24
+    spec, plant, N, d, up, yp = _config5(B)
+    w = np.zeros((B, n_steps, spec.p))
+    out = {}
+    for path in ("auto", "cold"):
+        with _spec_engine(spec, N, B) as eng:
+            eng.set_data(d["u_d"], d["y_d"])
+            eng.set_closed_loop_path(path)
+            out[path] = eng.closed_loop(plant["A"], plant["B"], plant["C"], plant["D"], d["x_end"], up, yp, w, n_mpc_step=1)
+    for a, b in zip(out["auto"], out["cold"]):
+        assert np.array_equal(a, b)
+    u_sys, y_sys, status = out["auto"][:3]
+    assert np.all(status == 0)
+    assert np.max(np.abs(y_sys[:, -1, :] - spec.y_s)) < np.max(np.abs(y_sys[:, 0, :] - spec.y_s))      # it is heading for the setpoint

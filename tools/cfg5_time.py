@@ -1,7 +1,7 @@
 """Timing only (no oracle, no worker processes: safe under rocprofv3) of the BASELINE configs[4] problem on
 ddmpc_nominal_rr_kernel, or with --robust of the same size with the ROBUST scheme + slack box on ddmpc_large_solve_kernel.
 
-    python tools/cfg5_time.py [--robust] [--steps 5]
+    python tools/cfg5_time.py [--robust] [--steps 5] [--warm]
 
 Prints ms per batch, solves/s and the algorithmic TFLOP/s against the fp64-MFMA peak (flop model below).  Parity at this
 size is tools/config5_check.py and the GPU tests."""
@@ -34,6 +34,8 @@ def large_flops(m, p, n, Lh, N, robust, iters=1.0, passes=1):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser(); ap.add_argument("--robust", action="store_true"); ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--warm", action="store_true", help="also time ddmpc_prepare and ddmpc_step (NOMINAL: solves on the factors kept "
+                    "from ddmpc_prepare)")
     a = ap.parse_args()
     rng = np.random.default_rng(0)
     ns = n = 8; m = p = 8; Lh = 30; N = 2000; B = a.batch
@@ -66,3 +68,19 @@ if __name__ == "__main__":
     print("%s B=%d: %.2f ms per batch, %.3e solves/s; status ok %s; %.1f MFLOP per solve (algorithmic) -> %.2f TFLOP/s = %.3f of the "
           "%.1f TF fp64-MFMA peak" % (eng.kernel_name(), B, ms, rate, bool((out[2] == 0).all()), fl / 1e6, rate * fl / 1e12,
                                       rate * fl / 1e12 / PEAK_TF, PEAK_TF))
+    if a.warm and not a.robust:
+        torch.cuda.synchronize()
+        e0.record()
+        eng.prepare()
+        e1.record(); torch.cuda.synchronize()
+        prep_ms = e0.elapsed_time(e1)
+        w = eng.step(up, yp)
+        same = bool((w[0] == out[0]).all() and (w[1] == out[1]).all())
+        eng.step(up, yp, *w)
+        e0.record()
+        for _ in range(a.steps):
+            eng.step(up, yp, *w)
+        e1.record(); torch.cuda.synchronize()
+        wms = e0.elapsed_time(e1) / a.steps
+        print("warm: ddmpc_prepare %.2f ms once per data set; ddmpc_step %.2f ms per batch, %.3e steps/s (bit-equal to ddmpc_solve: %s)"
+              % (prep_ms, wms, B / wms * 1e3, same))
