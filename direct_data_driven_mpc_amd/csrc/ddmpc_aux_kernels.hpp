@@ -759,9 +759,10 @@ __device__ __forceinline__ int packed_psd_cholesky(double* A, int n, double tol_
       }
       // ---- update with the columns factored so far -------------------------------------------------------
       for (int j0 = 0; j0 < k0; j0 += 16) {
+        // (all loads of the chunk unconditional and independent of one another -- pb is clamped to a valid row -- so that they
+        //  share ONE memory round trip: with b0 = a0 as the fall-back the compiler waited for a0 before it issued the rest)
         const d2u8 a0 = *reinterpret_cast<const d2u8*>(pa + j0), a1 = *reinterpret_cast<const d2u8*>(pa + j0 + 2);
-        d2u8 b0 = a0, b1 = a1;
-        if (nbb > 0) { b0 = *reinterpret_cast<const d2u8*>(pb + j0); b1 = *reinterpret_cast<const d2u8*>(pb + j0 + 2); }
+        const d2u8 b0 = *reinterpret_cast<const d2u8*>(pb + j0), b1 = *reinterpret_cast<const d2u8*>(pb + j0 + 2);
         // every load of the chunk is issued before the first MFMA (row pointers of idle slots are clamped to a valid
         // row): one memory round trip per 16 columns, not one per row tile
         d2u8 x0[PSD_TG], x1[PSD_TG];
@@ -1584,7 +1585,9 @@ __global__ __launch_bounds__(512, DDMPC_RR_WAVES) void ddmpc_nominal_rr_kernel(K
   int* skipT = skip + rv;
   int* iperm = skipT + rv;                              // component -> position in the fixed-first order
   double* pan = reinterpret_cast<double*>(iperm + rv);                 // PSD_PAN doubles: scratch of the Cholesky / Gram (always LDS)
-  double* rsm = scratch ? scratch + b * scratch_stride : pan + PSD_PAN;
+  double* rsm;
+  if constexpr (MODE == 0) rsm = scratch ? scratch + b * scratch_stride : pan + PSD_PAN;
+  else rsm = scratch + b * scratch_stride;                // (a kernel-argument pointer: the matrices are addressed with global, not flat, loads)
   double* G = rsm;                                      // r(r+1)/2
   double* T = G + r * (r + 1) / 2;                      // nR(nR+1)/2
   __shared__ double red[16];
