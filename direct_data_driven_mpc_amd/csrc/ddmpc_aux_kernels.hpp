@@ -1722,7 +1722,7 @@ __global__ __launch_bounds__(512, DDMPC_RR_WAVES) void ddmpc_nominal_rr_kernel(K
   __syncthreads();
   // The pass is repeated while it still pays: the correction of pass k is applied through the rounded factors, so the
   // error left behind is about (relative size of that correction) x (relative accuracy of the factors ~ size of the FIRST
-  // correction); another pass is made while that product is above 1e-10 (cap P.refine_max, at least one pass).
+  // correction); another pass is made while that product is above 1e-9 (cap P.refine_max, at least one pass).
   double rel0 = 0.0, prevrel = 1e300;
   for (int pass = 0;; ++pass) {
   for (int a = tid; a < nR; a += nthr) vv[a] = wk[nF + a];             // w2 of this pass ((b) below reads it)
@@ -1781,7 +1781,7 @@ __global__ __launch_bounds__(512, DDMPC_RR_WAVES) void ddmpc_nominal_rr_kernel(K
   }
   const double rel = block_max(dmx, red) / fmax(block_max(wmx, red), 1e-300);
   if (pass == 0) rel0 = rel;
-  const bool more_passes = (pass + 1 < P.refine_max) && (rel * rel0 > 1e-10) && (rel < 0.25 * prevrel);
+  const bool more_passes = (pass + 1 < P.refine_max) && (rel * rel0 > 1e-9) && (rel < 0.25 * prevrel);
   __syncthreads();
   if (!more_passes) break;
   prevrel = rel;
