@@ -623,10 +623,10 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
     return DDMPC_OK;
   }
   if (h->large) {                  // robust scheme beyond the register-resident kernels: matrices in a global workspace
-    const size_t r = (size_t)h->kp.r, npk = r * (r + 1) / 2, rv = (r + 1) & ~(size_t)1;
+    const size_t r = (size_t)h->kp.r, npk = pk_size(r), rv = (r + 1) & ~(size_t)1;      // (packed rows on 128-byte boundaries)
     const size_t nB = h->kp.convex ? (size_t)h->prm.p * h->prm.L : 0;      // components the slack box acts on
-    const size_t nlag = (size_t)h->kp.Ln * h->kp.nch * h->kp.nch, sb = nB * (nB + 1);
-    const size_t stride = npk + (nlag > sb ? nlag : sb);
+    const size_t nlag = (size_t)h->kp.Ln * h->kp.nch * h->kp.nch, sb = 2 * pk_size(nB);
+    const size_t stride = (npk + (nlag > sb ? nlag : sb) + 15) & ~(size_t)15;      // every instance's slice on a 128-byte boundary
     if ((rc = h->d_rr.ensure((size_t)h->batch * stride * sizeof(double)))) return rc;
     if ((rc = h->d_beta.ensure((size_t)h->batch * h->kp.rE * sizeof(double)))) return rc;
     if ((rc = h->d_act.ensure((size_t)h->batch * h->kp.rE))) return rc;
@@ -728,7 +728,7 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
                                  int32_t* status, int32_t* iters, int rr_mode = 0) {
   if (h->prm.controller_type != DDMPC_NOMINAL || h->prm.weight_kind == DDMPC_WEIGHT_DENSE) return DDMPC_OK;
   const size_t r = (size_t)h->kp.r, nR = (size_t)h->n_free;
-  const size_t ndbl = r * (r + 1) / 2 + nR * (nR + 1) / 2;
+  const size_t ndbl = pk_size(r) + pk_size(nR);                   // packed rows on 128-byte boundaries (ddmpc_aux_kernels.hpp)
   const size_t rv = (r + 1) & ~(size_t)1;
   const size_t vec_bytes = 10 * rv * sizeof(double) + 4 * rv * sizeof(int) +    // the kernel's r-vectors, always in LDS,
                            (size_t)PSD_PAN * sizeof(double);                        // and the scratch of its Cholesky / Gram

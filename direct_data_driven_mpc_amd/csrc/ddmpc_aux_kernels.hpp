@@ -643,7 +643,18 @@ __global__ void ddmpc_pe_guard_kernel(const double* __restrict__ X, int N, int m
 // when they fit (four-tank size), else in a global workspace; plain VALU code, one workgroup per instance.  A set-up-time / rescue path, not a
 // throughput kernel.  Diagonal weights only.
 // --------------------------------------------------------------------------
-__device__ __forceinline__ int tri_row(int e) {
+// Packed lower-triangular storage of the matrices in the global workspace (and in LDS at the four-tank sizes): row i holds
+// its columns 0 .. i and STARTS ON A 128-BYTE BOUNDARY -- rows 16 t .. 16 t + 15 have 16 (t + 1) slots.  A 16-column piece of
+// a row is then exactly one cache line (with rows packed back to back, i (i + 1) / 2, the four 32-byte lane pieces of a row
+// straddle two lines fifteen times out of sixteen: twice the tag look-ups per load, and the vector-memory path of a CU that
+// runs two of these workgroups is what their factorisations queue on).  +2.5 % of storage at 608 rows.
+__host__ __device__ __forceinline__ size_t pk_row(size_t i) {
+  const size_t t = i >> 4;
+  return 128 * t * (t + 1) + (i & 15) * 16 * (t + 1);
+}
+__host__ __device__ __forceinline__ size_t pk_size(size_t n) { return pk_row(n); }   // (a multiple of 16: what follows stays aligned)
+
+__device__ __forceinline__ int tri_row(int e) {       // row of entry e in the LOGICAL enumeration e = i (i + 1) / 2 + j
   int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
   while ((i + 1) * (i + 2) / 2 <= e) ++i;
   while (i * (i + 1) / 2 > e) --i;
@@ -738,7 +749,7 @@ __device__ __forceinline__ int packed_psd_cholesky(double* A, int n, double tol_
   double* Xs = pan + 1024;           // X(1,0)' = rows k0+16.. of the first half's columns, k-major: Xs[k][row]
   double* Dinv = pan + 1280;         // 2 x 16 reciprocal pivots
   if (ncols < 0) ncols = n;
-  auto rowp = [&](int i) -> const double* { i = i < n ? i : n - 1; return A + (size_t)i * (i + 1) / 2; };
+  auto rowp = [&](int i) -> const double* { i = i < n ? i : n - 1; return A + pk_row(i); };
   for (int k0 = 0; k0 < ncols; k0 += 32) {
     const int nba = (ncols - k0) < 16 ? (ncols - k0) : 16;
     const int nbb = (ncols - k0 - 16) < 0 ? 0 : ((ncols - k0 - 16) < 16 ? (ncols - k0 - 16) : 16);
@@ -811,7 +822,7 @@ __device__ __forceinline__ int packed_psd_cholesky(double* A, int n, double tol_
 #pragma unroll
           for (int e = 0; e < 4; ++e) {                                   // L(0,0) -> matrix
             const int idx = lane + 64 * e, rr = idx >> 4, c = idx & 15;
-            if (c <= rr && c < nba && k0 + rr < n) A[(size_t)(k0 + rr) * (k0 + rr + 1) / 2 + k0 + c] = Dga[rr * 16 + c];
+            if (c <= rr && c < nba && k0 + rr < n) A[pk_row(k0 + rr) + k0 + c] = Dga[rr * 16 + c];
           }
         }
         __syncthreads();                                                  // Msa visible
@@ -841,7 +852,7 @@ __device__ __forceinline__ int packed_psd_cholesky(double* A, int n, double tol_
             for (int e = 0; e < 4; ++e) {                                 // L(1,1) -> matrix
               const int idx = lane + 64 * e, rr = idx >> 4, c = idx & 15;
               const int gi = k0 + 16 + rr;
-              if (c <= rr && c < nbb && gi < n) A[(size_t)gi * (gi + 1) / 2 + k0 + 16 + c] = Dgb[rr * 16 + c];
+              if (c <= rr && c < nbb && gi < n) A[pk_row(gi) + k0 + 16 + c] = Dgb[rr * 16 + c];
             }
           }
           __syncthreads();                                                // Xs, Msb visible
@@ -858,7 +869,7 @@ __device__ __forceinline__ int packed_psd_cholesky(double* A, int n, double tol_
             acc[s][0] = x;
           }
           const int i = k0 + 16 * ti[s] + l15;
-          double* Ai = A + (size_t)(i < n ? i : 0) * ((i < n ? i : 0) + 1) / 2;
+          double* Ai = A + pk_row(i < n ? i : 0);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int cc = k0 + l4 + 4 * q;
@@ -892,7 +903,7 @@ __device__ __forceinline__ int packed_psd_cholesky(double* A, int n, double tol_
           const int i = ib + hw;
           double s0 = 0.0, s1 = 0.0;
           if (i < n) {
-            const double* Li = A + (size_t)i * (i + 1) / 2;
+            const double* Li = A + pk_row(i);
             int j = t32;
             for (; j + 32 < k0; j += 64) { const double l0 = Li[j], l1 = Li[j + 32]; s0 += l0 * l0; s1 += l1 * l1; }
             if (j < k0) { const double l0 = Li[j]; s0 += l0 * l0; }
@@ -900,7 +911,7 @@ __device__ __forceinline__ int packed_psd_cholesky(double* A, int n, double tol_
           double sacc = s0 + s1;
 #pragma unroll
           for (int off = 16; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 32);
-          if (i < n) dm = fmax(dm, A[(size_t)i * (i + 1) / 2 + i] - sacc);
+          if (i < n) dm = fmax(dm, A[pk_row(i) + i] - sacc);
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) dm = fmax(dm, __shfl_xor(dm, off, 64));
@@ -915,7 +926,7 @@ __device__ __forceinline__ int packed_psd_cholesky(double* A, int n, double tol_
           const size_t e0 = (size_t)i1 * (i1 + 1) / 2, e1 = (size_t)n * (n + 1) / 2;
           for (size_t e = e0 + tid; e < e1; e += blockDim.x) {             // rows >= i1: their entries in columns >= i1
             const int i = tri_row((int)e), j = (int)(e - (size_t)i * (i + 1) / 2);
-            if (j >= i1) A[e] = 0.0;
+            if (j >= i1) A[pk_row(i) + j] = 0.0;
           }
           __syncthreads();
           return k0;
@@ -940,13 +951,14 @@ __device__ __forceinline__ void packed_back_substitute(const double* Lm, int n, 
     const int nb = (n - k0) < 16 ? (n - k0) : 16;
     // operands of the update of the rows above the block: Lu[q] = L(k0 + q, j), j = tid < k0
     double Lu[16];
+    const size_t kb = pk_row(k0), krs = (size_t)k0 + 16;     // rows k0 .. k0+15 (one 16-row block): row k0 + q starts at kb + q * krs
 #pragma unroll
-    for (int q = 0; q < 16; ++q) Lu[q] = (tid < k0 && q < nb) ? Lm[(size_t)(k0 + q) * (k0 + q + 1) / 2 + tid] : 0.0;
+    for (int q = 0; q < 16; ++q) Lu[q] = (tid < k0 && q < nb) ? Lm[kb + q * krs + tid] : 0.0;
     if (tid < 64) {
       // lane a owns unknown k0 + a and column a of the diagonal block: Lc[q] = L(k0 + q, k0 + a), q >= a
       double Lc[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) Lc[q] = (q >= a && q < nb) ? Lm[(size_t)(k0 + q) * (k0 + q + 1) / 2 + k0 + a] : 0.0;
+      for (int q = 0; q < 16; ++q) Lc[q] = (q >= a && q < nb) ? Lm[kb + q * krs + k0 + a] : 0.0;
       const bool dead = a >= nb || (skip != nullptr && skip[k0 + a] != 0);
       double inv = 0.0;
 #pragma unroll
@@ -968,7 +980,7 @@ __device__ __forceinline__ void packed_back_substitute(const double* Lm, int n, 
     }
     for (int j = tid + nthr; j < k0; j += nthr) {       // more rows than threads: the remaining entries, loaded now
       double sacc = 0.0;
-      for (int q = 0; q < nb; ++q) sacc += Lm[(size_t)(k0 + q) * (k0 + q + 1) / 2 + j] * x[k0 + q];
+      for (int q = 0; q < nb; ++q) sacc += Lm[kb + q * krs + j] * x[k0 + q];
       y[j] -= sacc;
     }
     __syncthreads();
@@ -988,15 +1000,16 @@ __device__ __forceinline__ void packed_forward_substitute(const double* Lm, int 
   const int a = tid & 15;
   for (int k0 = 0; k0 < n; k0 += 16) {
     const int nb = (n - k0) < 16 ? (n - k0) : 16;
+    const size_t kb = pk_row(k0), krs = (size_t)k0 + 16;     // rows k0 .. k0+15 (one 16-row block): row k0 + q starts at kb + q * krs
     double Lr[16];                                       // wave 0: row a of the diagonal block, Lr[q] = L(k0 + a, k0 + q), q <= a
     if (tid < 64) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) Lr[q] = (q <= a && a < nb) ? Lm[(size_t)(k0 + a) * (k0 + a + 1) / 2 + k0 + q] : 0.0;
+      for (int q = 0; q < 16; ++q) Lr[q] = (q <= a && a < nb) ? Lm[kb + a * krs + k0 + q] : 0.0;
     }
     for (int h = hw; h < 16; h += nhw) {
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
       if (h < nb) {
-        const double* La = Lm + (size_t)(k0 + h) * (k0 + h + 1) / 2;
+        const double* La = Lm + kb + h * krs;
         int j = t32;
         for (; j + 96 < k0; j += 128) {                  // four loads in flight per lane
           const double l0 = La[j], l1 = La[j + 32], l2 = La[j + 64], l3 = La[j + 96];
@@ -1039,7 +1052,7 @@ __device__ __forceinline__ void packed_rows_times(const double* Lm, int row0, in
     const int i = ib + hw;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (i < nrows) {
-      const double* Li = Lm + (size_t)(row0 + i) * (row0 + i + 1) / 2;
+      const double* Li = Lm + pk_row(row0 + i);
       const double* xv = x - j0;
       const int je = jend(i);
       int j = j0 + t32;
@@ -1065,13 +1078,13 @@ __device__ __forceinline__ void packed_cols_times(const double* Lm, int row0, in
     int i = ibeg(k);
     for (; i + 3 < nrows; i += 4) {
       const size_t ri = (size_t)(row0 + i);
-      const double l0 = Lm[ri * (ri + 1) / 2 + col0 + k], l1 = Lm[(ri + 1) * (ri + 2) / 2 + col0 + k];
-      const double l2 = Lm[(ri + 2) * (ri + 3) / 2 + col0 + k], l3 = Lm[(ri + 3) * (ri + 4) / 2 + col0 + k];
+      const double l0 = Lm[pk_row(ri) + col0 + k], l1 = Lm[pk_row(ri + 1) + col0 + k];
+      const double l2 = Lm[pk_row(ri + 2) + col0 + k], l3 = Lm[pk_row(ri + 3) + col0 + k];
       s0 += l0 * v(i); s1 += l1 * v(i + 1); s2 += l2 * v(i + 2); s3 += l3 * v(i + 3);
     }
     for (; i < nrows; ++i) {
       const size_t ri = (size_t)(row0 + i);
-      s0 += Lm[ri * (ri + 1) / 2 + col0 + k] * v(i);
+      s0 += Lm[pk_row(ri) + col0 + k] * v(i);
     }
     out(k, (s0 + s1) + (s2 + s3));
   }
@@ -1099,7 +1112,7 @@ __device__ __forceinline__ void packed_weighted_gram_mfma(const double* Lm, int 
       for (int i0 = 16 * A; i0 < nR; i0 += 4) {
         const int i = i0 + l4;
         const size_t ri = (size_t)(row0 + (i < nR ? i : nR - 1));
-        const double* Li = Lm + ri * (ri + 1) / 2 + row0;
+        const double* Li = Lm + pk_row(ri) + row0;
         const double av = (i < nR && a <= i && a < ncol) ? Li[a] * w[i] : 0.0;
         double bv[4];                                    // all loads of the step before the first MFMA
 #pragma unroll
@@ -1118,7 +1131,7 @@ __device__ __forceinline__ void packed_weighted_gram_mfma(const double* Lm, int 
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int ar = 16 * A + l4 + 4 * q;
-            if (ar < ncol && bcol <= ar) T[(size_t)ar * (ar + 1) / 2 + bcol] = (ar == bcol && skipd[ar]) ? 1.0 : acc[g][q];
+            if (ar < ncol && bcol <= ar) T[pk_row(ar) + bcol] = (ar == bcol && skipd[ar]) ? 1.0 : acc[g][q];
           }
         }
       }
@@ -1133,7 +1146,7 @@ __device__ __forceinline__ void packed_schur_mfma(const double* Lm, int row0, in
   const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwave = (int)(blockDim.x >> 6);
   const int nt = (nB + 15) >> 4;
-  auto rowp = [&](int i) -> const double* { const size_t ri = (size_t)(row0 + (i < nB ? i : nB - 1)); return Lm + ri * (ri + 1) / 2; };
+  auto rowp = [&](int i) -> const double* { const size_t ri = (size_t)(row0 + (i < nB ? i : nB - 1)); return Lm + pk_row(ri); };
   int item = 0;
   for (int A = nt - 1; A >= 0; --A) {
     for (int B0 = 0; B0 <= A; B0 += 4, ++item) {
@@ -1179,7 +1192,7 @@ __device__ __forceinline__ void packed_schur_mfma(const double* Lm, int row0, in
             const int i = 16 * A + l4 + 4 * q;
             if (i < nB && j <= i) {
               const size_t ri = (size_t)(row0 + i);
-              S[(size_t)i * (i + 1) / 2 + j] = Lm[ri * (ri + 1) / 2 + row0 + j] - acc[g][q];
+              S[pk_row(i) + j] = Lm[pk_row(ri) + row0 + j] - acc[g][q];
             }
           }
         }
@@ -1399,6 +1412,40 @@ __device__ __forceinline__ void hankel_normal_times(const KParams& P, const doub
   __syncthreads();
 }
 
+// Rows [t0, t0 + nrows) of the channel-interleaved trajectory into dst[row * nch + ch] (zeros beyond the last time step),
+// by the whole workgroup.  Branch-free: one unconditional load per entry from an address that is always valid (a select
+// between u_d and y_d or a range test per entry turns into one exec-masked block per entry, whose loads then wait for one
+// another), SR entries per thread in flight at once; no barrier inside.
+template <int SR>
+__device__ __forceinline__ void stage_trajectory(const KParams& P, const double* __restrict__ ud, const double* __restrict__ yd,
+                                                 int t0, int nrows, double* dst) {
+  const int nthr = blockDim.x, m = P.m, p = P.p, nch = P.nch, total = nrows * nch;
+  const long long dyu = reinterpret_cast<const char*>(yd) - reinterpret_cast<const char*>(ud);   // (one flat address space)
+  const bool pow2 = (nch & (nch - 1)) == 0;
+  const int lg = 31 - __clz(nch);
+  for (int base = 0; base < total; base += SR * nthr) {
+    int tq = threadIdx.x;
+    asm volatile("" : "+v"(tq));                       // (opaque per round: keeps the SR source addresses from being hoisted and spilled)
+    double v[SR], keep[SR];
+#pragma unroll
+    for (int e = 0; e < SR; ++e) {
+      int i = base + tq + e * nthr;
+      i = i < total ? i : total - 1;
+      const int row = pow2 ? (i >> lg) : i / nch, ch = i - row * nch;
+      const int t = t0 + row, tc = t < P.N ? t : P.N - 1;
+      keep[e] = t < P.N ? 1.0 : 0.0;
+      const long long ou = ((long long)tc * m + ch) * 8, oy = dyu + ((long long)tc * p + (ch - m)) * 8;
+      v[e] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ud) + ((ch < m) ? ou : oy));
+    }
+    __builtin_amdgcn_sched_barrier(0);                 // all SR loads are in flight before the first is touched
+#pragma unroll
+    for (int e = 0; e < SR; ++e) {
+      const int i = base + tq + e * nthr;
+      if (i < total) dst[i] = v[e] * keep[e];
+    }
+  }
+}
+
 // Packed lower triangle of G = H H' for the block-Hankel H of one instance, through the Hankel structure (as in the
 // cold kernel): with components (k, a) = (time offset, channel),
 //   G((k+d, a), (k, b)) = C_d(a,b) + sum_{j<k} ( x_a[j+c+d] x_b[j+c] - x_a[j+d] x_b[j] ),   C_d(a,b) = sum_{t<c} x_a[t+d] x_b[t],
@@ -1434,10 +1481,7 @@ __device__ __forceinline__ void hankel_gram_packed(const KParams& P, const doubl
           const int nt = (c - t0) < TCH ? (c - t0) : TCH;                    // terms of this chunk
           const int nload = nt + P.Ln - 1;                                  // time steps needed (x_a[t+d], d < Ln)
           __syncthreads();
-          for (int i = tid; i < nload * nch; i += nthr) {
-            const int tt = i / nch, ch = i - tt * nch;
-            xc[i] = xat(ch, t0 + tt);
-          }
+          stage_trajectory<4>(P, ud, yd, t0, nload, xc);
           __syncthreads();
           for (int s4 = 0; s4 < nt; s4 += 4) {
             const int t = s4 + l4;
@@ -1464,17 +1508,30 @@ __device__ __forceinline__ void hankel_gram_packed(const KParams& P, const doubl
       }
   __syncthreads();
   // one (lag, channel pair) diagonal per thread-iteration, walked with the O(1) window update; every unordered
-  // pair of components is met exactly once (lag 0: channel pairs a >= b only)
+  // pair of components is met exactly once (lag 0: channel pairs a >= b only).  The walk only touches the first and the
+  // last Ln - 1 rows of the window range: both pieces are staged in LDS (one dependent L2 round trip per step otherwise).
+  const int nw = P.Ln - 1;
+  double* xh = pan;                                                         // rows 0 .. Ln-2
+  double* xt = pan + nw * nch;                                              // rows c .. c+Ln-2
+  const bool walk_lds = 2 * nw * nch <= PSD_PAN;
+  if (walk_lds) {
+    stage_trajectory<4>(P, ud, yd, 0, nw, xh);
+    stage_trajectory<4>(P, ud, yd, c, nw, xt);
+    __syncthreads();
+  }
   for (int e = tid; e < nlag; e += nthr) {
     const int d = e / (nch * nch), ab = e - d * nch * nch, a = ab / nch, bb = ab - a * nch;
     if (d == 0 && a < bb) continue;
     double s = Ctab[e];
     for (int k = 0; k + d < P.Ln; ++k) {
-      if (k > 0) s += xat(a, k - 1 + c + d) * xat(bb, k - 1 + c) - xat(a, k - 1 + d) * xat(bb, k - 1);
+      if (k > 0) {
+        if (walk_lds) s += xt[(k - 1 + d) * nch + a] * xt[(k - 1) * nch + bb] - xh[(k - 1 + d) * nch + a] * xh[(k - 1) * nch + bb];
+        else s += xat(a, k - 1 + c + d) * xat(bb, k - 1 + c) - xat(a, k - 1 + d) * xat(bb, k - 1);
+      }
       const int ci = (k + d) * nch + a, cj = k * nch + bb;
       const int pi = iperm ? iperm[ci] : ci, pj = iperm ? iperm[cj] : cj;
       const int hi = pi > pj ? pi : pj, lo = pi > pj ? pj : pi;
-      G[hi * (hi + 1) / 2 + lo] = s;
+      G[pk_row(hi) + lo] = s;
     }
   }
 }
@@ -1589,7 +1646,7 @@ __global__ __launch_bounds__(512, DDMPC_RR_WAVES) void ddmpc_nominal_rr_kernel(K
   if constexpr (MODE == 0) rsm = scratch ? scratch + b * scratch_stride : pan + PSD_PAN;
   else rsm = scratch + b * scratch_stride;                // (a kernel-argument pointer: the matrices are addressed with global, not flat, loads)
   double* G = rsm;                                      // r(r+1)/2
-  double* T = G + r * (r + 1) / 2;                      // nR(nR+1)/2
+  double* T = G + pk_row(r);                      // nR(nR+1)/2
   __shared__ double red[16];
   __shared__ int cnt4[4];
   const double* ud = u_d + b * (long long)P.N * m;
@@ -1623,16 +1680,16 @@ __global__ __launch_bounds__(512, DDMPC_RR_WAVES) void ddmpc_nominal_rr_kernel(K
   //   G((k+d, a), (k, b)) = C_d(a,b) + sum_{j<k} ( x_a[j+c+d] x_b[j+c] - x_a[j+d] x_b[j] ),   C_d(a,b) = sum_{t<c} x_a[t+d] x_b[t],
   // so only the Ln*nch^2 lag sums need the full length-c dot product (cfg 5: 19 M instead of 363 M multiply-adds).
   // The lag table borrows the (not yet used) storage of T; if it does not fit there, plain dot products are used.
-  const int npk = r * (r + 1) / 2;
+  const int npk = pk_row(r);
   const int nlag = P.Ln * nch * nch;
   int* meta = meta_ws ? meta_ws + b * (long long)(2 * rv + 2) : nullptr;
   int nlive = 0, nRl = 0;
   if constexpr (MODE != 2) {
-  if (nlag <= nR * (nR + 1) / 2) {
+  if (nlag <= pk_row(nR)) {
     for (int i = tid; i < r; i += nthr) iperm[perm[i]] = i;
     hankel_gram_packed(P, ud, yd, G, T, iperm, pan);
   } else {
-    for (int e = tid; e < npk; e += nthr) {
+    for (int e = tid; e < r * (r + 1) / 2; e += nthr) {
       const int i = tri_row(e), j = e - i * (i + 1) / 2;
       const int ri = perm[i], rj = perm[j];
       const int ki = ri / nch, ci = ri - ki * nch, kj = rj / nch, cj = rj - kj * nch;
@@ -1643,13 +1700,13 @@ __global__ __launch_bounds__(512, DDMPC_RR_WAVES) void ddmpc_nominal_rr_kernel(K
       int t = 0;
       for (; t + 1 < c; t += 2) { s0 += xi[t * si] * xj[t * sj]; s1 += xi[(t + 1) * si] * xj[(t + 1) * sj]; }
       if (t < c) s0 += xi[t * si] * xj[t * sj];
-      G[e] = s0 + s1;
+      G[pk_row(i) + j] = s0 + s1;
     }
   }
   __syncthreads();
   if (dbg && tid == 0) dbg[b * 16 + 1] = __builtin_amdgcn_s_memrealtime();
   double dmx = 0.0;
-  for (int i = tid; i < r; i += nthr) dmx = fmax(dmx, G[i * (i + 1) / 2 + i]);
+  for (int i = tid; i < r; i += nthr) dmx = fmax(dmx, G[pk_row(i) + i]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) dmx = fmax(dmx, __shfl_xor(dmx, off, 64));
   if ((tid & 63) == 0) red[tid >> 6] = dmx;
@@ -1695,7 +1752,7 @@ __global__ __launch_bounds__(512, DDMPC_RR_WAVES) void ddmpc_nominal_rr_kernel(K
   if (dbg && tid == 0) dbg[b * 16 + 4] = __builtin_amdgcn_s_memrealtime();
   if constexpr (MODE != 2) {
     double tmx = 0.0;
-    for (int a = 0; a < nRl; ++a) tmx = fmax(tmx, T[a * (a + 1) / 2 + a]);
+    for (int a = 0; a < nRl; ++a) tmx = fmax(tmx, T[pk_row(a) + a]);
     packed_psd_cholesky(T, nRl, 1e-14 * tmx, skipT, pan);
     if (meta) {                                          // what a later mode-2 launch needs besides the two factors
       for (int i = tid; i < r; i += nthr) meta[i] = skip[i];
@@ -1869,7 +1926,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
   int* perm = skip + rv;                                // position -> component
   int* iperm = perm + rv;                               // component -> position
   double* pan = reinterpret_cast<double*>(iperm + rv);
-  const int npk = r * (r + 1) / 2;
+  const int npk = pk_row(r);
   double* G = scratch + b * scratch_stride;             // Gram -> [L_AA; L_BA] in its first nA columns
   __shared__ double red[16];
   __shared__ int flag[1];
@@ -1883,7 +1940,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
     return (P.convex && (kind == K_WPRED || kind == K_WTERM)) ? 1 : 0;
   }, perm, skip, cnt);
   const int nA = cnt[0], nB = r - nA;
-  const int npB = nB * (nB + 1) / 2;
+  const int npB = pk_row(nB);
   double* S = G + npk;                                  // Schur complement of the B block (without lam*D_B)
   double* T = S + npB;                                  // S + lam*D_B -> its factor
   for (int i = tid; i < r; i += nthr) {
@@ -1913,13 +1970,13 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
   __syncthreads();
   if (P.dense_w) {     // dense weighting matrices: lam * W^-1 (shared by the batch, component order) on every pair of components;
                        // the diagonal table below then only carries the 1/lamb_sigma terms, which is all the slack box switches
-    for (int e = tid; e < npk; e += nthr) {
+    for (int e = tid; e < r * (r + 1) / 2; e += nthr) {
       const int i = tri_row(e), j = e - i * (i + 1) / 2;
-      G[e] += P.lam * P.dmat[(long long)perm[i] * RPs + perm[j]];
+      G[pk_row(i) + j] += P.lam * P.dmat[(long long)perm[i] * RPs + perm[j]];
     }
     __syncthreads();
   }
-  for (int i = tid; i < nA; i += nthr) G[i * (i + 1) / 2 + i] += P.lam * P.tabd[0 * RPs + perm[i]];
+  for (int i = tid; i < nA; i += nthr) G[pk_row(i) + i] += P.lam * P.tabd[0 * RPs + perm[i]];
   __syncthreads();
   packed_psd_cholesky(G, r, 0.0, skip, pan, nA);        // columns of A only; a pivot that is not positive is skipped
   int st = 0, iter = 0;
@@ -1945,7 +2002,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
       for (int i = tid; i < nB; i += nthr) {
         const int rho = perm[nA + i];
         const double D = act[nA + i] ? P.tabd[1 * RPs + rho] : P.tabd[0 * RPs + rho];
-        T[i * (i + 1) / 2 + i] += P.lam * D;
+        T[pk_row(i) + i] += P.lam * D;
       }
       __syncthreads();
       packed_psd_cholesky(T, nB, 0.0, skip + nA, pan);
