@@ -704,7 +704,12 @@ __device__ __forceinline__ void psd_tile_factor(double* Dg, double* Ms, double* 
       old[t] = on ? Dg[rr * 16 + c2] : 0.0;
     }
     const bool sk = !(dk > tol_abs);                   // the same value in every lane
-    const double inv = sk ? 0.0 : 1.0 / sqrt(dk);
+    // 1/sqrt by the hardware seed + one Newton step (relative error ~1e-16): `1.0 / sqrt(dk)` expands to two long
+    // software sequences on the critical path of every column of every diagonal tile
+    const double dks = sk ? 1.0 : dk;
+    const double y0 = __builtin_amdgcn_rsq(dks);
+    const double ye = fma(-dks * y0, y0, 1.0);
+    const double inv = sk ? 0.0 : fma(0.5 * y0, ye, y0);
     const double u = lrc * inv;
     if (cg == 0 && rr >= c) Dg[rr * 16 + c] = u;
     if (lane == 0) { skipout[c] = sk ? 1 : 0; Dinv[c] = inv; }
@@ -734,11 +739,13 @@ __device__ __forceinline__ void psd_tile_factor(double* Dg, double* Ms, double* 
 // `early` (full factorisations only): when a whole panel comes out without a pivot, the diagonal of the Schur complement
 // behind it is formed (one pass over the rows below); if none of its entries exceeds tol_abs either, every remaining
 // pivot would be skipped as well (the diagonal of a PSD Schur complement only shrinks): the remaining columns are
-// marked skipped, the trailing block is zeroed and the factorisation stops.  Returns the number of columns in front of
+// marked skipped, the trailing block is zeroed and the factorisation stops (tested for panels from column `early_from` on:
+// a dead panel inside the fixed block of the rank-revealing route has live rows behind it by construction, and every test
+// is a latency-bound pass over the rows below -- three of them were 0.22 ms of a cfg-5 factorisation).  Returns the number of columns in front of
 // that point (n when it ran to the end): all columns >= the return value are zero.  With the dependent rows ordered last
 // (exact data: the rank-revealing kernel) this saves the factorisation of the dead half of the matrix.
 __device__ __forceinline__ int packed_psd_cholesky(double* A, int n, double tol_abs, int* skip, double* pan, int ncols = -1,
-                                                   bool early = false) {
+                                                   bool early = false, int early_from = 0) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = (int)(blockDim.x >> 6);
@@ -799,18 +806,36 @@ __device__ __forceinline__ int packed_psd_cholesky(double* A, int n, double tol_
         }
       }
       // ---- P' = A' - acc on the valid entries (row < n, column <= row, column < ncols), zero elsewhere -----
+      {
+        // (all 8 PSD_TG entries loaded unconditionally from positions clamped into the row, selected afterwards: with the
+        //  test around the load every entry became an exec-masked block of its own and the loads waited for one another)
+        double av[PSD_TG][2][4];
 #pragma unroll
-      for (int s = 0; s < PSD_TG; ++s) {
-        const int i = k0 + 16 * ti[s] + l15;
-        const double* Ai = rowp(i);
+        for (int s = 0; s < PSD_TG; ++s) {
+          const int i = k0 + 16 * ti[s] + l15;
+          const int ic = i < n ? i : n - 1;
+          const double* Ai = A + pk_row(ic);
 #pragma unroll
-        for (int C = 0; C < 2; ++C)
+          for (int C = 0; C < 2; ++C)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int cc = k0 + 16 * C + l4 + 4 * q;
-            const bool ok = ti[s] < ntile && i < n && cc <= i && cc < ncols;
-            acc[s][C][q] = ok ? Ai[cc] - acc[s][C][q] : 0.0;
-          }
+            for (int q = 0; q < 4; ++q) {
+              const int cc = k0 + 16 * C + l4 + 4 * q;
+              av[s][C][q] = Ai[cc <= ic ? cc : ic];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < PSD_TG; ++s) {
+          const int i = k0 + 16 * ti[s] + l15;
+#pragma unroll
+          for (int C = 0; C < 2; ++C)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int cc = k0 + 16 * C + l4 + 4 * q;
+              const bool ok = ti[s] < ntile && i < n && cc <= i && cc < ncols;
+              acc[s][C][q] = ok ? av[s][C][q] - acc[s][C][q] : 0.0;
+            }
+        }
       }
       if (g0 == 0) {
         // ---- diagonal tiles: wave 0 owns tile row 0, wave 1 (or wave 0 again, single-wave launch) tile row 1 ----
@@ -892,7 +917,7 @@ __device__ __forceinline__ int packed_psd_cholesky(double* A, int n, double tol_
       }
     }
     __syncthreads();                                                      // panel stored before the next update reads it; LDS tiles free
-    if (early && ncols == n && k0 + 32 < n) {
+    if (early && ncols == n && k0 + 32 < n && k0 >= early_from) {
       bool alldead = true;
       for (int q = 0; q < 32; ++q) alldead = alldead && (skip[k0 + q] != 0);      // LDS, the same for every thread
       if (alldead) {
@@ -1714,7 +1739,7 @@ __global__ __launch_bounds__(512, DDMPC_RR_WAVES) void ddmpc_nominal_rr_kernel(K
   double dmax = 0.0;
   for (int w = 0; w < (nthr >> 6); ++w) dmax = fmax(dmax, red[w]);
   __syncthreads();
-  nlive = packed_psd_cholesky(G, r, rank_tol * dmax, skip, pan, -1, true);                // columns >= nlive are zero
+  nlive = packed_psd_cholesky(G, r, rank_tol * dmax, skip, pan, -1, true, nF);                // columns >= nlive are zero
   nRl = (nlive > nF) ? ((nlive - nF) < nR ? (nlive - nF) : nR) : 0;                           // live columns of the free block
   } else {
     for (int i = tid; i < r; i += nthr) skip[i] = meta[i];
