@@ -962,51 +962,76 @@ __device__ __forceinline__ int packed_psd_cholesky(double* A, int n, double tol_
   return n;
 }
 
-// Back substitution L' x = y for a packed lower factor, 16 rows at a time: the 16x16 diagonal block is solved by the
-// first 16 lanes of wave 0 (its entries in registers, the unknowns passed on by lane shuffles), then every thread j
-// below the block subtracts the 16 rows' contributions from y[j].  The operands of that update do not depend on the
-// unknowns, so their loads are issued BEFORE the block solve: two workgroup barriers and one global round trip per 16
-// rows (the row-by-row form paid a barrier and two dependent round trips per row, ~1 ms for 608 rows).
+// One lane's double as a wave-uniform value (two v_readlane_b32 into an SGPR pair): the unknown-by-unknown chains of the
+// blocked substitutions pass values on this way -- a __shfl is a trip through the LDS crossbar, ~100 cycles per step.
+__device__ __forceinline__ double lane_value_f64(double v, int srclane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+
+// Back substitution L' x = y for a packed lower factor, 16 rows at a time, with a one-block look-ahead: wave 0 solves
+// block b -- it first takes the contribution of block b+1 (the 16x16 coupling block, four entries per lane) off its 16
+// right-hand sides, then runs the 16x16 diagonal solve with the unknowns passed on by lane shuffles -- WHILE the other
+// waves subtract block b+1's unknowns from all the rows above block b (column pieces of the factor, coalesced; their
+// loads do not depend on anything computed here).  One workgroup barrier and no exposed memory round trip per 16 rows:
+// the form without look-ahead (solve, barrier, update everything, barrier) spent ~3.3 us per block, twice this.
 // y is consumed (overwritten), x must not alias it; `skip` (optional) marks rows whose unknown is zero.
 constexpr int PSD_RPT = 2;      // r-vector entries per thread where a routine keeps them in registers (r <= PSD_RPT * blockDim.x)
 __device__ __forceinline__ void packed_back_substitute(const double* Lm, int n, double* y, double* x, const int* skip) {
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int a = tid & 15;
-  for (int k0 = ((n - 1) >> 4) << 4; k0 >= 0; k0 -= 16) {
+  const int lane = tid & 63, a = lane & 15, g4 = lane >> 4;
+  const int nblk = (n + 15) >> 4;
+  for (int b = nblk - 1; b >= 0; --b) {
+    const int k0 = 16 * b;
     const int nb = (n - k0) < 16 ? (n - k0) : 16;
-    // operands of the update of the rows above the block: Lu[q] = L(k0 + q, j), j = tid < k0
-    double Lu[16];
     const size_t kb = pk_row(k0), krs = (size_t)k0 + 16;     // rows k0 .. k0+15 (one 16-row block): row k0 + q starts at kb + q * krs
-#pragma unroll
-    for (int q = 0; q < 16; ++q) Lu[q] = (tid < k0 && q < nb) ? Lm[kb + q * krs + tid] : 0.0;
+    const bool below = b + 1 < nblk;                         // block b+1 exists: its unknowns x[k0+16 ..] were stored before the last barrier
+    const int nbn = below ? ((n - k0 - 16) < 16 ? (n - k0 - 16) : 16) : 0;
+    const size_t kbn = kb + 16 * krs, krn = krs + 16;        // rows of block b+1
     if (tid < 64) {
       // lane a owns unknown k0 + a and column a of the diagonal block: Lc[q] = L(k0 + q, k0 + a), q >= a
+      // (unconditional loads from rows clamped into the block, selected afterwards: all 20 in flight at once)
       double Lc[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) Lc[q] = (q >= a && q < nb) ? Lm[kb + q * krs + k0 + a] : 0.0;
+      for (int q = 0; q < 16; ++q) Lc[q] = Lm[kb + (q < nb ? q : nb - 1) * krs + k0 + a];
+      // coupling with block b+1: lane (g4, a) takes rows k0+16 + 4 g4 .. + 3 of column k0 + a
+      double cq[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cq[i] = Lm[(nbn > 0 ? kbn + (4 * g4 + i < nbn ? 4 * g4 + i : nbn - 1) * krn : kb) + k0 + a];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Lc[q] = (q >= a && q < nb) ? Lc[q] : 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cq[i] = (4 * g4 + i < nbn && a < nb) ? cq[i] : 0.0;
       const bool dead = a >= nb || (skip != nullptr && skip[k0 + a] != 0);
       double inv = 0.0;
 #pragma unroll
       for (int q = 0; q < 16; ++q) if (q == a) inv = dead ? 0.0 : 1.0 / Lc[q];
-      double v = (a < nb) ? y[k0 + a] : 0.0;
+      double cs = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cs += cq[i] * ((4 * g4 + i < nbn) ? x[k0 + 16 + 4 * g4 + i] : 0.0);
+      cs += __shfl_xor(cs, 16, 64);
+      cs += __shfl_xor(cs, 32, 64);
+      double v = (a < nb) ? y[k0 + a] - cs : 0.0;
 #pragma unroll
       for (int q = 15; q >= 0; --q) {
-        const double xq = __shfl(v * inv, q, 16);       // final once every row below q has been subtracted
+        const double xq = lane_value_f64(v * inv, q);   // final once every row below q has been subtracted (the four 16-lane groups hold the same values)
         if (a < q) v -= Lc[q] * xq;
       }
       if (tid < nb) x[k0 + a] = v * inv;
-    }
-    __syncthreads();
-    if (tid < k0) {
-      double sacc = 0.0;
+    } else if (below) {
+      // rows above block b: y[j] -= sum_q L(k0+16+q, j) x[k0+16+q], j < k0 (block b's own rows get theirs from wave 0)
+      for (int j = tid - 64; j < k0; j += nthr - 64) {
+        double Lu[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) sacc += Lu[q] * ((q < nb) ? x[k0 + q] : 0.0);
-      y[tid] -= sacc;
-    }
-    for (int j = tid + nthr; j < k0; j += nthr) {       // more rows than threads: the remaining entries, loaded now
-      double sacc = 0.0;
-      for (int q = 0; q < nb; ++q) sacc += Lm[kb + q * krs + j] * x[k0 + q];
-      y[j] -= sacc;
+        for (int q = 0; q < 16; ++q) Lu[q] = Lm[kbn + (q < nbn ? q : nbn - 1) * krn + j];
+        __builtin_amdgcn_sched_barrier(0);
+        double sacc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sacc += Lu[q] * ((q < nbn) ? x[k0 + 16 + q] : 0.0);
+        y[j] -= sacc;
+      }
     }
     __syncthreads();
   }
@@ -1014,52 +1039,74 @@ __device__ __forceinline__ void packed_back_substitute(const double* Lm, int n, 
 
 __device__ __forceinline__ double block_sum(double v, double* red);       // defined below
 
-// L y = rhs over the rows that are not skipped (y = 0 on skipped ones) for a packed lower factor, 16 rows at a time:
-// every 32-lane half wave forms the dot product of one row of the block with the y known so far (coalesced 256-byte
-// pieces of the row), then the first 16 lanes of wave 0 solve the 16x16 diagonal block with lane shuffles.  Two
-// workgroup barriers per 16 rows.  y must not alias rhs; `red` holds >= 16 doubles.
+// L y = rhs over the rows that are not skipped (y = 0 on skipped ones) for a packed lower factor, 16 rows at a time, with
+// a one-block look-ahead: while wave 0 solves block b (right-hand sides minus the partial sums formed one block earlier
+// minus the 16x16 coupling with block b-1, then the diagonal solve with lane shuffles), the other half waves already
+// form the dot products of block b+1's rows with the y known so far (columns < 16 b; coalesced 256-byte pieces of a
+// row).  One workgroup barrier per 16 rows, the row loads off wave 0's path.  y must not alias rhs; `red` is not used any more.
 __device__ __forceinline__ void packed_forward_substitute(const double* Lm, int n, const double* rhs, double* y,
                                                           const int* skip, double* red) {
+  (void)red;
+  __shared__ double fsub_part[2][16];                    // partial sums of the current / the next block (one instance per kernel)
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int hw = tid >> 5, t32 = tid & 31, nhw = nthr >> 5;
-  const int a = tid & 15;
-  for (int k0 = 0; k0 < n; k0 += 16) {
+  const int lane = tid & 63, a = lane & 15, g4 = lane >> 4;
+  const int nblk = (n + 15) >> 4;
+  if (tid < 16) fsub_part[0][tid] = 0.0;
+  __syncthreads();
+  for (int b = 0; b < nblk; ++b) {
+    const int k0 = 16 * b;
     const int nb = (n - k0) < 16 ? (n - k0) : 16;
+    const int cur = b & 1, nxt = cur ^ 1;
     const size_t kb = pk_row(k0), krs = (size_t)k0 + 16;     // rows k0 .. k0+15 (one 16-row block): row k0 + q starts at kb + q * krs
-    double Lr[16];                                       // wave 0: row a of the diagonal block, Lr[q] = L(k0 + a, k0 + q), q <= a
     if (tid < 64) {
+      const int ac = a < nb ? a : nb - 1;                  // (unconditional loads from a row clamped into the block, selected afterwards)
+      double Lr[16];                                       // row a of the diagonal block, Lr[q] = L(k0 + a, k0 + q), q <= a
 #pragma unroll
-      for (int q = 0; q < 16; ++q) Lr[q] = (q <= a && a < nb) ? Lm[kb + a * krs + k0 + q] : 0.0;
-    }
-    for (int h = hw; h < 16; h += nhw) {
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      if (h < nb) {
-        const double* La = Lm + kb + h * krs;
-        int j = t32;
-        for (; j + 96 < k0; j += 128) {                  // four loads in flight per lane
-          const double l0 = La[j], l1 = La[j + 32], l2 = La[j + 64], l3 = La[j + 96];
-          s0 += l0 * y[j]; s1 += l1 * y[j + 32]; s2 += l2 * y[j + 64]; s3 += l3 * y[j + 96];
-        }
-        for (; j < k0; j += 32) s0 += La[j] * y[j];
-      }
-      double sacc = (s0 + s1) + (s2 + s3);
+      for (int q = 0; q < 16; ++q) Lr[q] = Lm[kb + ac * krs + k0 + q];
+      double cq[4];                                        // coupling with block b-1: lane (g4, a) takes columns k0-16 + 4 g4 .. + 3 of row k0 + a
 #pragma unroll
-      for (int off = 16; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 32);
-      if (t32 == 0) red[h] = sacc;
-    }
-    __syncthreads();
-    if (tid < 64) {
+      for (int i = 0; i < 4; ++i) cq[i] = Lm[kb + ac * krs + (b > 0 ? k0 - 16 : 0) + 4 * g4 + i];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Lr[q] = (q <= a && a < nb) ? Lr[q] : 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cq[i] = (b > 0 && a < nb) ? cq[i] : 0.0;
       const bool dead = a >= nb || (skip != nullptr && skip[k0 + a] != 0);
       double inv = 0.0;
 #pragma unroll
       for (int q = 0; q < 16; ++q) if (q == a) inv = dead ? 0.0 : 1.0 / Lr[q];
-      double v = (a < nb) ? rhs[k0 + a] - red[a] : 0.0;
+      double cs = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cs += cq[i] * ((b > 0) ? y[k0 - 16 + 4 * g4 + i] : 0.0);
+      cs += __shfl_xor(cs, 16, 64);
+      cs += __shfl_xor(cs, 32, 64);
+      double v = (a < nb) ? rhs[k0 + a] - fsub_part[cur][a] - cs : 0.0;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const double yq = __shfl(v * inv, q, 16);       // final once every row above q has been subtracted
+        const double yq = lane_value_f64(v * inv, q);   // final once every row above q has been subtracted (the four 16-lane groups hold the same values)
         if (a > q) v -= Lr[q] * yq;
       }
       if (tid < nb) y[k0 + a] = v * inv;
+    } else if (b + 1 < nblk) {
+      // block b+1, columns < k0: one half wave per row
+      const size_t kbn = kb + 16 * krs, krn = krs + 16;
+      for (int h = hw - 2; h < 16; h += nhw - 2) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (k0 + 16 + h < n) {
+          const double* La = Lm + kbn + h * krn;
+          int j = t32;
+          for (; j + 96 < k0; j += 128) {                  // four loads in flight per lane
+            const double l0 = La[j], l1 = La[j + 32], l2 = La[j + 64], l3 = La[j + 96];
+            s0 += l0 * y[j]; s1 += l1 * y[j + 32]; s2 += l2 * y[j + 64]; s3 += l3 * y[j + 96];
+          }
+          for (; j < k0; j += 32) s0 += La[j] * y[j];
+        }
+        double sacc = (s0 + s1) + (s2 + s3);
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 32);
+        if (t32 == 0) fsub_part[nxt][h] = sacc;
+      }
     }
     __syncthreads();
   }
