@@ -611,9 +611,11 @@ static int next_refine_epoch(ddmpc_handle* h) {
   return ++h->epoch;
 }
 
+// large_mode (ROBUST controllers beyond the register-resident kernels only): 0 whole solve, 1 the data-dependent part alone
+// (ddmpc_prepare), 2 a solve on what that left in the workspace (ddmpc_step) -- see ddmpc_large_solve_kernel.
 static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
                        int32_t* status, int32_t* iters, double* lfac = nullptr, const int* only = nullptr,
-                       const KParams* kp_override = nullptr, bool want_ws = true, double* lfacT = nullptr) {
+                       const KParams* kp_override = nullptr, bool want_ws = true, double* lfacT = nullptr, int large_mode = 0) {
   int rc;
   h->beta_stale = false;
   h->rescue_ran = false;
@@ -632,11 +634,18 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
     if ((rc = h->d_act.ensure((size_t)h->batch * h->kp.rE))) return rc;
     const size_t lds = 6 * rv * sizeof(double) + 4 * rv * sizeof(int) + (size_t)PSD_PAN * sizeof(double);
     if (lds + 1024 > 160 * 1024) return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: %zu rows", r);
-    if (lds > 64 * 1024)
-      HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_large_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ddmpc_large_solve_kernel, dim3((unsigned)h->batch), dim3(large_threads(r)), lds, h->stream,
-                       kp_override ? *kp_override : h->kp, 16 * h->kc.NT, h->ud, h->yd, up, yp, uo, cost, (int*)status,
-                       (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, (double*)h->d_rr.p, (long long)stride);
+    if ((rc = h->d_rrmeta.ensure((size_t)h->batch * sizeof(int)))) return rc;
+    auto launch = [&](auto fn) -> int {
+      if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(fn, dim3((unsigned)h->batch), dim3(large_threads(r)), lds, h->stream,
+                         kp_override ? *kp_override : h->kp, 16 * h->kc.NT, h->ud, h->yd, up, yp, uo, cost, (int*)status,
+                         (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, (double*)h->d_rr.p, (long long)stride,
+                         (int*)h->d_rrmeta.p);
+      return DDMPC_OK;
+    };
+    if ((rc = large_mode == 1 ? launch(ddmpc_large_solve_kernel<1>) : large_mode == 2 ? launch(ddmpc_large_solve_kernel<2>)
+                                                                                     : launch(ddmpc_large_solve_kernel<0>)))
+      return rc;
     HIP_TRY(hipGetLastError());
     return DDMPC_OK;
   }
@@ -781,6 +790,11 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
 }
 
 typedef int (*launch_fn)(ddmpc_handle*, const double*, const double*, double*, double*, int32_t*, int32_t*);
+// ROBUST controller beyond the register-resident kernels, warm: a solve on what ddmpc_prepare left in the workspace
+static int launch_large_robust_warm(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
+                                    int32_t* status, int32_t* iters) {
+  return launch_cold(h, up, yp, uo, cost, status, iters, nullptr, nullptr, nullptr, true, nullptr, 2);
+}
 // NOMINAL controller beyond the register-resident kernels, warm: a solve on the factors ddmpc_prepare left in the workspace
 static int launch_large_nominal_warm(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
                                      int32_t* status, int32_t* iters) {
@@ -973,7 +987,14 @@ int ddmpc_prepare(ddmpc_handle* h) {
     h->prepared = true;
     return DDMPC_OK;
   }
-  if (h->large) return DDMPC_OK;          // ROBUST at this size: every step is a full solve
+  if (h->large) {                         // ROBUST at this size: Gram + lam D, the factor of the columns outside the slack box and
+                                          // the Schur complement of the boxed block are formed once and kept
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = launch_cold(h, h->ud, h->yd, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, nullptr, 1);
+    if (rc) return rc;
+    h->prepared = true;
+    return DDMPC_OK;
+  }
   HIP_TRY(hipSetDevice(h->device));
   const ddmpc_params& p = h->prm;
   const KParams& k = h->kp;
@@ -1059,13 +1080,12 @@ int ddmpc_step(ddmpc_handle* h, const double* u_past, const double* y_past, doub
                int32_t* status, int32_t* iters, int mem) {
   if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
   if (!h->have_data) return fail(DDMPC_ERR_NOT_READY, "ddmpc_set_data must be called before ddmpc_step");
-  if (h->large && !h->large_nominal) return solve_impl(h, u_past, y_past, u_opt, cost, status, iters, mem, &launch_cold_plain);
   if (!h->prepared) {
     int rc = ddmpc_prepare(h);
     if (rc) return rc;
   }
   return solve_impl(h, u_past, y_past, u_opt, cost, status, iters, mem,
-                    h->large_nominal ? &launch_large_nominal_warm : &launch_warm_plain);
+                    h->large_nominal ? &launch_large_nominal_warm : h->large ? &launch_large_robust_warm : &launch_warm_plain);
 }
 
 int ddmpc_get_gain(ddmpc_handle* h, double* out, int mem) {
@@ -1315,7 +1335,7 @@ int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps
   }
   const bool warm_ok = h->closed_loop_path != DDMPC_PATH_COLD &&
                        (size_t)n_mpc_step * m <= (size_t)WARM_MAX_NF && n * h->kp.nch <= WARM_MAX_NF;
-  const bool warm_large = h->large_nominal && h->closed_loop_path != DDMPC_PATH_COLD;   // per step, on the factors of ddmpc_prepare
+  const bool warm_large = h->large && h->closed_loop_path != DDMPC_PATH_COLD;           // per step, on what ddmpc_prepare kept
   if (warm_large && (rc = ddmpc_prepare(h))) return rc;
   bool warm = warm_ok && !h->kp.convex && !h->large;   // no inequality: fused loop, one launch
   const bool warm_box = warm_ok && h->kp.convex && !h->large;     // slack box: per step, affine iterate + cold re-solve where a bound is active
@@ -1368,7 +1388,7 @@ int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps
   auto enqueue_steps = [&]() -> int {
     for (int t = 0; !warm && t < n_steps; t += n_mpc_step) {
       int rcs = warm_box ? launch_warm(h, dup, dyp, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int32_t*)h->d_status.p, nullptr)
-                : warm_large ? launch_large_nominal_warm(h, dup, dyp, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int32_t*)h->d_status.p, nullptr)
+                : warm_large ? (h->large_nominal ? launch_large_nominal_warm : launch_large_robust_warm)(h, dup, dyp, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int32_t*)h->d_status.p, nullptr)
                          : launch_cold_plain(h, dup, dyp, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int32_t*)h->d_status.p, nullptr);
       if (rcs) return rcs;
       const int nsub = (t + n_mpc_step <= n_steps) ? n_mpc_step : n_steps - t;

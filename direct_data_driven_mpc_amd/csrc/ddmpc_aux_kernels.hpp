@@ -1971,6 +1971,11 @@ __global__ __launch_bounds__(512, DDMPC_RR_WAVES) void ddmpc_nominal_rr_kernel(K
 // status and iteration count as ddmpc_cold_solve_kernel (ddmpc_kernels.hpp); scalar, diagonal or dense weights.  One workgroup
 // per instance.  Workspace per instance: r(r+1)/2 + max(Ln*nch^2, 2*|B|(|B|+1)/2) doubles.
 // ---------------------------------------------------------------------------------------------------------------
+// MODE 0: the whole solve (ddmpc_solve).  MODE 1: what depends on the data and the weights alone -- Gram + lam D, the factor
+// of the A columns, the Schur complement of the boxed block -- left in the workspace, with the outcome of that
+// factorisation in meta_ws[b] (ddmpc_prepare).  MODE 2: a solve on what a MODE-1 launch left there (ddmpc_step: only the past
+// window has changed, controller.py:389-407); same arithmetic, so the results are bit-equal to MODE 0's.
+template <int MODE>
 __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, int RPs, const double* __restrict__ u_d,
                                                                 const double* __restrict__ y_d,
                                                                 const double* __restrict__ u_past,
@@ -1979,7 +1984,7 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
                                                                 int* __restrict__ status, int* __restrict__ iters,
                                                                 double* __restrict__ beta_ws,
                                                                 signed char* __restrict__ act_ws, double* scratch,
-                                                                long long scratch_stride) {
+                                                                long long scratch_stride, int* __restrict__ meta_ws) {
   extern __shared__ __attribute__((aligned(16))) double lsm_lds[];
   const long long b = blockIdx.x;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -2038,6 +2043,8 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
       if (t32 == 0 && rho < r) wib[rho] = sacc;
     }
   };
+  int st = 0, iter = 0;
+  if constexpr (MODE != 2) {
   hankel_gram_packed(P, ud, yd, G, G + npk, iperm, pan);   // lag table in the (not yet used) storage behind G
   __syncthreads();
   if (P.dense_w) {     // dense weighting matrices: lam * W^-1 (shared by the batch, component order) on every pair of components;
@@ -2051,16 +2058,20 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
   for (int i = tid; i < nA; i += nthr) G[pk_row(i) + i] += P.lam * P.tabd[0 * RPs + perm[i]];
   __syncthreads();
   packed_psd_cholesky(G, r, 0.0, skip, pan, nA);        // columns of A only; a pivot that is not positive is skipped
-  int st = 0, iter = 0;
   {
     double nbad = 0.0;
     for (int i = tid; i < nA; i += nthr) nbad += skip[i] ? 1.0 : 0.0;
     if (block_sum(nbad, red) != 0.0) st = 4;            // uniform
   }
   __syncthreads();
+  // S = K_BB - L_BA L_BA'  (the diagonal shift of B is added per active set)
+  if (st == 0) packed_schur_mfma(G, nA, nB, nA, S);
+  if (tid == 0) meta_ws[b] = st;                        // (a whole solve leaves the same record behind as MODE 1)
+  if constexpr (MODE == 1) return;
+  } else {
+    st = meta_ws[b];                                    // uniform: how the factorisation of the A columns went
+  }
   if (st == 0) {
-    // S = K_BB - L_BA L_BA'  (the diagonal shift of B is added per active set)
-    packed_schur_mfma(G, nA, nB, nA, S);
     // L_AA y_A = t_A (t_A does not depend on the active set), zb = L_BA y_A
     packed_forward_substitute(G, nA, ct, yv, nullptr, red);
     packed_rows_times(G, nA, nB, 0, yv, [&](int) { return nA; }, [&](int i, double sacc) { zb[i] = sacc; });

@@ -138,11 +138,11 @@ int ddmpc_device_count(void);
  * matrices in a global workspace (a Gram-route solve plus refinement with exact Hankel products; throughput: see
  * profiles/README.md): ROBUST ones on ddmpc_large_solve_kernel (same outputs, status, iterations, ddmpc_get_solution),
  * NOMINAL ones on the rank-revealing kernel (ddmpc_get_solution: ubar / ybar from its z, alpha = H'x from the vector it
- * exports).  No affine law is formed at that size (ddmpc_get_gain is DDMPC_ERR_UNSUPPORTED); the warm path of a NOMINAL
- * controller there is factor reuse -- ddmpc_prepare forms what depends on the data alone (Gram, its rank-revealing
- * factor, the reduced normal matrix and its factor), ddmpc_step and the per-step closed loop solve on those factors,
- * with results bit-equal to ddmpc_solve's -- while for a ROBUST one ddmpc_prepare is a no-op and ddmpc_step ==
- * ddmpc_solve.  Dense weighting matrices of a NOMINAL controller beyond 271 rows, and any problem beyond
+ * exports).  No affine law is formed at that size (ddmpc_get_gain is DDMPC_ERR_UNSUPPORTED); the warm path there is
+ * factor reuse -- ddmpc_prepare forms what depends on the data and the weights alone (NOMINAL: Gram, its rank-revealing
+ * factor, the reduced normal matrix and its factor; ROBUST: Gram + lam D, the factor of the columns outside the slack
+ * box, the Schur complement of the boxed block), ddmpc_step and the per-step closed loop solve on what it kept, with
+ * results bit-equal to ddmpc_solve's.  Dense weighting matrices of a NOMINAL controller beyond 271 rows, and any problem beyond
  * 1024 rows, are DDMPC_ERR_UNSUPPORTED (reported by ddmpc_create).
  *
  * Replaces DirectDataDrivenMPCController.__init__ parameter validation
@@ -205,7 +205,7 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
  *   The status of a warm step is the status of the factorisation it rests on.
  * ddmpc_get_gain: out [batch, nf+1, r] doubles, r = (m+p)(L+n) components in the internal
  *   time-major order rho = k*(m+p) + ch (ch < m: ubar, else ybar+sigma).
- * Beyond 271 rows: see the note on problem sizes at ddmpc_create (NOMINAL: the factors are kept, no law). */
+ * Beyond 271 rows: see the note on problem sizes at ddmpc_create (the data-dependent factors are kept, no law). */
 int ddmpc_prepare(ddmpc_handle* h);
 int ddmpc_step(ddmpc_handle* h, const double* u_past, const double* y_past,
                double* u_opt, double* cost, int32_t* status, int32_t* iters, int mem);

@@ -223,3 +223,68 @@ def test_large_nominal_closed_loop_warm_equals_cold(gpu):
     u_sys, y_sys, status = out["auto"][:3]
     assert np.all(status == 0)
     assert np.max(np.abs(y_sys[:, -1, :] - spec.y_s)) < np.max(np.abs(y_sys[:, 0, :] - spec.y_s))      # it is heading for the setpoint
+
+
+@pytest.mark.parametrize("slack", ["none", "convex"])
+def test_large_robust_warm_step_reuses_the_factors(gpu, slack):
+    # ROBUST scheme beyond the register-resident kernels (m = p = 3, L = 44: 288 rows): ddmpc_prepare keeps Gram + lam D, the
+    # factor of the columns outside the slack box and the Schur complement of the boxed block; ddmpc_step runs the rest
+    # (substitutions, active-set iterations on the boxed block, refinement) on them -- bit-equal to ddmpc_solve, for two
+    # past windows and after a change of the data set; and right: against the full-space oracle
+    rng = np.random.default_rng(11)
+    m = p = 3; ns = n = 4; Lh = 44; N = 700; B = 4
+    import test_gpu_parity as T
+    plant = T._random_plant(rng, ns, m, p, 0.002)
+    spec = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=2.0 * np.eye(p * Lh), R=0.05 * np.eye(m * Lh), u_s=0.1 * np.ones(m),
+                      y_s=0.05 * np.ones(p), robust=True, eps_max=0.002, lamb_alpha=30.0, lamb_sigma=800.0, c=1.0, slack=slack, tec=True)
+    d = harness.generate_batch(range(70, 70 + B), N=N, plant=plant)
+    d2 = harness.generate_batch(range(90, 90 + B), N=N, plant=plant)
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    up2 = d["u_d"][:, 50:50 + n, :].reshape(B, -1).copy(); yp2 = d["y_d"][:, 50:50 + n, :].reshape(B, -1).copy()
+    with _spec_engine(spec, N, B) as eng:
+        assert "large_solve" in eng.kernel_name()
+        eng.set_data(d["u_d"], d["y_d"])
+        cold1 = tuple(x.copy() for x in eng.solve(up, yp))
+        cold2 = tuple(x.copy() for x in eng.solve(up2, yp2))
+        eng.prepare()
+        warm2 = tuple(x.copy() for x in eng.step(up2, yp2))
+        sg = eng.get_solution("sigma")
+        warm1 = tuple(x.copy() for x in eng.step(up, yp))
+        for c, w in ((cold1, warm1), (cold2, warm2)):
+            assert np.all(c[2] == 0)
+            for k in range(4):
+                assert np.array_equal(c[k], w[k]), k
+        assert not np.array_equal(cold1[0], cold2[0]) and np.all(np.isfinite(sg))
+        eng.set_data(d2["u_d"], d2["y_d"])
+        upn = d2["u_d"][:, -n:, :].reshape(B, -1).copy(); ypn = d2["y_d"][:, -n:, :].reshape(B, -1).copy()
+        warm_new = tuple(x.copy() for x in eng.step(upn, ypn))          # prepares on first use
+        cold_new = tuple(x.copy() for x in eng.solve(upn, ypn))
+        assert np.array_equal(warm_new[0], cold_new[0]) and np.array_equal(warm_new[1], cold_new[1])
+    for b in range(B):
+        sol = orc.solve_fullspace(spec, d["u_d"][b], d["y_d"][b], up2[b], yp2[b])
+        assert sol.status == "optimal" and (slack == "none" or int(warm2[3][b]) == sol.iters)
+        assert np.max(np.abs(warm2[0][b] - sol.optimal_u)) / np.max(np.abs(sol.optimal_u)) < TOL_U
+        assert abs(warm2[1][b] - sol.cost) <= TOL_COST * abs(sol.cost)
+
+
+def test_large_robust_closed_loop_warm_equals_cold(gpu):
+    # per-step closed loop of a ROBUST controller beyond the register-resident kernels (slack box): the default path (solves on
+    # what ddmpc_prepare kept) and a full solve per step (DDMPC_PATH_COLD) give bit-equal trajectories
+    rng = np.random.default_rng(11)
+    m = p = 3; ns = n = 4; Lh = 44; N = 700; B = 3; n_steps = 12
+    import test_gpu_parity as T
+    plant = T._random_plant(rng, ns, m, p, 0.002)
+    spec = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=2.0 * np.eye(p * Lh), R=0.05 * np.eye(m * Lh), u_s=0.1 * np.ones(m),
+                      y_s=0.05 * np.ones(p), robust=True, eps_max=0.002, lamb_alpha=30.0, lamb_sigma=800.0, c=1.0, slack="convex", tec=True)
+    d = harness.generate_batch(range(70, 70 + B), N=N, plant=plant)
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    w = 0.002 * np.random.default_rng(5).uniform(-1, 1, size=(B, n_steps, p))
+    out = {}
+    for path in ("auto", "cold"):
+        with _spec_engine(spec, N, B) as eng:
+            eng.set_data(d["u_d"], d["y_d"])
+            eng.set_closed_loop_path(path)
+            out[path] = eng.closed_loop(plant["A"], plant["B"], plant["C"], plant["D"], d["x_end"], up, yp, w, n_mpc_step=1)
+    for a, b in zip(out["auto"], out["cold"]):
+        assert np.array_equal(a, b)
+    assert np.all(out["auto"][2] == 0)

@@ -34,8 +34,7 @@ def large_flops(m, p, n, Lh, N, robust, iters=1.0, passes=1):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser(); ap.add_argument("--robust", action="store_true"); ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512)
-    ap.add_argument("--warm", action="store_true", help="also time ddmpc_prepare and ddmpc_step (NOMINAL: solves on the factors kept "
-                    "from ddmpc_prepare)")
+    ap.add_argument("--warm", action="store_true", help="also time ddmpc_prepare and ddmpc_step (solves on what ddmpc_prepare kept)")
     a = ap.parse_args()
     rng = np.random.default_rng(0)
     ns = n = 8; m = p = 8; Lh = 30; N = 2000; B = a.batch
@@ -68,7 +67,7 @@ if __name__ == "__main__":
     print("%s B=%d: %.2f ms per batch, %.3e solves/s; status ok %s; %.1f MFLOP per solve (algorithmic) -> %.2f TFLOP/s = %.3f of the "
           "%.1f TF fp64-MFMA peak" % (eng.kernel_name(), B, ms, rate, bool((out[2] == 0).all()), fl / 1e6, rate * fl / 1e12,
                                       rate * fl / 1e12 / PEAK_TF, PEAK_TF))
-    if a.warm and not a.robust:
+    if a.warm:
         torch.cuda.synchronize()
         e0.record()
         eng.prepare()
