@@ -52,7 +52,7 @@ fi
 if [ "$PART" = "cfg5" ] || [ "$PART" = "all" ]; then
 # BASELINE configs[4] (nominal, m=p=8, r=608, exact data) and the robust scheme at that size: the global-workspace kernels
 timeout -k 10 200 python tools/cfg5_time.py --warm > "$OUT/cfg5_time.log" 2>&1
-timeout -k 10 200 python tools/cfg5_time.py --robust >> "$OUT/cfg5_time.log" 2>&1
+timeout -k 10 200 python tools/cfg5_time.py --robust --warm >> "$OUT/cfg5_time.log" 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg5_stats" -- \
     python tools/cfg5_time.py --steps 3 > "$OUT/cfg5_stats.log" 2>&1
 pass5() {  # name, counters...
