@@ -1287,7 +1287,7 @@ __device__ __forceinline__ void packed_schur_mfma(const double* Lm, int row0, in
 //   z[(k0+j) nch + ch] = sum_i X[i+k0+j][ch] alpha_i             thread = (4 offsets k0.., channel, a part of the i range): loop over i,
 //                                                                2 loads per 4 FMAs; accumulators live in registers across ALL chunks
 // (the one-column-per-half-wave form above moves 2 LDS loads per FMA: 38 MB of LDS traffic per call at the cfg-5 size, 320 us
-// measured; this form: 45 us).  The next chunk of the trajectory is fetched into registers while the current one is worked on.
+// measured; this form: 160 us).  The next chunk of the trajectory is fetched into registers while the current one is worked on.
 // Returns false (nothing done) for shapes it does not cover.
 __device__ __forceinline__ bool hankel_normal_times_blocked(const KParams& P, const double* __restrict__ ud,
                                                             const double* __restrict__ yd, const double* x, double* z, double* pan) {
@@ -1637,7 +1637,7 @@ __device__ __forceinline__ double block_max(double v, double* red) {
 // Stable partition of the components 0 .. r-1 by class (cls(rho) in 0 .. NC-1, anything else: dropped): perm[position] = rho
 // with class 0 first and the component order kept inside a class; cnt[k] = members of class k.  Every thread scans the
 // class table (r ints of LDS scratch `kcl`, broadcast reads) for its own components: O(r) per thread, all in parallel --
-// a single thread walking the table costs one dependent L2 round trip per component (1.1 ms for 608 rows, measured).
+// a single thread walking the table costs one dependent L2 round trip per component (0.2 ms of a cfg-5 batch, measured).
 template <int NC, class ClsF>
 __device__ __forceinline__ void stable_partition(int r, ClsF&& cls, int* perm, int* kcl, int* cnt) {
   const int tid = threadIdx.x, nthr = blockDim.x;
