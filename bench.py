@@ -141,6 +141,140 @@ def cpu_baseline(cfg, u_d, y_d, up, yp, n_sample, repeats=5):
     return rec, (u_c, c_c, st_c), (u_f, c_f)
 
 
+def large_flops(m, p, n, Lh, N, robust, iters=1.0, passes=1):
+    """Algorithmic flops of one solve beyond the register-resident kernels (what the mathematics needs, not what the tiles
+    execute): Hankel-structured Gram (lag sums + window walk), Cholesky, reduced system, refinement with exact products."""
+    nch, Ln = m + p, Lh + n
+    r, c = nch * Ln, N - Ln + 1
+    gram = 2.0 * nch * nch * Ln * c + 2.0 * r * r
+    refine = passes * (8.0 * r * c + 8.0 * r * r)            # two H(H'x) products and four triangular solves per pass
+    if robust:
+        nB = p * Lh                                          # boxed components: re-factored per active-set iteration
+        return gram + r ** 3 / 3.0 + (iters - 1.0) * nB ** 3 / 3.0 + 4.0 * r * r * iters + refine / 2.0
+    nF = 2 * n * nch                                         # fixed components (past window + terminal steps)
+    nR = r - nF
+    return gram + r ** 3 / 3.0 + 2.0 * nR ** 3 / 3.0 + 6.0 * r * r + refine
+
+
+def config5_problem(B):
+    """BASELINE configs[4] as SURVEY section 8 fixes it: nominal scheme, m = p = 8, n = 8, L = 30, N = 2000, exact data of a
+    seeded random stable plant (spectral radius 0.9), u_s = 0.1, y_s its equilibrium output, q = 3, r = 1e-4."""
+    from direct_data_driven_mpc_amd.harness import generate_batch
+    rng = np.random.default_rng(0)
+    ns = n = 8; m = p = 8; Lh = 30; N = 2000
+    A = rng.normal(size=(ns, ns)); A *= 0.9 / max(abs(np.linalg.eigvals(A)))
+    plant = dict(A=A, B=rng.normal(size=(ns, m)), C=rng.normal(size=(p, ns)), D=np.zeros((p, m)), eps_max=0.0)
+    u_s = 0.1 * np.ones(m)
+    y_s = (plant["C"] @ np.linalg.inv(np.eye(ns) - A) @ plant["B"]) @ u_s
+    d = generate_batch(range(B), N=N, plant=plant)
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    return dict(n=n, m=m, p=p, L=Lh, N=N, plant=plant, u_s=u_s, y_s=y_s, u_d=d["u_d"], y_d=d["y_d"], up=up, yp=yp, q=3.0, r=1e-4)
+
+
+def other_configs_host(cfg_base, n_check=64, n_check5=16):
+    """Host side of the `other_configs` block, BEFORE the GPU runtime is initialised: synthetic inputs of the other BASELINE
+    configurations and the checker's answers on a sample of each (compiled C restatement; cfg 5: the model-based solution of
+    the same QP).  Returns a list of job dicts that other_configs_device() times."""
+    from direct_data_driven_mpc_amd.harness import controller_params, generate_batch
+    from oracle import ddmpc_oracle as orc
+    from oracle import oracle_c
+    from oracle.nominal_exact import solve_nominal_model_based
+    jobs = []
+
+    def four_tank(tag, B, Lh, N, slack, seed0):
+        cfg = controller_params(dict(L=Lh, N=N, slack_var_constraint_type=slack))
+        d = generate_batch(range(seed0, seed0 + B), N=N)
+        n = cfg["n"]
+        up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+        spec = _oracle_spec(cfg)
+        k = min(n_check, B)
+        u_c, c_c, st_c, it_c = oracle_c.solve_batch(spec, N, d["u_d"][:k], d["y_d"][:k], up[:k], yp[:k], threads=host_cores())
+        jobs.append(dict(tag=tag, kind="four_tank", cfg=cfg, B=B, u_d=d["u_d"], y_d=d["y_d"], up=up, yp=yp, slack=slack,
+                         ref=(u_c, c_c, st_c, it_c), checker="oracle/ddmpc_oracle_c.c"))
+
+    four_tank("cfg2_convex: four-tank robust L=30 N=400, slack CONVEX, batch 4096 (BASELINE configs[1], SURVEY 8d)", 4096, 30, 400, 1, 0)
+    four_tank("cfg3_shard: four-tank robust L=30 N=400, slack NONE, one rank's 32768 of 262144 (BASELINE configs[2])", 32768, 30, 400, 0, 0)
+    four_tank("cfg4_none: four-tank robust L=60 N=1000, slack NONE, batch 1024 (BASELINE configs[3])", 1024, 60, 1000, 0, 0)
+    four_tank("cfg4_convex: four-tank robust L=60 N=1000, slack CONVEX, batch 1024 (BASELINE configs[3])", 1024, 60, 1000, 1, 0)
+    c5 = config5_problem(512)
+    spec5 = orc.QPSpec(n=c5["n"], m=c5["m"], p=c5["p"], L=c5["L"], Q=c5["q"] * np.eye(c5["p"] * c5["L"]),
+                       R=c5["r"] * np.eye(c5["m"] * c5["L"]), u_s=c5["u_s"], y_s=c5["y_s"], robust=False, eps_max=0.0,
+                       lamb_alpha=0.0, lamb_sigma=0.0, c=0.0, slack="none", tec=True)
+    k = min(n_check5, 512)
+    u5 = np.empty((k, c5["L"] * c5["m"])); cc5 = np.empty(k)
+    for b in range(k):
+        mod = solve_nominal_model_based(spec5, c5["plant"], c5["up"][b], c5["yp"][b])
+        u5[b] = mod["optimal_u"]; cc5[b] = mod["cost"]
+    jobs.append(dict(tag="cfg5: nominal m=p=8 n=8 L=30 N=2000, exact data, batch 512 (BASELINE configs[4])", kind="cfg5", c5=c5, B=512,
+                     ref=(u5, cc5, np.zeros(k, dtype=np.int32), None), checker="oracle/nominal_exact.py (model-based solution of the same QP)"))
+    return jobs
+
+
+def other_configs_device(jobs, dev, steps=10):
+    """Times every job of other_configs_host() on the GPU (inputs resident, HIP events on the launch stream, outside the
+    headline's timed region) and checks the sample against the checker's answers."""
+    import torch
+    from direct_data_driven_mpc_amd import _lib as L
+    from direct_data_driven_mpc_amd.engine import BatchedDDMPC
+    out = []
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def timed(fn, k):
+        fn(); fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(k):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return float(e0.elapsed_time(e1)) / k
+
+    for j in jobs:
+        B = j["B"]
+        if j["kind"] == "four_tank":
+            cfg = j["cfg"]
+            n, m, p = cfg["n"], cfg["m"], cfg["p"]
+            eng = BatchedDDMPC(n=n, m=m, p=p, L_=cfg["L"], N=cfg["N"], Q=cfg["Q"], R=cfg["R"], u_s=cfg["u_s"], y_s=cfg["y_s"],
+                               batch=B, controller_type=L.ROBUST, slack_type=L.SLACK_CONVEX if j["slack"] else L.SLACK_NONE,
+                               eps_max=cfg["eps_max"], lamb_alpha=cfg["lamb_alpha"], lamb_sigma=cfg["lamb_sigma"], c=cfg["c"],
+                               use_terminal_constraint=cfg["tec"], device=dev.index)
+            flops, _ = eng.cost_model()
+        else:
+            c5 = j["c5"]
+            n, m, p = c5["n"], c5["m"], c5["p"]
+            eng = BatchedDDMPC(n=n, m=m, p=p, L_=c5["L"], N=c5["N"], Q=c5["q"], R=c5["r"], u_s=c5["u_s"], y_s=c5["y_s"], batch=B,
+                               controller_type=L.NOMINAL, device=dev.index)
+            flops = large_flops(m, p, n, c5["L"], c5["N"], False)
+        src = j if j["kind"] == "four_tank" else j["c5"]
+        ud, yd, up, yp = t(src["u_d"]), t(src["y_d"]), t(src["up"]), t(src["yp"])
+        eng.set_data(ud, yd)
+        res = eng.solve(up, yp)
+        ms = timed(lambda: eng.solve(up, yp, *res), steps)
+        u, c, st, it = (x.cpu().numpy() for x in res)
+        ur, cr, sr, ir = j["ref"]
+        k = ur.shape[0]
+        rec = dict(workload=j["tag"], kernel=eng.kernel_name(), batch=B, ms_per_step=ms, value=B / (ms * 1e-3), unit="QP solves/s",
+                   flops_per_solve=flops, frac=flops * B / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, non_optimal_instances=int(np.count_nonzero(st)),
+                   iters_mean=float(it.mean()),
+                   parity=dict(checker=j["checker"], checked=int(k),
+                               max_rel_err_u=float(np.max(np.max(np.abs(u[:k] - ur), axis=1) / np.max(np.abs(ur), axis=1))),
+                               max_rel_err_cost=float(np.max(np.abs(c[:k] - cr) / np.abs(cr))),
+                               status_equal=bool(np.array_equal(st[:k], sr)),
+                               iters_equal=(None if ir is None else bool(np.array_equal(it[:k], ir))), tol_u=1e-8, tol_cost=1e-9))
+        if j["kind"] == "cfg5":           # warm: the data-dependent part once per data set (ddmpc_prepare), then ddmpc_step
+            torch.cuda.synchronize(); tp = time.perf_counter()
+            eng.prepare()
+            torch.cuda.synchronize(); prep_ms = (time.perf_counter() - tp) * 1e3
+            w = eng.step(up, yp)
+            wms = timed(lambda: eng.step(up, yp, *w), steps)
+            rec["warm_step"] = dict(ms_per_step=wms, value=B / (wms * 1e-3), unit="control steps/s", prepare_ms=prep_ms,
+                                    max_rel_diff_vs_cold_u=float((w[0] - res[0]).abs().max() / res[0].abs().max()))
+        out.append(rec)
+        eng.close()
+        del eng, ud, yd, up, yp
+    return out
+
+
 def default_batch_per_gpu(gpus):
     """--gpus 1: BASELINE configs[1] (4096 seeds on one GPU).  --gpus N > 1: BASELINE configs[2]'s shard, 32,768 seeds
     per GPU (262,144 over 8), the batch at which a GPU is 9 % faster per instance than at 4096 (profiles/)."""
@@ -175,6 +309,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-warm", action="store_true", help="skip the secondary warm-step measurement")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `other_configs` block (the other BASELINE configurations, timed outside the headline's timed region)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: run all ranks on device 0 with the gloo backend (exercises the "
                          "multi-rank code path on a one-GPU box; numbers are meaningless)")
@@ -217,6 +353,9 @@ def main():
     cpu = None
     if world == 1 and rank == 0 and not a.no_cpu_baseline:
         cpu = cpu_baseline(cfg, u_d_h, y_d_h, up_h, yp_h, min(a.cpu_sample, B))
+    other_jobs = None
+    if world == 1 and rank == 0 and not a.no_other_configs and not a.no_cpu_baseline and a.slack == "none" and not a.force_dist:
+        other_jobs = other_configs_host(cfg)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
     if a.rehearse_on_one_gpu:
@@ -359,6 +498,17 @@ def main():
             big.close()
             del big, upb, ypb, uob, cob, sob, iob
 
+    others = None
+    if rank == 0 and other_jobs is not None:
+        others = other_configs_device(other_jobs, dev)
+    dist_info = None
+    if use_dist:
+        # what the process group itself saw (not the environment): world size, backend, and the device every rank bound
+        mine = dict(rank=dist.get_rank(), device=int(local_rank), name=torch.cuda.get_device_name(local_rank),
+                    uuid=str(getattr(torch.cuda.get_device_properties(local_rank), "uuid", "")))
+        seen = [None] * dist.get_world_size()
+        dist.all_gather_object(seen, mine)
+        dist_info = dict(world_size=dist.get_world_size(), backend=dist.get_backend(), ranks=seen)
     if rank == 0:
         flops, bytes_ = eng.cost_model()
         achieved = flops * B / (kern_ms * 1e-3) / 1e12
@@ -375,7 +525,9 @@ def main():
                        "global_batch": total,
                        "parallelism": "instances sharded dp%d, no data-path collective, one final all-gather%s" % (
                            world, " (RCCL branch forced at world size 1)" if (a.force_dist and world == 1) else ""),
-                       "refinement": "auto (every solve checked with the exact-Hankel residual; flagged instances re-solved)",
+                       "refinement": "auto, two-stage per solve: an a-priori bound q = eps max(G_kk) |beta| / |t| dismisses an instance "
+                                     "outright; only undecided ones form the exact-Hankel residual, and only those above the threshold "
+                                     "are re-solved by the refining variant (on this data the bound dismisses every instance)",
                        "kernel": eng.kernel_name(), "non_optimal_instances": n_bad, "kernel_source_hash": kernel_source_hash()},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
@@ -385,6 +537,10 @@ def main():
         }
         if warm is not None:
             out["warm_step"] = warm
+        if others is not None:
+            out["other_configs"] = others
+        if dist_info is not None:
+            out["distributed"] = dist_info
         if cpu is not None:
             base, (u_c, c_c, st_c), (u_f, c_f) = cpu
             ns = u_c.shape[0]

@@ -761,7 +761,10 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
     if (!rcz) rcz = h->d_resc.ensure((size_t)h->batch * sizeof(int));
     if (!rcz) rcz = h->d_xws.ensure((size_t)h->batch * h->kp.rE * sizeof(double));
     if (rcz) return rcz;
-    HIP_TRY(hipMemsetAsync(h->d_resc.p, 0, (size_t)h->batch * sizeof(int), h->stream));
+    // (a factors-only launch, rr_mode 1, writes neither z_ws, x_ws nor the flags: what the previous solve left there stays
+    //  readable by ddmpc_get_solution, so the flags must not be cleared -- ddmpc_solve -> ddmpc_prepare -> ddmpc_get_solution)
+    if (rr_mode != 1 || !h->rescue_ran)
+      HIP_TRY(hipMemsetAsync(h->d_resc.p, 0, (size_t)h->batch * sizeof(int), h->stream));
   }
   // rank tolerance 1e-8 (relative to the largest diagonal entry of the Gram): with the fixed-first ordering the
   // pivots of dependent rows come out as rounding residue up to ~3e-10, genuine ones are >= ~5e-7 on exact
@@ -1015,6 +1018,28 @@ int ddmpc_prepare(ddmpc_handle* h) {
   if ((rc = launch_cold(h, z, z + B * p.n * p.m, (double*)h->d_uopt.p, (double*)h->d_cost.p,
                         (int32_t*)h->d_prep_status.p, nullptr, (double*)h->d_lfac.p, nullptr, &k0, true, (double*)h->d_lfacT.p)))
     return rc;
+  if (k.lam != 0.0 && k.refine == DDMPC_REFINE_AUTO) {
+    // AUTO decides from the exact-Hankel residual of a solve, which depends on the right-hand side -- and the factor-export
+    // solve above runs at the ZERO past window (with zero setpoints its right-hand side vanishes: beta = 0, residual 0,
+    // nothing would ever be flagged).  So the data sets are probed once more with a plain solve at the window a controller
+    // starts from, the last n steps of its own data (controller.py:184-185), and the two sets of flags are joined.
+    const int npu = p.n * p.m, npy = p.n * p.p;
+    if ((rc = h->d_status.ensure(B * sizeof(int32_t))) || (rc = h->d_need.ensure((B + 1) * sizeof(int)))) return rc;
+    double* pu = (double*)h->d_zero.p;
+    double* py = pu + B * (size_t)npu;
+    hipLaunchKernelGGL(ddmpc_tail_past_kernel, dim3((unsigned)((B * (size_t)(npu + npy) + 255) / 256)), dim3(256), 0, h->stream,
+                       (long long)B, p.N, p.m, p.p, p.n, h->ud, h->yd, pu, py);
+    HIP_TRY(hipMemsetAsync(h->d_need.p, 0, (B + 1) * sizeof(int), h->stream));
+    KParams kprobe = k0;
+    kprobe.epoch = h->prep_epoch;
+    hipLaunchKernelGGL(h->kc.fn2, dim3((unsigned)B), dim3(64 * h->kc.W), h->lds_bytes, h->stream, kprobe, h->ud, h->yd,
+                       (const double*)pu, (const double*)py, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int*)h->d_status.p,
+                       (int*)nullptr, (double*)nullptr, (signed char*)nullptr, (unsigned long long*)nullptr, (double*)nullptr,
+                       (double*)nullptr, (int*)h->d_need.p, (const int*)nullptr, 0LL, (int*)h->d_need.p + B);
+    hipLaunchKernelGGL(ddmpc_or_flags_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, (long long)B,
+                       h->prep_epoch, (const int*)h->d_need.p, (int*)h->d_rflag.p);
+    HIP_TRY(hipGetLastError());
+  }
   const size_t ntiles = B * (size_t)(NT * (NT + 1) / 2);
   if (ntiles > 0x7fffffffULL) return fail(DDMPC_ERR_INVALID, "batch too large for ddmpc_prepare");
   if ((rc = h->d_beta.ensure(B * k.rE * sizeof(double)))) return rc;     // beta of the cold launch above

@@ -310,6 +310,27 @@ __global__ void ddmpc_unit_past_kernel(long long batch, int npu, int npy, int f,
   const double v = (i == f) ? 1.0 : 0.0;
   if (i < npu) up[b * npu + i] = v; else yp[b * npy + (i - npu)] = v;
 }
+// The past window a controller starts from: the last n steps of its own data (controller.py:184-185), for the whole batch.
+// ddmpc_prepare (AUTO) probes the conditioning of every data set with a solve at THIS window: the factor-export solve runs
+// at the zero window, whose right-hand side vanishes altogether for zero setpoints (beta = 0, nothing to flag).
+__global__ void ddmpc_tail_past_kernel(long long batch, int N, int m, int p, int n, const double* __restrict__ u_d,
+                                       const double* __restrict__ y_d, double* __restrict__ up, double* __restrict__ yp) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const int npu = n * m, npy = n * p, np = npu + npy;
+  if (idx >= batch * np) return;
+  const long long b = idx / np;
+  const int i = (int)(idx - b * np);
+  if (i < npu) up[b * npu + i] = u_d[(b * N + (N - n)) * m + i];
+  else yp[b * npy + (i - npu)] = y_d[(b * N + (N - n)) * p + (i - npu)];
+}
+// flags of the probe solve (their own buffer, same stamp) joined into the flags of the factor-export solve; word `batch` of
+// both buffers is the largest stamp that flagged anything
+__global__ void ddmpc_or_flags_kernel(long long batch, int epoch, const int* __restrict__ probe, int* __restrict__ flags) {
+  const long long b = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (b >= batch || probe[b] != epoch) return;
+  flags[b] = epoch;
+  atomicMax(flags + batch, epoch);
+}
 __global__ void ddmpc_gain_column_kernel(long long batch, int r, int rE, int nrhs, int j, const double* __restrict__ beta,
                                          double* __restrict__ gain, const int* __restrict__ flags, int epoch) {
   const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -704,12 +725,15 @@ __device__ __forceinline__ void psd_tile_factor(double* Dg, double* Ms, double* 
       old[t] = on ? Dg[rr * 16 + c2] : 0.0;
     }
     const bool sk = !(dk > tol_abs);                   // the same value in every lane
-    // 1/sqrt by the hardware seed + one Newton step (relative error ~1e-16): `1.0 / sqrt(dk)` expands to two long
-    // software sequences on the critical path of every column of every diagonal tile
+    // 1/sqrt by the hardware seed + two Newton steps: `1.0 / sqrt(dk)` expands to two long software sequences on the
+    // critical path of every column of every diagonal tile.  The seed is only good to ~2^-24..2^-26, so ONE step leaves
+    // ~1.5 e0^2 ~ 5e-15 (some 50 eps in every pivot of the factor); the second brings it to rounding level.
     const double dks = sk ? 1.0 : dk;
     const double y0 = __builtin_amdgcn_rsq(dks);
     const double ye = fma(-dks * y0, y0, 1.0);
-    const double inv = sk ? 0.0 : fma(0.5 * y0, ye, y0);
+    const double y1 = fma(0.5 * y0, ye, y0);
+    const double ye1 = fma(-dks * y1, y1, 1.0);
+    const double inv = sk ? 0.0 : fma(0.5 * y1, ye1, y1);
     const double u = lrc * inv;
     if (cg == 0 && rr >= c) Dg[rr * 16 + c] = u;
     if (lane == 0) { skipout[c] = sk ? 1 : 0; Dinv[c] = inv; }
