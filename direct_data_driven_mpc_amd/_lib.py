@@ -23,6 +23,8 @@ GRAM_AUTO, GRAM_DENSE, GRAM_STRUCTURED = 0, 1, 2
 OPT_CLOSED_LOOP_PATH = 1
 OPT_CLOSED_LOOP_GRAPH = 2
 OPT_REFINE, OPT_REFINE_MAX, OPT_REFINE_RES_LOG10 = 3, 4, 5
+OPT_LARGE_PIPELINE = 6
+PIPELINE_ONE_WORKGROUP, PIPELINE_PHASES = 0, 1
 REFINE_OFF, REFINE_AUTO, REFINE_ALWAYS = 0, 1, 2
 PATH_AUTO, PATH_COLD, PATH_WARM = 0, 1, 2
 SOL_ALPHA, SOL_UBAR, SOL_YBAR, SOL_SIGMA = 0, 1, 2, 3
@@ -32,7 +34,7 @@ EXPORTS = (
     "ddmpc_set_stream", "ddmpc_synchronize", "ddmpc_set_data", "ddmpc_solve", "ddmpc_set_setpoints",
     "ddmpc_get_solution", "ddmpc_hankel", "ddmpc_cost_model", "ddmpc_kernel_name", "ddmpc_debug_stamps",
     "ddmpc_closed_loop", "ddmpc_prepare", "ddmpc_step", "ddmpc_get_gain", "ddmpc_set_option",
-    "ddmpc_pe_guard", "ddmpc_solve_from_host",
+    "ddmpc_pe_guard", "ddmpc_solve_from_host", "ddmpc_debug_workspace",
 )
 
 c_double_p = C.POINTER(C.c_double)
@@ -104,6 +106,8 @@ def load() -> C.CDLL:
     lib.ddmpc_pe_guard.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int, C.c_int]
     lib.ddmpc_solve_from_host.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32p, i32p]
     lib.ddmpc_solve_from_host.restype = C.c_int
+    lib.ddmpc_debug_workspace.argtypes = [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, vp]
+    lib.ddmpc_debug_workspace.restype = C.c_int
     for name in ("ddmpc_prepare", "ddmpc_step", "ddmpc_get_gain", "ddmpc_set_option", "ddmpc_pe_guard"):
         getattr(lib, name).restype = C.c_int
     for name in ("ddmpc_create", "ddmpc_destroy", "ddmpc_set_stream", "ddmpc_synchronize", "ddmpc_set_data",

@@ -2,7 +2,7 @@
 // Host-side responsibilities: parameter validation with the reference's error
 // conditions (direct_data_driven_mpc_controller.py:165-168,211-222,298-343,664-670),
 // device buffer ownership, kernel-instance selection, launch.
-#include "ddmpc_aux_kernels.hpp"
+#include "ddmpc_rr2.hpp"
 #include "../../include/ddmpc.h"
 
 #include <cmath>
@@ -146,6 +146,11 @@ struct ddmpc_handle {
   DevBuf d_rflag;                          // AUTO refinement: per-instance "refine me" flags of the plain cold kernel
   DevBuf d_zws, d_resc, d_xws;             // NOMINAL rescue kernel: z per component, a per-instance "rescued" flag and x = L^-T w (ddmpc_get_solution)
   DevBuf d_rrmeta;                         // ... pivot pattern + live column counts of the factors it leaves in d_rr (2 rv + 2 ints per instance)
+  DevBuf d_rr2mt;                          // ... Minv of every 64 x 64 diagonal block of the two factors (ddmpc_rr2.hpp)
+  DevBuf d_perm, d_rr2d;                   // phase kernels (ddmpc_rr2.hpp): fixed-first component order [perm | iperm]; per instance
+                                           // [max diag of G | max diag of T | live chunks of G | live chunks of T]
+  int nF = 0;                              // fixed components (hard constraints), nominal scheme
+  int large_pipeline = DDMPC_PIPELINE_PHASES;   // DDMPC_OPT_LARGE_PIPELINE
   bool rescue_ran = false;
   int epoch = 0;                           // cold launches so far (KParams::epoch)
   int prep_epoch = 0;                      // stamp of the flags recorded by ddmpc_prepare's factor-export launch (AUTO)
@@ -281,6 +286,22 @@ static int upload_params(ddmpc_handle* h) {
   h->n_free = 0;
   for (int rho = 0; rho < k.r; ++rho)
     if (ti[0 * RP + rho] == K_UFREE || ti[0 * RP + rho] == K_YFREE) ++h->n_free;
+  if (h->large_nominal) {
+    // the component order of the rank-revealing route (ddmpc_nominal_rr_kernel): fixed inputs, fixed outputs, free inputs,
+    // free outputs, time order inside a class -- the same for every instance, so it is formed once here for the phase kernels
+    const size_t rv = ((size_t)k.r + 1) & ~(size_t)1;
+    std::vector<int> pm(2 * rv, 0);
+    int pos = 0;
+    h->nF = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+      const int want = cls == 0 ? K_UFIX : cls == 1 ? K_YFIX : cls == 2 ? K_UFREE : K_YFREE;
+      for (int rho = 0; rho < k.r; ++rho)
+        if (ti[0 * RP + rho] == want) { pm[pos] = rho; pm[rv + rho] = pos; ++pos; }
+      if (cls == 1) h->nF = pos;
+    }
+    if ((rc = h->d_perm.ensure(pm.size() * sizeof(int)))) return rc;
+    HIP_TRY(hipMemcpy(h->d_perm.p, pm.data(), pm.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   h->kp.dense_w = 0;
   h->kp.dmat = nullptr;
   if (dense) {
@@ -530,7 +551,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_perm, &h->d_rr2d, &h->d_rr2mt};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -733,17 +754,19 @@ static int launch_warm(ddmpc_handle* h, const double* up, const double* yp, doub
 // kernel; it only touches instances the fast path marked SOLVER_ERROR.
 // rr_mode (problems whose matrices live in the global workspace only): 0 whole solve, 1 the data-dependent factors alone
 // (ddmpc_prepare), 2 a solve on the factors already in the workspace (ddmpc_step) -- see ddmpc_nominal_rr_kernel.
+static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, double rank_tol);
 static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
                                  int32_t* status, int32_t* iters, int rr_mode = 0) {
   if (h->prm.controller_type != DDMPC_NOMINAL || h->prm.weight_kind == DDMPC_WEIGHT_DENSE) return DDMPC_OK;
   const size_t r = (size_t)h->kp.r, nR = (size_t)h->n_free;
-  const size_t ndbl = pk_size(r) + pk_size(nR);                   // packed rows on 128-byte boundaries (ddmpc_aux_kernels.hpp)
+  size_t ndbl = pk_size(r) + pk_size(nR);                         // packed rows on 128-byte boundaries (ddmpc_aux_kernels.hpp)
   const size_t rv = (r + 1) & ~(size_t)1;
   const size_t vec_bytes = 10 * rv * sizeof(double) + 4 * rv * sizeof(int) +    // the kernel's r-vectors, always in LDS,
                            (size_t)PSD_PAN * sizeof(double);                        // and the scratch of its Cholesky / Gram
   size_t lds = vec_bytes + ndbl * sizeof(double);
   double* scratch = nullptr;
   if (lds + 1024 > 160 * 1024) {                              // matrices too big for LDS: per-instance slices of a global workspace
+    ndbl = pk_size((r + 15) & ~(size_t)15) + pk_size((nR + 15) & ~(size_t)15);   // (whole 16-row tiles: the phase kernels of ddmpc_rr2.hpp)
     int rc = h->d_rr.ensure((size_t)h->batch * ndbl * sizeof(double));
     if (rc) return rc;
     scratch = (double*)h->d_rr.p;
@@ -784,11 +807,69 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
   int rcl = DDMPC_OK;
   if (!scratch) rcl = launch(ddmpc_nominal_rr_kernel<0>);                 // matrices in LDS: one launch
   else {                                                                  // global workspace: factors, then the solve on them
-    if (rr_mode != 2) rcl = launch(ddmpc_nominal_rr_kernel<1>);
+    if (rr_mode != 2) {
+      const bool phases = h->large_pipeline == DDMPC_PIPELINE_PHASES && h->large_nominal && h->batch <= 65535 && !h->stamps_on;
+      rcl = phases ? launch_rr2_factors(h, scratch, (long long)ndbl, 1e-8) : launch(ddmpc_nominal_rr_kernel<1>);
+    }
     if (!rcl && rr_mode != 1) rcl = launch(ddmpc_nominal_rr_kernel<2>);
   }
   if (rcl) return rcl;
   if (rr_mode != 1) h->rescue_ran = true;
+  return DDMPC_OK;
+}
+
+// The data-dependent half of a NOMINAL solve beyond the register-resident kernels as phase kernels over the whole batch
+// (ddmpc_rr2.hpp): Gram -> lock-step Cholesky (64-column panels: update launch + panel launch) -> live counts -> C'WC ->
+// its Cholesky.  Leaves in the workspace / meta exactly what ddmpc_nominal_rr_kernel<1> leaves.
+static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, double rank_tol) {
+  const KParams& k = h->kp;
+  const int r = k.r, n16 = (r + 15) & ~15, nR = h->n_free, nF = h->nF, nR16 = (nR + 15) & ~15;
+  const int rv = (r + 1) & ~1;
+  const long long mstride = 2 * (long long)rv + 2;
+  const size_t B = (size_t)h->batch;
+  const long long m64G = (long long)((n16 + RR2_NB - 1) / RR2_NB) * RR2_NB * RR2_NB;       // Minv blocks of G's factor per instance
+  const long long m64T = (long long)((nR16 + RR2_NB - 1) / RR2_NB) * RR2_NB * RR2_NB;      // ... and of T's factor, behind them
+  int rc;
+  if ((rc = h->d_rr2d.ensure(B * 4 * sizeof(unsigned long long))) || (rc = h->d_rr2mt.ensure(B * (size_t)(m64G + m64T) * sizeof(double)))) return rc;
+  HIP_TRY(hipMemsetAsync(h->d_rr2d.p, 0, B * 4 * sizeof(unsigned long long), h->stream));
+  unsigned long long* dd = (unsigned long long*)h->d_rr2d.p;
+  int* meta = (int*)h->d_rrmeta.p;
+  const int* perm = (const int*)h->d_perm.p;
+  const int* iperm = perm + rv;
+  hipLaunchKernelGGL(rr2_gram_kernel, dim3((unsigned)((k.Ln + 4 * RR2_SL - 1) / (4 * RR2_SL)), (unsigned)B), dim3(256), 0, h->stream,
+                     k, h->ud, h->yd, iperm, scratch, ndbl, n16, dd);
+  auto cholesky = [&](const Rr2Chol& F, int nmax16) {
+    const int nt = nmax16 >> 4;
+    for (int c0 = 0; c0 < nmax16; c0 += RR2_NB) {
+      const int tp = c0 >> 4;
+      hipLaunchKernelGGL(rr2_chol_panel_kernel, dim3(1, (unsigned)B), dim3(256), 0, h->stream, F, c0);
+      const int nbelow = nt - tp - 4;                       // row tiles below the diagonal block
+      if (nbelow > 0)
+        hipLaunchKernelGGL(rr2_chol_update_kernel<RR2_UT>, dim3((unsigned)((nbelow + 4 * RR2_UT - 1) / (4 * RR2_UT)), (unsigned)B),
+                           dim3(256), 0, h->stream, F, c0);
+    }
+  };
+  Rr2Chol FG{};
+  FG.ws = scratch; FG.stride = ndbl; FG.off = 0; FG.n16 = n16; FG.n_inst = nullptr; FG.n_stride = 0;
+  FG.dmax = dd + 0; FG.d_stride = 4; FG.tol_rel = rank_tol; FG.skip = meta; FG.s_stride = mstride; FG.nflag = r;
+  FG.live = dd + 2; FG.l_stride = 4; FG.m64 = (double*)h->d_rr2mt.p; FG.m64_stride = m64G + m64T;
+  cholesky(FG, n16);
+  hipLaunchKernelGGL(rr2_meta_kernel, dim3((unsigned)B), dim3(256), 0, h->stream, meta, mstride, rv, r, nF, nR);
+  if (nR > 0) {
+    const int ldw = ((nR16 + 31) / 32) * 32 + 16;                         // LDS row of the C'WC kernel: 16 mod 32 doubles
+    const size_t cwlds = ((size_t)16 * ldw + 16) * sizeof(double);
+    if (cwlds > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute((const void*)rr2_cwc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cwlds));
+    hipLaunchKernelGGL(rr2_cwc_kernel, dim3((unsigned)B), dim3(1024), cwlds, h->stream, k, 16 * h->kc.NT, perm, scratch, ndbl,
+                       (long long)pk_size((size_t)n16), (const int*)meta, mstride, rv, nF, nR, dd + 1, ldw);
+    Rr2Chol FT{};
+    FT.ws = scratch; FT.stride = ndbl; FT.off = (long long)pk_size((size_t)n16); FT.n16 = nR16;
+    FT.n_inst = meta + 2 * rv + 1; FT.n_stride = mstride;
+    FT.dmax = dd + 1; FT.d_stride = 4; FT.tol_rel = 1e-14; FT.skip = meta + rv; FT.s_stride = mstride; FT.nflag = nR;
+    FT.live = dd + 3; FT.l_stride = 4; FT.m64 = (double*)h->d_rr2mt.p + m64G; FT.m64_stride = m64G + m64T;
+    cholesky(FT, nR16);
+  }
+  HIP_TRY(hipGetLastError());
   return DDMPC_OK;
 }
 
@@ -1152,6 +1233,12 @@ int ddmpc_set_option(ddmpc_handle* h, int option, int value) {
       h->kp.refine_res = std::pow(10.0, -0.1 * (double)value);
       h->prepared = false;
       return DDMPC_OK;
+    case DDMPC_OPT_LARGE_PIPELINE:
+      if (value != DDMPC_PIPELINE_ONE_WORKGROUP && value != DDMPC_PIPELINE_PHASES)
+        return fail(DDMPC_ERR_INVALID, "pipeline must be DDMPC_PIPELINE_ONE_WORKGROUP or DDMPC_PIPELINE_PHASES");
+      h->large_pipeline = value;
+      h->prepared = false;
+      return DDMPC_OK;
     default: return fail(DDMPC_ERR_INVALID, "unknown option %d", option);
   }
 }
@@ -1492,6 +1579,26 @@ int ddmpc_debug_stamps(ddmpc_handle* h, int enable, uint64_t* out) {
     HIP_TRY(hipMemsetAsync(h->d_stamps.p, 0, bytes, h->stream));
   }
   h->stamps_on = enable != 0;
+  return DDMPC_OK;
+}
+
+int ddmpc_debug_workspace(ddmpc_handle* h, int64_t b, double* ws_out, int64_t ws_count, int32_t* meta_out, int64_t meta_count,
+                          int64_t* ws_avail, int64_t* meta_avail) {
+  if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
+  if (!h->large_nominal || !h->d_rr.p || !h->d_rrmeta.p) return fail(DDMPC_ERR_NOT_READY, "no global workspace to read");
+  if (b < 0 || b >= h->batch) return fail(DDMPC_ERR_INVALID, "instance out of range");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t r = (size_t)h->kp.r, nR = (size_t)h->n_free, rv = (r + 1) & ~(size_t)1;
+  const size_t ndbl = pk_size((r + 15) & ~(size_t)15) + pk_size((nR + 15) & ~(size_t)15), nmeta = 2 * rv + 2;
+  if (ws_avail) *ws_avail = (int64_t)ndbl;
+  if (meta_avail) *meta_avail = (int64_t)nmeta;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (ws_out && ws_count > 0)
+    HIP_TRY(hipMemcpy(ws_out, (const double*)h->d_rr.p + (size_t)b * ndbl, sizeof(double) * (size_t)(ws_count < (int64_t)ndbl ? ws_count : (int64_t)ndbl),
+                      hipMemcpyDeviceToHost));
+  if (meta_out && meta_count > 0)
+    HIP_TRY(hipMemcpy(meta_out, (const int*)h->d_rrmeta.p + (size_t)b * nmeta, sizeof(int) * (size_t)(meta_count < (int64_t)nmeta ? meta_count : (int64_t)nmeta),
+                      hipMemcpyDeviceToHost));
   return DDMPC_OK;
 }
 

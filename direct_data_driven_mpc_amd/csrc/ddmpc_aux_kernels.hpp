@@ -1742,7 +1742,8 @@ __global__ __launch_bounds__(512, DDMPC_RR_WAVES) void ddmpc_nominal_rr_kernel(K
   if constexpr (MODE == 0) rsm = scratch ? scratch + b * scratch_stride : pan + PSD_PAN;
   else rsm = scratch + b * scratch_stride;                // (a kernel-argument pointer: the matrices are addressed with global, not flat, loads)
   double* G = rsm;                                      // r(r+1)/2
-  double* T = G + pk_row(r);                      // nR(nR+1)/2
+  // (in the global workspace both matrices take whole 16-row tiles: the layout the phase kernels of ddmpc_rr2.hpp work on)
+  double* T = G + ((MODE == 0 && !scratch) ? pk_row(r) : pk_row((size_t)((r + 15) & ~15)));   // nR(nR+1)/2
   __shared__ double red[16];
   __shared__ int cnt4[4];
   const double* ud = u_d + b * (long long)P.N * m;

@@ -1,0 +1,583 @@
+// ddmpc_rr2.hpp -- problems beyond the register-resident kernels ((m+p)(L+n) > 271, BASELINE configs[4]): the part of a
+// solve that depends on the DATA alone, as PHASE KERNELS that run the whole batch in lock step.
+//
+// ddmpc_nominal_rr_kernel<1> (ddmpc_aux_kernels.hpp) does all of this inside ONE workgroup per instance: a chain of dependent
+// steps on a workspace in HBM, one register allocation for every phase (219 spilled VGPRs), two co-resident workgroups that
+// queue on the same memory path.  Here every phase is a kernel of its own -- its own register budget, no scratch -- and an
+// instance is worked on by as many workgroups as the phase has independent tiles; the dependency between panel steps is the
+// kernel boundary (~2 us each, ~35 of them per factorisation chain):
+//
+//   rr2_gram_kernel          G = H H' in the fixed-first component order (controller.py:506-538 through hankel_matrix.py:5-53):
+//                            lag sums C_d = X_d' X_0 on the matrix pipe, then every wave walks "its" lags down the block
+//                            diagonals with one rank-2 MFMA per tile (the Hankel window update) and stores the tiles
+//   rr2_chol_update_kernel   left-looking update of one 64-column panel with every live column in front of it (MFMA tiles,
+//                            both operands 128-byte pieces of packed rows, dead 16-column chunks skipped by a bit mask)
+//   rr2_chol_panel_kernel    the panel's 64 x 64 diagonal block factored in LDS with the skipped-pivot rule, the rows below
+//                            it solved against it (MFMA), pivot flags and the live-chunk mask recorded
+//   rr2_meta_kernel          live column counts from the pivot pattern
+//   rr2_cwc_kernel           T = C' W C, the reduced normal matrix of the weighted components (MFMA)
+//   (the two Cholesky kernels again for T, with per-instance sizes)
+//
+// The workspace they leave -- the factor of G in place, the factor of T behind it, pivot flags and live counts in `meta` -- is
+// exactly what ddmpc_nominal_rr_kernel<2> (the solve on the factors) expects.
+#pragma once
+#include "ddmpc_aux_kernels.hpp"
+
+namespace ddmpc {
+
+constexpr int RR2_NB = 64;        // panel width of the lock-step Cholesky (four 16-column tiles)
+constexpr int RR2_SL = 5;         // lags per wave in the Gram kernel
+constexpr int RR2_XCAP = 4096;    // doubles of LDS the Gram kernel stages trajectory chunks in
+constexpr int RR2_UT = 4;         // row tiles per wave in the Cholesky update kernel
+
+// D[a][b] += sum_k A[a][k] B[k][b] on v_mfma_f64_16x16x4: lane (l15, l4) passes A[a = l15][k = l4] and B[k = l4][b = l15];
+// register q of the accumulator holds D[l4 + 4q][l15].
+__device__ __forceinline__ d4 rr2_mfma(double a, double b, d4 acc) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0); }
+
+// One packed factorisation of the batch (the Gram matrix G, or the reduced normal matrix T behind it).
+struct Rr2Chol {
+  double* ws;                       // workspace, instance b at ws + b * stride
+  long long stride;
+  long long off;                    // offset of this matrix inside an instance's slice
+  int n16;                          // rows (a multiple of 16), the same for every instance ...
+  const int* n_inst;                // ... unless this is set: rows of instance b = n_inst[b * n_stride] rounded up to 16
+  long long n_stride;
+  const unsigned long long* dmax;   // per instance: largest diagonal entry (bit pattern of a non-negative double)
+  long long d_stride;
+  double tol_rel;                   // pivots <= tol_rel * dmax are skipped
+  int* skip;                        // pivot flags out: skip[b * s_stride + i], i < nflag
+  long long s_stride;
+  int nflag;
+  unsigned long long* live;         // per instance: bit j = 16-column chunk j holds at least one pivot
+  long long l_stride;
+  double* m64;                      // per instance: Minv = S L~^-1 of every 64 x 64 diagonal block, row-major, block k at m64 + 4096 k
+  long long m64_stride;
+};
+
+__device__ __forceinline__ double rr2_bits_to_double(unsigned long long v) { return __longlong_as_double((long long)v); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Gram matrix in the permuted (fixed-first) order, packed lower triangle with rows on 128-byte boundaries (pk_row).
+// grid = (ceil(Ln / (4 RR2_SL)), batch), 256 threads: wave w of workgroup g owns the lags g*4*RR2_SL + w + 4*sl.
+//   G((k+d, a), (k, b)) = C_d(a,b) + sum_{j<k} ( x_a[j+c+d] x_b[j+c] - x_a[j+d] x_b[j] ),   C_d(a,b) = sum_{t<c} x_a[t+d] x_b[t]
+// The lag sums stay in the accumulators they were formed in; the window update of a whole 16x16 block is ONE MFMA with the
+// contraction index (tail term, -head term, 0, 0).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rr2_gram_kernel(KParams P, const double* __restrict__ u_d, const double* __restrict__ y_d,
+                                                       const int* __restrict__ iperm, double* __restrict__ ws, long long stride,
+                                                       int n16, unsigned long long* __restrict__ dmaxbits) {
+  __shared__ __attribute__((aligned(16))) double xc[RR2_XCAP];
+  __shared__ int ipl[1024];                                                 // component -> row of G (a global load per stored entry
+                                                                            // put one memory round trip into every step of the walk)
+  const long long b = blockIdx.y;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int m = P.m, p = P.p, nch = P.nch, c = P.c, Ln = P.Ln, r = P.r;
+  __shared__ int prl[1024];                                                 // pk_row(i): start of row i of G
+  for (int i = tid; i < r; i += nthr) { ipl[i] = iperm[i]; prl[i] = (int)pk_row((size_t)i); }
+  for (int i = tid; i < RR2_XCAP; i += nthr) xc[i] = 0.0;                   // (masked MFMA terms multiply whatever lies behind a chunk by zero: finite)
+  const double* ud = u_d + b * (long long)P.N * m;
+  const double* yd = y_d + b * (long long)P.N * p;
+  double* G = ws + b * stride;
+  const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6;
+  const int dg = blockIdx.x * nwave * RR2_SL;
+  const int nat = (nch + 15) >> 4;
+  const int TCH = ((RR2_XCAP / nch) - Ln - 3) & ~3;                        // time steps per chunk next to the lag overlap (+ 3 rows of slack)
+  const int nw = Ln - 1;
+  double* xh = xc;                                                          // walk: rows 0 .. Ln-2
+  double* xt = xc + nw * nch;                                               //       rows c .. c+Ln-2
+  double dmx = 0.0;
+  if (blockIdx.x == 0) {                                                    // padding rows r .. n16-1: zero (their pivots are skipped)
+    for (int i = r; i < n16; ++i)
+      for (int j = tid; j <= i; j += nthr) G[pk_row(i) + j] = 0.0;
+  }
+  for (int at = 0; at < nat; ++at)
+    for (int bt = 0; bt < nat; ++bt) {
+      d4 acc[RR2_SL];
+#pragma unroll
+      for (int sl = 0; sl < RR2_SL; ++sl) acc[sl] = d4{0.0, 0.0, 0.0, 0.0};
+      const int ca = (16 * at + l15 < nch) ? 16 * at + l15 : nch - 1;       // clamped: entries past nch are not stored
+      const int cb = (16 * bt + l15 < nch) ? 16 * bt + l15 : nch - 1;
+      for (int t0 = 0; t0 < c; t0 += TCH) {
+        const int nt = (c - t0) < TCH ? (c - t0) : TCH;
+        const int nload = nt + Ln - 1;
+        __syncthreads();
+        stage_trajectory<8>(P, ud, yd, t0, nload, xc);
+        __syncthreads();
+        // lane (l15, l4): B operand x_b[t], A operand x_a[t + d], t = s4 + l4; terms t >= nt are masked by a zero in B (what
+        // A reads there -- rows up to nload + 2 -- is finite: the region was zero-filled, later chunks leave older data)
+        const double* pb = xc + l4 * nch + cb;
+        const double* pa = xc + (l4 + dg + wave) * nch + ca;
+        const int lstep = nwave * nch;
+        for (int s4 = 0; s4 < nt; s4 += 4) {
+          const double bv = (s4 + l4 < nt) ? pb[s4 * nch] : 0.0;
+#pragma unroll
+          for (int sl = 0; sl < RR2_SL; ++sl)
+            if (dg + wave + nwave * sl < Ln) acc[sl] = rr2_mfma(pa[s4 * nch + sl * lstep], bv, acc[sl]);   // (wave-uniform)
+        }
+      }
+      __syncthreads();
+      stage_trajectory<8>(P, ud, yd, 0, nw, xh);
+      stage_trajectory<8>(P, ud, yd, c, nw, xt);
+      __syncthreads();
+      const double* xsel = (l4 == 0) ? xt : xh;
+      const double sga = (l4 == 0) ? 1.0 : (l4 == 1 ? -1.0 : 0.0), sgb = (l4 < 2) ? 1.0 : 0.0;
+#pragma unroll
+      for (int sl = 0; sl < RR2_SL; ++sl) {
+        const int d = dg + wave + nwave * sl;
+        if (d >= Ln) continue;
+        for (int k = 0; k + d < Ln; ++k) {
+          if (k > 0) acc[sl] = rr2_mfma(sga * xsel[(k - 1 + d) * nch + ca], sgb * xsel[(k - 1) * nch + cb], acc[sl]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int a = 16 * at + l4 + 4 * q, bb = 16 * bt + l15;
+            if (a < nch && bb < nch && (d > 0 || a >= bb)) {
+              const int pi = ipl[(k + d) * nch + a], pj = ipl[k * nch + bb];
+              const int hi = pi > pj ? pi : pj, lo = pi > pj ? pj : pi;
+              G[prl[hi] + lo] = acc[sl][q];
+              if (d == 0 && a == bb) dmx = fmax(dmx, acc[sl][q]);
+            }
+          }
+        }
+      }
+    }
+  if (dg + wave == 0) {                                                     // the wave that owns lag 0 has met every diagonal entry
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dmx = fmax(dmx, __shfl_xor(dmx, off, 64));
+    if (lane == 0) atomicMax(dmaxbits + 4 * b, (unsigned long long)__double_as_longlong(fmax(dmx, 0.0)));   // (four words per instance)
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Rows below the diagonal block of the panel at column c0 (RR2_NB columns), in ONE pass over the panel:
+//   P(i, c) = A(i, c) - sum_{j < c0, j live} L(i, j) L(c, j)        left-looking update with every live column in front of it
+//   X(i, :) = P(i, :) Minv'                                          Minv = inverse of the block's factor (panel kernel)
+// grid = (row groups, batch), 256 threads: a wave owns RT row tiles x the four column tiles.  Accumulators transposed
+// (register q of lane (l4, l15) = entry [panel column l4 + 4q][row l15]), which makes a finished P tile directly the B operand
+// of the multiplication with Minv.  Per live 16-column chunk the panel's own 64 rows -- the operand every wave of every
+// workgroup of the instance needs -- are staged ONCE per workgroup in LDS (double-buffered, one barrier per chunk), the waves'
+// own rows are 32-byte pieces of packed rows loaded one chunk ahead of the MFMAs that consume them.  (As two kernels -- update
+// with a store of P, then a solve that read P back -- the panel went through HBM four times per step instead of twice.)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int RR2_PLD = 18;         // doubles per staged panel row (16 + 2: the 16 rows of a tile land in different banks)
+template <int RT>
+__global__ __launch_bounds__(256, 2) void rr2_chol_update_kernel(Rr2Chol F, int c0) {
+  __shared__ __attribute__((aligned(16))) double pl[2][64 * RR2_PLD];
+  __shared__ __attribute__((aligned(16))) double Mi[10][256];               // tile (t, u), u <= t, of Minv at index t (t + 1) / 2 + u, row-major
+  const long long b = blockIdx.y;
+  const int n16 = F.n_inst ? ((F.n_inst[b * F.n_stride] + 15) & ~15) : F.n16;
+  if (c0 + RR2_NB >= n16) return;                                           // (workgroup-uniform) no row below the block
+  double* A = F.ws + b * F.stride + F.off;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tp = c0 >> 4, nt = n16 >> 4;
+  const int tb = tp + 4;                                                    // first row tile below the block
+  if (tb + (int)blockIdx.x * 4 * RT >= nt) return;                          // (workgroup-uniform: no row tile left for this group)
+  const int t0 = tb + ((int)blockIdx.x * 4 + wave) * RT;                    // first row tile of this wave (wave-uniform)
+  unsigned long long live = F.live[b * F.l_stride] & ((1ull << tp) - 1ull);   // chunks in front of the panel (tp <= 63)
+  // staging role of this thread: 32 bytes of panel row (tid >> 2), columns 4 (tid & 3) .. + 3 of the chunk
+  const int srow = tid >> 2, spart = tid & 3;
+  const double* sptr = A + pk_row((size_t)(c0 + srow)) + 4 * spart;
+  const int soff = srow * RR2_PLD + 4 * spart;
+  const double* mrow[RT];
+  bool on[RT];
+#pragma unroll
+  for (int s = 0; s < RT; ++s) {
+    on[s] = t0 + s < nt;
+    const int T = on[s] ? t0 + s : nt - 1;
+    mrow[s] = A + (size_t)128 * T * (T + 1) + (size_t)l15 * 16 * (T + 1) + 4 * l4;
+  }
+  d4 acc[RT][4];
+#pragma unroll
+  for (int s = 0; s < RT; ++s)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[s][ct] = d4{0.0, 0.0, 0.0, 0.0};
+  {   // Minv of the block (written by the panel kernel of this step): ten 8-byte loads per thread
+    const double* m64 = F.m64 + b * F.m64_stride + (size_t)(c0 / RR2_NB) * (RR2_NB * RR2_NB);
+    double mv[10];
+    const int rr = (tid >> 4) & 15, cc = tid & 15;
+#pragma unroll
+    for (int ti = 0; ti < 10; ++ti) {
+      const int t = ti < 1 ? 0 : (ti < 3 ? 1 : (ti < 6 ? 2 : 3)), u = ti - t * (t + 1) / 2;
+      mv[ti] = m64[(16 * t + rr) * RR2_NB + 16 * u + cc];
+    }
+#pragma unroll
+    for (int ti = 0; ti < 10; ++ti) Mi[ti][tid] = mv[ti];
+  }
+  d4 xa[2][RT], sreg;
+  auto load = [&](int buf, int jc) __attribute__((always_inline)) {
+    sreg = *reinterpret_cast<const d4*>(sptr + 16 * jc);
+#pragma unroll
+    for (int s = 0; s < RT; ++s) xa[buf][s] = *reinterpret_cast<const d4*>(mrow[s] + 16 * jc);
+  };
+  auto stage = [&](int buf) __attribute__((always_inline)) {
+    *reinterpret_cast<d2*>(&pl[buf][soff]) = d2{sreg[0], sreg[1]};
+    *reinterpret_cast<d2*>(&pl[buf][soff + 2]) = d2{sreg[2], sreg[3]};
+  };
+  auto fma_chunk = [&](int buf) __attribute__((always_inline)) {
+    if (!on[0]) return;                                                     // (wave-uniform) an idle wave only stages
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const double* pp = &pl[buf][(16 * ct + l15) * RR2_PLD + 4 * l4];
+      const d2 p0 = *reinterpret_cast<const d2*>(pp), p1 = *reinterpret_cast<const d2*>(pp + 2);
+#pragma unroll
+      for (int s = 0; s < RT; ++s)
+        if (on[s]) {                                                        // (wave-uniform)
+          acc[s][ct] = rr2_mfma(p0[0], xa[buf][s][0], acc[s][ct]);
+          acc[s][ct] = rr2_mfma(p0[1], xa[buf][s][1], acc[s][ct]);
+          acc[s][ct] = rr2_mfma(p1[0], xa[buf][s][2], acc[s][ct]);
+          acc[s][ct] = rr2_mfma(p1[1], xa[buf][s][3], acc[s][ct]);
+        }
+    }
+  };
+  if (live != 0ull) {
+    int jc = __builtin_ctzll(live);
+    live &= live - 1ull;
+    load(0, jc);
+    for (;;) {
+      stage(0);
+      __syncthreads();
+      bool more = live != 0ull;
+      if (more) { jc = __builtin_ctzll(live); live &= live - 1ull; load(1, jc); }
+      fma_chunk(0);
+      if (!more) break;
+      stage(1);
+      __syncthreads();
+      more = live != 0ull;
+      if (more) { jc = __builtin_ctzll(live); live &= live - 1ull; load(0, jc); }
+      fma_chunk(1);
+      if (!more) break;
+    }
+  }
+  __syncthreads();                                                          // Mi is in LDS (and every wave is through with pl)
+  // P' = A' - acc, then X' = Minv P' tile row by tile row, in place
+#pragma unroll
+  for (int s = 0; s < RT; ++s) {
+    if (!on[s]) continue;
+    const int i = 16 * (t0 + s) + l15;
+    double* Ai = A + pk_row((size_t)i) + c0;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[s][ct][q] = Ai[16 * ct + l4 + 4 * q] - acc[s][ct][q];
+    d4 x[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) x[ct] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          if (ct >= u) x[ct] = rr2_mfma(Mi[ct * (ct + 1) / 2 + u][l15 * 16 + l4 + 4 * e], acc[s][u][e], x[ct]);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Ai[16 * ct + l4 + 4 * q] = x[ct][q];
+  }
+}
+
+// Left-looking update of up to three tiles of the diagonal block by one wave (the tiles (S0,T0), (S1,T1), (S2,T2) of the block,
+// S >= T, -1: none; chosen so that a wave touches few distinct tile rows): P(s,t) = A(s,t) - sum_{j < c0, j live} L(s rows, j)
+// L(t rows, j)', operands one live chunk ahead, result into the LDS tile (strict upper triangle of a diagonal tile: zero).
+template <int S0, int T0, int S1, int T1, int S2, int T2>
+__device__ __forceinline__ void rr2_diag_update(const double* A, double (*Dt)[256], unsigned long long livemask, int c0, int n4) {
+  constexpr int SS[3] = {S0, S1, S2};
+  constexpr int TT[3] = {T0, T1, T2};
+  const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int tp = c0 >> 4;
+  unsigned long long live = livemask & ((1ull << tp) - 1ull);
+  const double* rowp[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int T = (t < n4) ? tp + t : tp + n4 - 1;
+    rowp[t] = A + (size_t)128 * T * (T + 1) + (size_t)l15 * 16 * (T + 1) + 4 * l4;
+  }
+  d4 acc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) acc[k] = d4{0.0, 0.0, 0.0, 0.0};
+  d4 xr[2][4];
+  auto load = [&](int buf, int jc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      bool need = false;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) need = need || (SS[k] == t) || (SS[k] >= 0 && TT[k] == t);
+      if (need) xr[buf][t] = *reinterpret_cast<const d4*>(rowp[t] + 16 * jc);
+    }
+  };
+  auto fma = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (SS[k] < 0) continue;
+      if (SS[k] >= n4) continue;                                            // (wave-uniform) tile past the end of the matrix
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[k] = rr2_mfma(xr[buf][TT[k]][e], xr[buf][SS[k]][e], acc[k]);
+    }
+  };
+  if (live != 0ull) {
+    int jc = __builtin_ctzll(live);
+    live &= live - 1ull;
+    load(0, jc);
+    for (;;) {
+      bool more = live != 0ull;
+      if (more) { jc = __builtin_ctzll(live); live &= live - 1ull; load(1, jc); }
+      fma(0);
+      if (!more) break;
+      more = live != 0ull;
+      if (more) { jc = __builtin_ctzll(live); live &= live - 1ull; load(0, jc); }
+      fma(1);
+      if (!more) break;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (SS[k] < 0) continue;
+    if (SS[k] >= n4) continue;
+    const int i = c0 + 16 * SS[k] + l15;
+    const double* Ai = A + pk_row((size_t)i) + c0 + 16 * TT[k];
+    double* Dst = Dt[SS[k] * (SS[k] + 1) / 2 + TT[k]];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cc = l4 + 4 * q;
+      const bool lower = (SS[k] > TT[k]) || (cc <= l15);
+      const double av = Ai[lower ? cc : 0];
+      Dst[l15 * 16 + cc] = lower ? av - acc[k][q] : 0.0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Panel step, part 1: the (up to) 64 x 64 diagonal block at column c0 is brought up to date (the left-looking update with the
+// live columns in front of it, its ten lower tiles dealt to the four waves; operands one chunk ahead) and factored in LDS --
+// 16 x 16 tiles, each diagonal tile by one wave with the skipped-pivot rule (psd_tile_factor, which also yields Mt = S L~^-1), the tiles below it and the
+// trailing tiles of the block by MFMA.  Stores the block's factor in place, the inverse Minv of the block in `m64` (for part 2
+// and for the substitutions of the solve), the pivot flags and the live-chunk bits.  grid = (1, batch), 256 threads: ONE workgroup per instance (the block is factored in place).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rr2_chol_panel_kernel(Rr2Chol F, int c0) {
+  __shared__ __attribute__((aligned(16))) double Dt[10][256];               // tile (s, t), s >= t, at index s (s + 1) / 2 + t, row-major
+  __shared__ __attribute__((aligned(16))) double Ms[4][256];                // Mt of the diagonal tiles, k-major
+  __shared__ double Dinv[64];
+  __shared__ int skipl[64];
+  const long long b = blockIdx.y;
+  const int n16 = F.n_inst ? ((F.n_inst[b * F.n_stride] + 15) & ~15) : F.n16;
+  if (c0 >= n16) return;
+  double* A = F.ws + b * F.stride + F.off;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6;
+  const int tp = c0 >> 4, nt = n16 >> 4;
+  const int n4 = (nt - tp) < 4 ? (nt - tp) : 4;                             // tiles across the panel
+  const double tol = F.tol_rel * rr2_bits_to_double(F.dmax[b * F.d_stride]);
+  // ---- the diagonal block, updated, into LDS (strict upper triangle of the diagonal tiles zero, absent tiles zero)
+  for (int e = tid; e < 10 * 256; e += nthr) Dt[e >> 8][e & 255] = 0.0;
+  __syncthreads();
+  if (wave == 0) rr2_diag_update<0, 0, 1, 0, 1, 1>(A, Dt, F.live[b * F.l_stride], c0, n4);
+  else if (wave == 1) rr2_diag_update<2, 0, 2, 1, 2, 2>(A, Dt, F.live[b * F.l_stride], c0, n4);
+  else if (wave == 2) rr2_diag_update<3, 0, 3, 1, -1, -1>(A, Dt, F.live[b * F.l_stride], c0, n4);
+  else rr2_diag_update<3, 2, 3, 3, -1, -1>(A, Dt, F.live[b * F.l_stride], c0, n4);
+  for (int e = tid; e < 4 * 256; e += nthr) Ms[e >> 8][e & 255] = 0.0;
+  __syncthreads();
+  for (int t = 0; t < n4; ++t) {
+    if (wave == 0) psd_tile_factor(Dt[t * (t + 1) / 2 + t], Ms[t], Dinv + 16 * t, 16, tol, skipl + 16 * t);
+    __syncthreads();
+    // tiles below the diagonal tile: X(s,t) = P(s,t) Mt'   (X'[m][i] = sum_k Mt[m][k] P'[k][i])
+    if (wave >= 1 && t + wave < n4) {
+      double* Pst = Dt[(t + wave) * (t + wave + 1) / 2 + t];
+      double pv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pv[q] = Pst[l15 * 16 + l4 + 4 * q];
+      d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x = rr2_mfma(Ms[t][(l4 + 4 * q) * 16 + l15], pv[q], x);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Pst[l15 * 16 + l4 + 4 * q] = x[q];
+    }
+    __syncthreads();
+    // trailing tiles of the block: P(s,u) -= X(s,t) X(u,t)',  t < u <= s
+    {
+      int idx = 0;
+      for (int s = t + 1; s < n4; ++s)
+        for (int u = t + 1; u <= s; ++u, ++idx) {
+          if (idx % nwave != wave) continue;                                // wave-uniform
+          const double* Xs = Dt[s * (s + 1) / 2 + t];
+          const double* Xu = Dt[u * (u + 1) / 2 + t];
+          d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = rr2_mfma(Xu[l15 * 16 + l4 + 4 * e], Xs[l15 * 16 + l4 + 4 * e], acc);
+          double* Psu = Dt[s * (s + 1) / 2 + u];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Psu[l15 * 16 + l4 + 4 * q] -= acc[q];
+        }
+    }
+    __syncthreads();
+  }
+  // ---- Minv = S L~^-1 of the whole block (L~: the block's factor with unit diagonal where a pivot was skipped), 16 x 16 tiles:
+  //        Minv(t,t) = Mt_t,   Minv(s,t) = -Mt_s sum_{t <= u < s} L(s,u) Minv(u,t)     (by distance s - t from the diagonal)
+  // With it the rows below the block are ONE multiplication X = P Minv' of independent MFMA chains (part 2) instead of a
+  // forward substitution through four dependent tile solves, and a substitution with the finished factor advances 64 rows
+  // per step (ddmpc_rr2_solve.hpp).  The Dt tiles of the diagonal (their factor is no longer needed in LDS form) are reused.
+  __shared__ __attribute__((aligned(16))) double Mi[10][256];               // tile (s, t) row-major
+  for (int e = tid; e < 4 * 256; e += nthr) {
+    const int t = e >> 8, a = (e >> 4) & 15, bb = e & 15;
+    Mi[t * (t + 1) / 2 + t][a * 16 + bb] = Ms[t][bb * 16 + a];
+  }
+  __syncthreads();
+  for (int dist = 1; dist < n4; ++dist) {
+    const int t = wave, s = wave + dist;                                    // (wave-uniform) one tile per wave and distance
+    if (s < n4) {
+      d4 w = d4{0.0, 0.0, 0.0, 0.0};
+      for (int u = t; u < s; ++u) {
+        const double* Lsu = Dt[s * (s + 1) / 2 + u];
+        const double* Mut = Mi[u * (u + 1) / 2 + t];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w = rr2_mfma(Lsu[l15 * 16 + l4 + 4 * e], Mut[(l4 + 4 * e) * 16 + l15], w);
+      }
+      d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x = rr2_mfma(Ms[s][(l4 + 4 * e) * 16 + l15], w[e], x);
+      double* Mst = Mi[s * (s + 1) / 2 + t];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Mst[(l4 + 4 * q) * 16 + l15] = -x[q];
+    }
+    __syncthreads();
+  }
+  // ---- the block's own factor, Minv, pivot flags, live-chunk bits
+  for (int e = tid; e < 10 * 256; e += nthr) {
+    const int ti = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
+    int s = 0;
+    while ((s + 1) * (s + 2) / 2 <= ti) ++s;
+    const int t = ti - s * (s + 1) / 2;
+    if (s < n4) {
+      const int i = c0 + 16 * s + rr, j = c0 + 16 * t + cc;
+      if (j <= i) A[pk_row((size_t)i) + j] = Dt[ti][rr * 16 + cc];
+    }
+  }
+  double* m64 = F.m64 + b * F.m64_stride + (size_t)(c0 / RR2_NB) * (RR2_NB * RR2_NB);
+  for (int e = tid; e < RR2_NB * RR2_NB; e += nthr) {                       // 64 x 64, row-major, zero above the diagonal tiles
+    const int i = e >> 6, j = e & 63, s = i >> 4, t = j >> 4;
+    m64[e] = (t <= s && s < n4) ? Mi[s * (s + 1) / 2 + t][(i & 15) * 16 + (j & 15)] : 0.0;
+  }
+  if (tid < 16 * n4 && c0 + tid < F.nflag) F.skip[b * F.s_stride + c0 + tid] = skipl[tid];
+  if (tid == 0) {
+    unsigned long long bits = 0ull;
+    for (int t = 0; t < n4; ++t) {
+      bool any = false;
+      for (int q = 0; q < 16; ++q) any = any || (skipl[16 * t + q] == 0);
+      if (any) bits |= 1ull << (tp + t);
+    }
+    F.live[b * F.l_stride] |= bits;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Live column counts from the pivot pattern of G's factor: nlive = 1 + the last column with a pivot (every column behind it
+// is zero), nRl = the part of it inside the free block.  Also presets the pivot flags of T (the dead tail counts as skipped).
+// meta per instance: [skip (rv) | skipT (rv) | nlive | nRl].  grid = batch, 256 threads.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rr2_meta_kernel(int* __restrict__ meta, long long mstride, int rv, int r, int nF, int nR) {
+  __shared__ int red[4];
+  int* mt = meta + blockIdx.x * mstride;
+  int last = -1;
+  for (int i = threadIdx.x; i < r; i += blockDim.x) if (mt[i] == 0) last = i;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(last, off, 64); last = o > last ? o : last; }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = last;
+  __syncthreads();
+  int all = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) all = red[w] > all ? red[w] : all;
+  const int nlive = all + 1;
+  int nRl = nlive - nF;
+  nRl = nRl < 0 ? 0 : (nRl > nR ? nR : nRl);
+  if (threadIdx.x == 0) { mt[2 * rv] = nlive; mt[2 * rv + 1] = nRl; }
+  for (int a = threadIdx.x; a < nR; a += blockDim.x) mt[rv + a] = (a >= nRl) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// T = C' W C for the lower-triangular block C(i, a) = L(nF + i, nF + a), a <= i < nR, W = diag(w) (the cost weights of the free
+// components in the permuted order: tabd[3][perm[nF + i]]), leading nRl columns only; a skipped pivot has a zero column in L:
+// its row and column of T come out zero and the diagonal entry is set to one.  The rows [nRl, 16 ceil(nRl / 16)) are written
+// as zeros (the lock-step Cholesky works on whole tiles).
+// One workgroup (1024 threads) per instance: C is streamed ONCE through LDS, 16 rows at a time (coalesced pieces of packed
+// rows), and every wave keeps up to RR2_CW_TPW tiles of T in accumulators -- the row index is the contraction index, 4 MFMAs
+// per tile and row block, both operands from the block in LDS.  (A first version dealt (tile row, four tile columns) items to
+// the waves of several workgroups, each streaming its own rows from L2: 7.5 x the traffic, 1.9 ms per 512 instances.)
+// More tiles than 16 RR2_CW_TPW: further passes over C.  LDS: 16 rows of `ldw` doubles (ldw = 16 mod 32) + 16 weights.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int RR2_CW_TPW = 5;
+__global__ __launch_bounds__(1024) void rr2_cwc_kernel(KParams P, int RPs, const int* __restrict__ perm, double* __restrict__ ws,
+                                                         long long stride, long long toff, const int* __restrict__ meta, long long mstride,
+                                                         int rv, int nF, int nR, unsigned long long* __restrict__ tmaxbits, int ldw) {
+  extern __shared__ __attribute__((aligned(16))) double rr2_cb[];
+  double* cb = rr2_cb;                                   // [16][ldw]
+  double* wb = rr2_cb + 16 * ldw;                        // [16]
+  const long long b = blockIdx.x;
+  const int* mt = meta + b * mstride;
+  const int ncol = mt[2 * rv + 1];
+  const int nt = (ncol + 15) >> 4;
+  if (nt == 0) return;
+  const double* Lm = ws + b * stride;
+  double* T = ws + b * stride + toff;
+  const int* skipd = mt + nF;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6;
+  const int ntile = nt * (nt + 1) / 2;
+  double tmx = 0.0;
+  for (int t0 = 0; t0 < ntile; t0 += nwave * RR2_CW_TPW) {
+    d4 acc[RR2_CW_TPW];
+    int tA[RR2_CW_TPW], tB[RR2_CW_TPW];
+#pragma unroll
+    for (int s = 0; s < RR2_CW_TPW; ++s) {
+      acc[s] = d4{0.0, 0.0, 0.0, 0.0};
+      const int id = t0 + wave + nwave * s;               // wave-uniform
+      int A = (int)((sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+      while ((A + 1) * (A + 2) / 2 <= id) ++A;
+      while (A * (A + 1) / 2 > id) --A;
+      tA[s] = (id < ntile) ? A : -1;
+      tB[s] = id - A * (A + 1) / 2;
+    }
+    for (int i0 = 0; i0 < nR; i0 += 16) {
+      const int cw = (i0 + 16) < 16 * nt ? (i0 + 16) : 16 * nt;      // columns that can be non-zero in this row block
+      __syncthreads();                                     // the previous block has been consumed
+      for (int e = tid; e < 16 * cw; e += nthr) {
+        const int ii = e / cw, cc = e - ii * cw;
+        const int i = i0 + ii;
+        double v = 0.0;
+        if (i < nR && cc <= i && cc < ncol) v = Lm[pk_row((size_t)(nF + i)) + nF + cc];
+        cb[ii * ldw + cc] = v;
+      }
+      if (tid < 16) wb[tid] = (i0 + tid < nR) ? P.tabd[3 * RPs + perm[nF + i0 + tid]] : 0.0;
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < RR2_CW_TPW; ++s) {
+        if (tA[s] < 0 || 16 * tA[s] > i0 + 15) continue;   // (wave-uniform) rows of this block have no entry in tile column A
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = l4 + 4 * e;
+          acc[s] = rr2_mfma(cb[k * ldw + 16 * tA[s] + l15] * wb[k], cb[k * ldw + 16 * tB[s] + l15], acc[s]);
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < RR2_CW_TPW; ++s) {
+      if (tA[s] < 0) continue;
+      const int bcol = 16 * tB[s] + l15;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ar = 16 * tA[s] + l4 + 4 * q;
+        if (bcol <= ar) {
+          double v = 0.0;
+          if (ar < ncol) v = (ar == bcol && skipd[ar]) ? 1.0 : acc[s][q];
+          T[pk_row((size_t)ar) + bcol] = v;
+          if (ar == bcol) tmx = fmax(tmx, v);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) tmx = fmax(tmx, __shfl_xor(tmx, off, 64));
+  if (lane == 0 && tmx > 0.0) atomicMax(tmaxbits + 4 * b, (unsigned long long)__double_as_longlong(tmx));   // (four words per instance)
+}
+
+}  // namespace ddmpc

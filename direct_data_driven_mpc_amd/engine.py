@@ -245,6 +245,12 @@ class BatchedDDMPC:
         if res_log10 is not None:
             L.check(self._lib.ddmpc_set_option(self._h, L.OPT_REFINE_RES_LOG10, int(round(-10 * res_log10))))
 
+    def set_large_pipeline(self, mode: str) -> None:
+        """NOMINAL controllers beyond the register-resident kernels: 'phases' (default: one kernel per phase over the whole
+        batch) | 'one_workgroup' (DDMPC_OPT_LARGE_PIPELINE)."""
+        L.check(self._lib.ddmpc_set_option(self._h, L.OPT_LARGE_PIPELINE,
+                                           {"one_workgroup": L.PIPELINE_ONE_WORKGROUP, "phases": L.PIPELINE_PHASES}[mode]))
+
     def closed_loop(self, A, B, Cm, D, x0, u_past, y_past, w, n_mpc_step: int = 1):
         """Batched closed loop on the device (controller_operation.py:259-305 for every instance).
 

@@ -104,6 +104,12 @@ extern "C" {
 #define DDMPC_OPT_REFINE_RES_LOG10 5  /* auto mode: refine when |t - (H(H'beta) + lam D beta)|_inf / |t|_inf exceeds
                                          10^(-value/10), value in tenths of a decade below 1 (default DDMPC_REFINE_RES_DEFAULT;
                                          3000 refines everything, 0 only what comes out non-finite) */
+#define DDMPC_OPT_LARGE_PIPELINE 6     /* NOMINAL controllers beyond the register-resident kernels ((m+p)(L+n) > 271): how the
+                                         data-dependent half of a solve (Gram, rank-revealing Cholesky, C'WC and its factor;
+                                         controller.py:506-538) is executed -- results agree to rounding */
+#define DDMPC_PIPELINE_ONE_WORKGROUP 0 /* one workgroup per instance runs every phase (ddmpc_nominal_rr_kernel<1>) */
+#define DDMPC_PIPELINE_PHASES 1        /* default: one kernel per phase over the whole batch in lock step, several workgroups
+                                         per instance, Cholesky by 64-column panels (ddmpc_rr2.hpp) */
 #define DDMPC_REFINE_RES_DEFAULT 107  /* 2e-11: benchmark data stays below ~2e-12, the parity bars are missed from ~1.3e-10 on */
 
 typedef struct ddmpc_handle ddmpc_handle;
@@ -285,6 +291,13 @@ const char* ddmpc_kernel_name(ddmpc_handle* h);
  * [15]/[13] the 100 MHz real-time counter at entry/exit.  Off by default; a stamping
  * run must not be used for timing claims. */
 int ddmpc_debug_stamps(ddmpc_handle* h, int enable, uint64_t* out);
+
+/* Diagnostics only (problems beyond the register-resident kernels): copies instance `b`'s slice of the global workspace
+ * (packed factor of the Gram matrix, then the packed factor of the reduced normal matrix; rows on 128-byte boundaries)
+ * and its pivot record [skip (rv) | skipT (rv) | nlive | nRl] to host memory, at most `ws_count` doubles / `meta_count`
+ * ints; either output may be NULL.  *ws_avail / *meta_avail (may be NULL) receive the sizes of the slices. */
+int ddmpc_debug_workspace(ddmpc_handle* h, int64_t b, double* ws_out, int64_t ws_count, int32_t* meta_out, int64_t meta_count,
+                          int64_t* ws_avail, int64_t* meta_avail);
 
 #ifdef __cplusplus
 }
