@@ -2,7 +2,7 @@
 // Host-side responsibilities: parameter validation with the reference's error
 // conditions (direct_data_driven_mpc_controller.py:165-168,211-222,298-343,664-670),
 // device buffer ownership, kernel-instance selection, launch.
-#include "ddmpc_rr2.hpp"
+#include "ddmpc_rr2_solve.hpp"
 #include "../../include/ddmpc.h"
 
 #include <cmath>
@@ -146,6 +146,8 @@ struct ddmpc_handle {
   DevBuf d_rflag;                          // AUTO refinement: per-instance "refine me" flags of the plain cold kernel
   DevBuf d_zws, d_resc, d_xws;             // NOMINAL rescue kernel: z per component, a per-instance "rescued" flag and x = L^-T w (ddmpc_get_solution)
   DevBuf d_rrmeta;                         // ... pivot pattern + live column counts of the factors it leaves in d_rr (2 rv + 2 ints per instance)
+  DevBuf d_rr2v, d_rr2zp, d_rr2sc, d_wz;   // ... vectors, Hankel partial sums and scalars of the solve (ddmpc_rr2_solve.hpp); weights / targets
+  bool rr2_x_pending = false;              // ... x = L^-T w of the last solve has not been formed yet (ddmpc_get_solution does it on demand)
   DevBuf d_rr2mt;                          // ... Minv of every 64 x 64 diagonal block of the two factors (ddmpc_rr2.hpp)
   DevBuf d_perm, d_rr2d;                   // phase kernels (ddmpc_rr2.hpp): fixed-first component order [perm | iperm]; per instance
                                            // [max diag of G | max diag of T | live chunks of G | live chunks of T]
@@ -301,6 +303,10 @@ static int upload_params(ddmpc_handle* h) {
     }
     if ((rc = h->d_perm.ensure(pm.size() * sizeof(int)))) return rc;
     HIP_TRY(hipMemcpy(h->d_perm.p, pm.data(), pm.size() * sizeof(int), hipMemcpyHostToDevice));
+    std::vector<double> wz(2 * rv, 0.0);            // cost weight and target of the free components, position order
+    for (int i = 0; i + h->nF < k.r; ++i) { wz[i] = td[3 * (size_t)RP + pm[h->nF + i]]; wz[rv + i] = td[2 * (size_t)RP + pm[h->nF + i]]; }
+    if ((rc = h->d_wz.ensure(wz.size() * sizeof(double)))) return rc;
+    HIP_TRY(hipMemcpy(h->d_wz.p, wz.data(), wz.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   h->kp.dense_w = 0;
   h->kp.dmat = nullptr;
@@ -551,7 +557,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_perm, &h->d_rr2d, &h->d_rr2mt};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_perm, &h->d_rr2d, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -755,6 +761,8 @@ static int launch_warm(ddmpc_handle* h, const double* up, const double* yp, doub
 // rr_mode (problems whose matrices live in the global workspace only): 0 whole solve, 1 the data-dependent factors alone
 // (ddmpc_prepare), 2 a solve on the factors already in the workspace (ddmpc_step) -- see ddmpc_nominal_rr_kernel.
 static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, double rank_tol);
+static int launch_rr2_solve(ddmpc_handle* h, double* scratch, long long ndbl, const double* up, const double* yp, double* uo,
+                            double* cost, int32_t* status, int32_t* iters, double feas_tol);
 static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
                                  int32_t* status, int32_t* iters, int rr_mode = 0) {
   if (h->prm.controller_type != DDMPC_NOMINAL || h->prm.weight_kind == DDMPC_WEIGHT_DENSE) return DDMPC_OK;
@@ -807,11 +815,12 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
   int rcl = DDMPC_OK;
   if (!scratch) rcl = launch(ddmpc_nominal_rr_kernel<0>);                 // matrices in LDS: one launch
   else {                                                                  // global workspace: factors, then the solve on them
-    if (rr_mode != 2) {
-      const bool phases = h->large_pipeline == DDMPC_PIPELINE_PHASES && h->large_nominal && h->batch <= 65535 && !h->stamps_on;
-      rcl = phases ? launch_rr2_factors(h, scratch, (long long)ndbl, 1e-8) : launch(ddmpc_nominal_rr_kernel<1>);
+    const bool phases = h->large_pipeline == DDMPC_PIPELINE_PHASES && h->large_nominal && h->batch <= 65535 && !h->stamps_on;
+    if (rr_mode != 2) rcl = phases ? launch_rr2_factors(h, scratch, (long long)ndbl, 1e-8) : launch(ddmpc_nominal_rr_kernel<1>);
+    if (!rcl && rr_mode != 1) {
+      h->rr2_x_pending = false;
+      rcl = phases ? launch_rr2_solve(h, scratch, (long long)ndbl, up, yp, uo, cost, status, iters, 1e-7) : launch(ddmpc_nominal_rr_kernel<2>);
     }
-    if (!rcl && rr_mode != 1) rcl = launch(ddmpc_nominal_rr_kernel<2>);
   }
   if (rcl) return rcl;
   if (rr_mode != 1) h->rescue_ran = true;
@@ -870,6 +879,68 @@ static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, 
     cholesky(FT, nR16);
   }
   HIP_TRY(hipGetLastError());
+  return DDMPC_OK;
+}
+
+// The solve on those factors (what a control step repeats, controller.py:389-407), as phase kernels (ddmpc_rr2_solve.hpp).
+static int rr2_solve_desc(ddmpc_handle* h, double* scratch, long long ndbl, Rr2Solve* out) {
+  const KParams& k = h->kp;
+  const int r = k.r, n16 = (r + 15) & ~15, nR = h->n_free, nF = h->nF, nR16 = (nR + 15) & ~15;
+  const int rv = (r + 1) & ~1, VL = (r + 63) & ~63;
+  const size_t B = (size_t)h->batch;
+  const long long m64G = (long long)((n16 + RR2_NB - 1) / RR2_NB) * RR2_NB * RR2_NB;
+  const long long m64T = (long long)((nR16 + RR2_NB - 1) / RR2_NB) * RR2_NB * RR2_NB;
+  int rc;
+  if ((rc = h->d_rr2v.ensure(B * (size_t)V_NV * VL * sizeof(double))) || (rc = h->d_rr2zp.ensure(B * (size_t)RR2_NG * VL * sizeof(double))) ||
+      (rc = h->d_rr2sc.ensure(B * (4 * sizeof(double) + 2 * sizeof(int) + sizeof(unsigned long long)))))
+    return rc;
+  Rr2Solve S{};
+  S.ws = scratch; S.stride = ndbl; S.toff = (long long)pk_size((size_t)n16);
+  S.m64 = (const double*)h->d_rr2mt.p; S.m64_stride = m64G + m64T; S.m64T = m64G;
+  S.meta = (const int*)h->d_rrmeta.p; S.mstride = 2 * (long long)rv + 2; S.rv = rv;
+  S.dd = (const unsigned long long*)h->d_rr2d.p;
+  S.perm = (const int*)h->d_perm.p;
+  S.wz = (const double*)h->d_wz.p;
+  S.V = (double*)h->d_rr2v.p; S.vstride = (long long)V_NV * VL; S.VL = VL;
+  S.ZP = (double*)h->d_rr2zp.p;
+  S.sc = (double*)h->d_rr2sc.p;
+  S.resid = (unsigned long long*)(S.sc + 4 * B);
+  S.si = (int*)(S.resid + B);
+  S.r = r; S.nF = nF; S.nR = nR;
+  *out = S;
+  return DDMPC_OK;
+}
+
+static int launch_rr2_solve(ddmpc_handle* h, double* scratch, long long ndbl, const double* up, const double* yp, double* uo,
+                            double* cost, int32_t* status, int32_t* iters, double feas_tol) {
+  Rr2Solve S;
+  int rc = rr2_solve_desc(h, scratch, ndbl, &S);
+  if (rc) return rc;
+  const KParams& k = h->kp;
+  const unsigned B = (unsigned)h->batch;
+  const int RPs = 16 * h->kc.NT, nF = S.nF, nR = S.nR;
+  auto grp = [](int n, int per) { return (unsigned)((n + per - 1) / per < 1 ? 1 : (n + per - 1) / per); };
+  hipStream_t st = h->stream;
+  hipLaunchKernelGGL(rr2_s1_kernel, dim3(B), dim3(RR2_TS), 0, st, S, k, RPs, up, yp);
+  hipLaunchKernelGGL(rr2_rows_kernel<0>, dim3(grp(nF + nR, 32), B), dim3(256), 0, st, S, k, RPs, (double*)nullptr, (double*)nullptr, 0);
+  hipLaunchKernelGGL(rr2_cols_kernel<0>, dim3(grp(nR, 64), B), dim3(512), 0, st, S, 0);
+  for (int pass = 0; pass < k.refine_max; ++pass) {
+    hipLaunchKernelGGL(rr2_s4_kernel, dim3(B), dim3(RR2_TS), 0, st, S, pass);
+    hipLaunchKernelGGL(rr2_hankel_kernel, dim3(RR2_NG, B), dim3(512), 0, st, S, k, h->ud, h->yd, (int)V_X, pass);
+    hipLaunchKernelGGL(rr2_rows_kernel<1>, dim3(grp(nR, 32), B), dim3(256), 0, st, S, k, RPs, (double*)nullptr, (double*)nullptr, pass);
+    hipLaunchKernelGGL(rr2_cols_kernel<1>, dim3(grp(nF, 64), B), dim3(512), 0, st, S, pass);
+    hipLaunchKernelGGL(rr2_s8_kernel, dim3(B), dim3(RR2_TS), 0, st, S, pass);
+    hipLaunchKernelGGL(rr2_hankel_kernel, dim3(RR2_NG, B), dim3(512), 0, st, S, k, h->ud, h->yd, (int)V_VC, pass);
+    hipLaunchKernelGGL(rr2_rows_kernel<2>, dim3(grp(nR, 32), B), dim3(256), 0, st, S, k, RPs, (double*)nullptr, (double*)nullptr, pass);
+    hipLaunchKernelGGL(rr2_s11_kernel, dim3(B), dim3(RR2_TS), 0, st, S, pass);
+    hipLaunchKernelGGL(rr2_cols_kernel<2>, dim3(grp(nR, 64), B), dim3(512), 0, st, S, pass);
+    hipLaunchKernelGGL(rr2_s13_kernel, dim3(B), dim3(RR2_TS), 0, st, S, pass, k.refine_max);
+  }
+  hipLaunchKernelGGL(rr2_rows_kernel<3>, dim3(grp(nR, 32), B), dim3(256), 0, st, S, k, RPs, uo, (double*)h->d_zws.p, 0);
+  hipLaunchKernelGGL(rr2_s15_kernel, dim3(B), dim3(RR2_TS), 0, st, S, k, RPs, feas_tol, uo, cost, (int*)status, (int*)iters,
+                     (double*)h->d_zws.p, (int*)h->d_resc.p);
+  HIP_TRY(hipGetLastError());
+  h->rr2_x_pending = true;
   return DDMPC_OK;
 }
 
@@ -1311,6 +1382,17 @@ int ddmpc_get_solution(ddmpc_handle* h, int what, double* out, int mem) {
   // the vector x it exported
   const bool resc = h->rescue_ran && h->d_resc.p && h->d_zws.p;
   if (h->large_nominal && !resc) return fail(DDMPC_ERR_NOT_READY, "no solve to read a solution from");
+  if (h->large_nominal && h->rr2_x_pending && what == DDMPC_SOL_ALPHA) {
+    // phase-kernel solve: x = L_I^-T w (alpha = H' x) is formed here, on demand, from the final w the solve kept
+    const size_t r_ = (size_t)k.r, nR_ = (size_t)h->n_free;
+    const long long ndbl_ = (long long)(pk_size((r_ + 15) & ~(size_t)15) + pk_size((nR_ + 15) & ~(size_t)15));
+    Rr2Solve S;
+    int rcx = rr2_solve_desc(h, (double*)h->d_rr.p, ndbl_, &S);
+    if (rcx) return rcx;
+    hipLaunchKernelGGL(rr2_xws_kernel, dim3((unsigned)h->batch), dim3(RR2_TS), 0, h->stream, S, k, (double*)h->d_xws.p);
+    HIP_TRY(hipGetLastError());
+    h->rr2_x_pending = false;
+  }
   hipLaunchKernelGGL(ddmpc_reconstruct_kernel, dim3((unsigned)h->batch), dim3(256), 0, h->stream, k, 16 * h->kc.NT, what, h->ud,
                      h->yd, h->last_up, h->last_yp, (const double*)h->d_beta.p, (const signed char*)h->d_act.p, dst,
                      resc ? (const double*)h->d_zws.p : (const double*)nullptr, resc ? (const int*)h->d_resc.p : (const int*)nullptr,

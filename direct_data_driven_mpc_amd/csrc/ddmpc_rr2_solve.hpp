@@ -1,0 +1,537 @@
+// ddmpc_rr2_solve.hpp -- NOMINAL controllers beyond the register-resident kernels: the solve on the factors the phase kernels of
+// ddmpc_rr2.hpp leave (what changes from control step to control step, controller.py:389-407), itself as phase kernels over
+// the whole batch.  Same mathematics as ddmpc_nominal_rr_kernel<2> (ddmpc_aux_kernels.hpp):
+//
+//   hard constraints      L_FF w1 = f                                   z0 = L_RF w1
+//   reduced normal eq.    T w2 = C' W (zs - z0)                          T = C' W C
+//   one or more passes of iterative refinement on the KKT system in the coordinates w of z = B w, B = H H_I' L_I^-T, with B
+//   and B' applied exactly (two products with the implicit Hankel matrix, one triangular solve each) and the correction
+//   solved with the factors at hand
+//
+// but every step is a launch over all instances, shaped after what the step is bound by:
+//   * triangular solves: one workgroup per instance, 64 rows per step -- the partial sums of a block are independent loads
+//     (up to 32 per thread in flight), the 64 x 64 diagonal block is applied as its inverse Minv (panel kernel), so a solve
+//     of 424 rows is 7 dependent steps instead of 27 (16-row blocks with a 16-step substitution each);
+//   * products with blocks of the factor (rows x vector, vector x columns): many workgroups per instance, streaming;
+//   * H (H' x): the column range of H split over several workgroups per instance, partial sums joined in a fixed order.
+// Nothing here uses atomics on floating-point sums: the results are reproducible bit for bit (warm step == cold solve).
+#pragma once
+#include "ddmpc_rr2.hpp"
+
+namespace ddmpc {
+
+constexpr int RR2_TS = 256;         // threads of the one-workgroup-per-instance kernels
+constexpr int RR2_VMAX = 1088;      // LDS vector length: r <= 1024 rounded up to 64, + one block
+constexpr int RR2_NG = 6;           // workgroups per instance in the Hankel product
+
+// per-instance vectors in the global workspace (position order unless noted), RR2 vector length VL = r rounded up to 64
+enum : int { V_FV = 0, V_W1, V_Z0, V_VV, V_W2, V_WK, V_X /* component order */, V_RZ, V_RBR, V_RA, V_VC /* component order */,
+             V_RW, V_DW1, V_RDR, V_DW2, V_CP, V_NV };
+// per-instance scalars (doubles): [0] max(1, |f|)  [1] rel0  [2] prevrel  [3] cost;  ints: [0] more (another pass)  [1] passes done
+struct Rr2Solve {
+  const double* ws; long long stride; long long toff;        // factor of G at +0, factor of T at +toff of an instance's slice
+  const double* m64; long long m64_stride; long long m64T;    // Minv blocks: of G at +0, of T at +m64T
+  const int* meta; long long mstride; int rv;                 // [skip (rv) | skipT (rv) | nlive | nRl]
+  const unsigned long long* dd;                               // per instance [max diag G | max diag T | live chunks G | live chunks T]
+  const int* perm;                                            // position -> component
+  const double* wz;                                           // [w (rv) | zs (rv)]: cost weight and target of the free components, position order
+  double* V; long long vstride; int VL;                       // vectors
+  double* ZP;                                                 // Hankel partial sums [batch][RR2_NG][VL], component order
+  double* sc; int* si; unsigned long long* resid;             // scalars (4 doubles, 2 ints per instance), max residual of the dependent rows (bits)
+  int r, nF, nR;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// y = L^-1 rhs on the leading n x n block of a packed factor (skipped pivots: y = 0), by one workgroup of RR2_TS threads.
+// rhs, y: LDS, length >= n rounded up to 64; tmp: 64 doubles of LDS.  Thread (row = tid / 4, part = tid % 4) of a 64-row block:
+// the part's 32-byte pieces of the row for every live 16-column chunk in front of the block (8 pieces in flight), then
+// 16 entries of the row of Minv.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rr2_trsv_fwd(const double* __restrict__ Lm, const double* __restrict__ m64, int n,
+                                             unsigned long long live, const double* rhs, double* y, double* tmp) {
+  const int tid = threadIdx.x, row = tid >> 2, part = tid & 3;
+  const int nb = (n + 63) >> 6;
+  for (int b = 0; b < nb; ++b) {
+    const int k0 = 64 * b, i = k0 + row;
+    const bool rok = i < n;
+    const double* Li = Lm + pk_row((size_t)(rok ? i : n - 1)) + 4 * part;
+    const double* Mr = m64 + (size_t)b * 4096 + row * 64 + 16 * part;
+    d4 mv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mv[q] = *reinterpret_cast<const d4*>(Mr + 4 * q);
+    unsigned long long lv = live & ((1ull << (4 * b)) - 1ull);              // (4 b <= 60)
+    double s = 0.0;
+    while (lv != 0ull) {
+      d4 v[8];
+      int jj[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool ok = lv != 0ull;
+        const int jc = ok ? __builtin_ctzll(lv) : 0;
+        if (ok) lv &= lv - 1ull;
+        jj[u] = ok ? jc : -1;
+        v[u] = *reinterpret_cast<const d4*>(Li + 16 * jc);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (jj[u] >= 0) {                                                   // (wave-uniform)
+          const double* yy = y + 16 * jj[u] + 4 * part;
+          s += (v[u][0] * yy[0] + v[u][1] * yy[1]) + (v[u][2] * yy[2] + v[u][3] * yy[3]);
+        }
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (part == 0) tmp[row] = rok ? rhs[i] - s : 0.0;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t += mv[q][e] * tmp[16 * part + 4 * q + e];   // (Minv is lower triangular: zeros above the diagonal)
+    t += __shfl_xor(t, 1, 64);
+    t += __shfl_xor(t, 2, 64);
+    if (part == 0) y[i] = rok ? t : 0.0;
+    __syncthreads();
+  }
+}
+
+// x = L^-T yv on the leading n x n block (skipped pivots: x = 0).  yv, x: LDS (x must not alias yv); red: 16 x 64 doubles, tmp: 64.
+// Thread (cq = tid % 16, rg = tid / 16): columns 4 cq .. + 3 of the block, rows rg, rg + 16, ... below it (8 in flight).
+__device__ __forceinline__ void rr2_trsv_bwd(const double* __restrict__ Lm, const double* __restrict__ m64, int n,
+                                             unsigned long long live, const double* yv, double* x, double* red, double* tmp) {
+  const int tid = threadIdx.x, cq = tid & 15, rg = tid >> 4;
+  const int c = tid & 63, pr = tid >> 6;
+  const int nb = (n + 63) >> 6;
+  for (int b = nb - 1; b >= 0; --b) {
+    const int k0 = 64 * b;
+    const double* Mb = m64 + (size_t)b * 4096;
+    double mc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) mc[q] = Mb[(16 * pr + q) * 64 + c];        // column c of Minv, rows 16 pr .. + 15
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+    for (int i0 = k0 + 64 + rg; i0 < n; i0 += 128) {
+      d4 v[8];
+      double xi[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 16 * u;
+        const bool ok = i < n && ((live >> (i >> 4)) & 1ull) != 0ull;
+        v[u] = *reinterpret_cast<const d4*>(Lm + pk_row((size_t)(i < n ? i : n - 1)) + k0 + 4 * cq);
+        xi[u] = ok ? x[i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc[0] += v[u][0] * xi[u]; acc[1] += v[u][1] * xi[u]; acc[2] += v[u][2] * xi[u]; acc[3] += v[u][3] * xi[u]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rg * 64 + 4 * cq + e] = acc[e];
+    __syncthreads();
+    if (tid < 64) {
+      double s = 0.0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) s += red[g * 64 + tid];
+      tmp[tid] = (k0 + tid < n) ? yv[k0 + tid] - s : 0.0;
+    }
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += mc[q] * tmp[16 * pr + q];             // (rows above the diagonal of column c: zeros)
+    red[pr * 64 + c] = t;
+    __syncthreads();
+    if (tid < 64) x[k0 + tid] = (k0 + tid < n) ? (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]) : 0.0;
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ double rr2_block_max(double v, double* red) {    // maximum over the workgroup (all threads get it)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = fmax(t, red[w]);
+  __syncthreads();
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// S1: the hard values f (past window / setpoint, controller.py:577-581,612-627), w1 = L_FF^-1 f.  grid = batch.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RR2_TS) void rr2_s1_kernel(Rr2Solve S, KParams P, int RPs, const double* __restrict__ u_past,
+                                                       const double* __restrict__ y_past) {
+  __shared__ __attribute__((aligned(16))) double fv[RR2_VMAX], y[RR2_VMAX], tmp[64];
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int nF = S.nF, n = P.npu / P.m;
+  const double* up = u_past + b * (long long)P.npu;
+  const double* yp = y_past + b * (long long)(n * P.p);
+  double fm = 1.0;
+  for (int i = tid; i < ((nF + 63) & ~63); i += nthr) {
+    double v = 0.0;
+    if (i < nF) {
+      const int rho = S.perm[i];
+      const int pidx = P.tabi[1 * RPs + rho];
+      v = (pidx >= 0) ? ((pidx < P.npu) ? up[pidx] : yp[pidx - P.npu]) : P.tabd[2 * RPs + rho];
+      fm = fmax(fm, fabs(v));
+    }
+    fv[i] = v; y[i] = 0.0;
+  }
+  fm = rr2_block_max(fm, tmp);
+  const double* G = S.ws + b * S.stride;
+  rr2_trsv_fwd(G, S.m64 + b * S.m64_stride, nF, S.dd[4 * b + 2], fv, y, tmp);
+  double* V = S.V + b * S.vstride;
+  for (int i = tid; i < nF; i += nthr) { V[V_FV * S.VL + i] = fv[i]; V[V_W1 * S.VL + i] = y[i]; }
+  if (tid == 0) { S.sc[4 * b + 0] = fm; S.sc[4 * b + 1] = 0.0; S.sc[4 * b + 2] = 1e300; S.si[2 * b + 0] = 1; S.si[2 * b + 1] = 0; S.resid[b] = 0ull; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Rows of the factor times a vector: out_i = sum_{j0 <= j < jend(i)} L(row0 + i, j) x[j - j0], one 32-lane half wave per row
+// (coalesced 256-byte pieces, eight loads in flight per lane).  grid = (row groups of 32, batch), 256 threads.
+//   OP 0 (after S1):   rows 0 .. nF+nR: dependent fixed rows -> their residual |f_i - L(i,:) w1| (max into `resid`);
+//                      free rows -> z0 = L_RF w1
+//   OP 1 (pass, b):    rbR_i = w_i (z0_i + C(i,:) w2 - zs_i)
+//   OP 2 (pass, d):    rdR_i = L_RF(i,:) dw1
+//   OP 3 (outputs):    z_i = rz_R,i + rdR_i + C(i,:) dw2 -> optimal_u, z_ws, cost contributions
+// ---------------------------------------------------------------------------------------------------------------
+template <int OP>
+__global__ __launch_bounds__(256) void rr2_rows_kernel(Rr2Solve S, KParams P, int RPs, double* __restrict__ u_opt,
+                                                      double* __restrict__ z_ws, int pass) {
+  __shared__ double xs[RR2_VMAX];
+  const long long b = blockIdx.y;
+  if ((OP == 1 || OP == 2) && pass > 0 && S.si[2 * b] == 0) return;         // (workgroup-uniform) this instance takes no further pass
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int nF = S.nF, nR = S.nR, VL = S.VL;
+  const int* mt = S.meta + b * S.mstride;
+  const int nlive = mt[2 * S.rv];
+  double* V = S.V + b * S.vstride;
+  const double* Lm = S.ws + b * S.stride;
+  const int nrows = (OP == 0) ? nF + nR : nR;
+  const int row_lo = (int)blockIdx.x * 32;
+  if (row_lo >= nrows) return;
+  const int xslot = (OP == 0) ? V_W1 : (OP == 1) ? V_W2 : (OP == 2) ? V_DW1 : V_DW2;
+  const int xn = (OP == 0 || OP == 2) ? nF : nR;
+  for (int i = tid; i < xn; i += nthr) xs[i] = V[xslot * VL + i];
+  __syncthreads();
+  const int hw = tid >> 5, t32 = tid & 31;
+  for (int k = 0; k < 4; ++k) {
+    const int i = row_lo + hw + 8 * k;
+    if (i >= nrows) break;                                                  // (uniform per half wave)
+    int row, j0, je;
+    if (OP == 0) { row = i; j0 = 0; je = i < nF ? i : nF; }
+    else if (OP == 2) { row = nF + i; j0 = 0; je = nF; }
+    else { row = nF + i; j0 = nF; je = (nF + i + 1) < nlive ? (nF + i + 1) : nlive; }
+    const double* Li = Lm + pk_row((size_t)row);
+    const double* xv = xs - j0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int j = j0 + t32;
+    for (; j + 224 < je; j += 256) {
+      const double l0 = Li[j], l1 = Li[j + 32], l2 = Li[j + 64], l3 = Li[j + 96], l4 = Li[j + 128], l5 = Li[j + 160], l6 = Li[j + 192],
+                   l7 = Li[j + 224];
+      s0 += l0 * xv[j] + l4 * xv[j + 128]; s1 += l1 * xv[j + 32] + l5 * xv[j + 160];
+      s2 += l2 * xv[j + 64] + l6 * xv[j + 192]; s3 += l3 * xv[j + 96] + l7 * xv[j + 224];
+    }
+    for (; j + 96 < je; j += 128) {
+      const double l0 = Li[j], l1 = Li[j + 32], l2 = Li[j + 64], l3 = Li[j + 96];
+      s0 += l0 * xv[j]; s1 += l1 * xv[j + 32]; s2 += l2 * xv[j + 64]; s3 += l3 * xv[j + 96];
+    }
+    for (; j < je; j += 32) s0 += Li[j] * xv[j];
+    double sacc = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 32);
+    if (t32 == 0) {
+      if (OP == 0) {
+        if (i < nF) {
+          if (mt[i]) atomicMax(S.resid + b, (unsigned long long)__double_as_longlong(fabs(V[V_FV * VL + i] - sacc)));
+        } else V[V_Z0 * VL + (i - nF)] = sacc;
+      } else if (OP == 1) {
+        V[V_RBR * VL + i] = S.wz[i] * (V[V_Z0 * VL + i] + sacc - S.wz[S.rv + i]);
+      } else if (OP == 2) {
+        V[V_RDR * VL + i] = sacc;
+      } else {
+        const double z = V[V_RZ * VL + nF + i] + V[V_RDR * VL + i] + sacc;
+        const double dlt = z - S.wz[S.rv + i];
+        V[V_CP * VL + i] = S.wz[i] * dlt * dlt;
+        const int rho = S.perm[nF + i];
+        const int oidx = P.tabi[2 * RPs + rho];
+        if (oidx >= 0) u_opt[b * (long long)((P.Ln - P.npu / P.m) * P.m) + oidx] = z;
+        if (z_ws) z_ws[b * (long long)P.rE + rho] = z;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A vector times columns of the factor: out_k = sum_{ibeg(k) <= i < nR} L(nF + i, col0 + k) v_i, 64 columns per workgroup, one
+// lane per column (coalesced 512-byte pieces of packed rows), 8 row groups, 8 loads in flight per thread; the row groups
+// meet in LDS in a fixed order.  grid = (column groups of 64, batch), 512 threads.
+//   OP 0 (after OP 0 of the rows kernel): v_i = w_i (zs_i - z0_i);  vv_a = skip ? 0 : sum_{i >= a} C(i, a) v_i       (a < nRl)
+//   OP 1 (pass, b):   v = rbR;  ra_k = - sum_i L_RF(i, k) v_i                                                        (k < nF)
+//   OP 2 (pass, d):   v_i = w_i rdR_i;  vv_a = skip ? 0 : - rw_{nF + a} - sum_{i >= a} C(i, a) v_i                   (a < nRl)
+// ---------------------------------------------------------------------------------------------------------------
+template <int OP>
+__global__ __launch_bounds__(512) void rr2_cols_kernel(Rr2Solve S, int pass) {
+  __shared__ double vs[RR2_VMAX];
+  __shared__ double red[8 * 64];
+  const long long b = blockIdx.y;
+  if (pass > 0 && S.si[2 * b] == 0) return;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int nF = S.nF, nR = S.nR, VL = S.VL;
+  const int* mt = S.meta + b * S.mstride;
+  const int nRl = mt[2 * S.rv + 1];
+  double* V = S.V + b * S.vstride;
+  const double* Lm = S.ws + b * S.stride;
+  const int ncols = (OP == 1) ? nF : nRl;
+  const int col0 = (OP == 1) ? 0 : nF;
+  const int k0 = (int)blockIdx.x * 64;
+  if (k0 >= ncols) return;
+  for (int i = tid; i < nR; i += nthr)
+    vs[i] = (OP == 0) ? S.wz[i] * (S.wz[S.rv + i] - V[V_Z0 * VL + i]) : (OP == 1) ? V[V_RBR * VL + i] : S.wz[i] * V[V_RDR * VL + i];
+  __syncthreads();
+  const int cl = tid & 63, rg = tid >> 6;
+  const int k = k0 + cl;
+  const bool kok = k < ncols;
+  const int kc = kok ? k : ncols - 1;
+  const int ib = (OP == 1) ? 0 : (k0 / 8) * 8;                              // first row any column of the group needs (lower-triangular block)
+  double s0 = 0.0, s1 = 0.0;
+  for (int i0 = ib + rg; i0 < nR; i0 += 64) {
+    double l[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 8 * u;
+      l[u] = Lm[pk_row((size_t)(nF + (i < nR ? i : nR - 1))) + col0 + ((OP == 1 || kc <= (i < nR ? i : nR - 1)) ? kc : 0)];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 8 * u;
+      const bool ok = i < nR && (OP == 1 || k <= i);
+      if (u & 1) s1 += ok ? l[u] * vs[i] : 0.0; else s0 += ok ? l[u] * vs[i] : 0.0;
+    }
+  }
+  red[rg * 64 + cl] = s0 + s1;
+  __syncthreads();
+  if (tid < 64 && kok) {
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += red[g * 64 + tid];
+    if (OP == 0) V[V_VV * VL + k] = mt[nF + k] ? 0.0 : s;
+    else if (OP == 1) V[V_RA * VL + k] = -s;
+    else V[V_VV * VL + k] = mt[nF + k] ? 0.0 : -V[V_RW * VL + nF + k] - s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// S4: (pass 0) w2 = T^-1 vv, w = [w1; w2];  (every pass) x = L_I^-T w in component order for the Hankel product.  grid = batch.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RR2_TS) void rr2_s4_kernel(Rr2Solve S, int pass) {
+  __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], red[16 * 64], tmp[64];
+  const long long b = blockIdx.x;
+  if (pass > 0 && S.si[2 * b] == 0) return;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int nF = S.nF, nR = S.nR, r = S.r, VL = S.VL;
+  const int* mt = S.meta + b * S.mstride;
+  const int nlive = mt[2 * S.rv], nRl = mt[2 * S.rv + 1];
+  double* V = S.V + b * S.vstride;
+  const double* G = S.ws + b * S.stride;
+  if (pass == 0) {
+    const double* T = G + S.toff;
+    const double* mT = S.m64 + b * S.m64_stride + S.m64T;
+    for (int i = tid; i < ((nRl + 63) & ~63); i += nthr) { va[i] = (i < nRl) ? V[V_VV * VL + i] : 0.0; vb[i] = 0.0; }
+    __syncthreads();
+    rr2_trsv_fwd(T, mT, nRl, S.dd[4 * b + 3], va, vb, tmp);                 // vb = T^-1 (forward)
+    rr2_trsv_bwd(T, mT, nRl, S.dd[4 * b + 3], vb, va, red, tmp);            // va = w2
+    for (int a = tid; a < nR; a += nthr) {
+      const double w2 = (a < nRl) ? va[a] : 0.0;
+      V[V_W2 * VL + a] = w2; V[V_WK * VL + nF + a] = w2;
+    }
+    for (int i = tid; i < nF; i += nthr) V[V_WK * VL + i] = V[V_W1 * VL + i];
+    __syncthreads();
+  }
+  for (int i = tid; i < ((nlive + 63) & ~63); i += nthr) { va[i] = (i < nlive) ? V[V_WK * VL + i] : 0.0; vb[i] = 0.0; }
+  __syncthreads();
+  rr2_trsv_bwd(G, S.m64 + b * S.m64_stride, nlive, S.dd[4 * b + 2], va, vb, red, tmp);
+  for (int k = tid; k < r; k += nthr) V[V_X * VL + S.perm[k]] = (k < nlive) ? vb[k] : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// z = H (H' x) over the column range of one of RR2_NG workgroups (columns of H = windows of the trajectory: a sub-range is
+// the same product on a shifted, shorter trajectory), x in component order (V_X or V_VC), partial result into ZP.
+// grid = (RR2_NG, batch), 512 threads.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void rr2_hankel_kernel(Rr2Solve S, KParams P, const double* __restrict__ u_d,
+                                                        const double* __restrict__ y_d, int slot, int pass) {
+  __shared__ __attribute__((aligned(16))) double xs[RR2_VMAX], zs[RR2_VMAX], pan[PSD_PAN];
+  const long long b = blockIdx.y;
+  if (pass > 0 && S.si[2 * b] == 0) return;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int g = blockIdx.x;
+  const int cg = (((P.c + RR2_NG - 1) / RR2_NG) + 3) & ~3;
+  const int clo = g * cg;
+  double* zp = S.ZP + (b * RR2_NG + g) * (long long)S.VL;
+  if (clo >= P.c) { for (int k = tid; k < S.r; k += nthr) zp[k] = 0.0; return; }
+  KParams Pg = P;
+  Pg.c = (P.c - clo) < cg ? (P.c - clo) : cg;
+  Pg.N = P.N - clo;
+  const double* ud = u_d + (b * (long long)P.N + clo) * P.m;
+  const double* yd = y_d + (b * (long long)P.N + clo) * P.p;
+  const double* xin = S.V + b * S.vstride + (long long)slot * S.VL;
+  for (int k = tid; k < S.r; k += nthr) xs[k] = xin[k];
+  __syncthreads();
+  hankel_normal_times(Pg, ud, yd, xs, zs, pan);
+  for (int k = tid; k < S.r; k += nthr) zp[k] = zs[k];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// S8: rz = z_ex (position order);  multipliers mu = L_FF^-T ra;  v = [mu on the independent fixed rows; W (z_ex,R - zs)] in
+// component order for the second Hankel product;  dw1 = L_FF^-1 (f - z_ex,F).  grid = batch.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RR2_TS) void rr2_s8_kernel(Rr2Solve S, int pass) {
+  __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], red[16 * 64], tmp[64];
+  const long long b = blockIdx.x;
+  if (pass > 0 && S.si[2 * b] == 0) return;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int nF = S.nF, r = S.r, VL = S.VL;
+  const int* mt = S.meta + b * S.mstride;
+  double* V = S.V + b * S.vstride;
+  const double* G = S.ws + b * S.stride;
+  const double* mG = S.m64 + b * S.m64_stride;
+  const double* zp = S.ZP + b * RR2_NG * (long long)VL;
+  for (int k = tid; k < r; k += nthr) {
+    const int rho = S.perm[k];
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < RR2_NG; ++g) s += zp[g * (long long)VL + rho];
+    V[V_RZ * VL + k] = s;
+  }
+  for (int i = tid; i < ((nF + 63) & ~63); i += nthr) { va[i] = (i < nF) ? V[V_RA * VL + i] : 0.0; vb[i] = 0.0; }
+  __syncthreads();
+  rr2_trsv_bwd(G, mG, nF, S.dd[4 * b + 2], va, vb, red, tmp);               // vb = mu
+  for (int k = tid; k < r; k += nthr) {
+    const double v = (k < nF) ? (mt[k] ? 0.0 : vb[k]) : S.wz[k - nF] * (V[V_RZ * VL + k] - S.wz[S.rv + k - nF]);
+    V[V_VC * VL + S.perm[k]] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < ((nF + 63) & ~63); i += nthr) { va[i] = (i < nF) ? V[V_FV * VL + i] - V[V_RZ * VL + i] : 0.0; vb[i] = 0.0; }
+  __syncthreads();
+  rr2_trsv_fwd(G, mG, nF, S.dd[4 * b + 2], va, vb, tmp);
+  for (int i = tid; i < nF; i += nthr) V[V_DW1 * VL + i] = vb[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// S11: rb = H (H' v) in position order;  rw = L_I^-1 rb  (= minus the residual of the stationarity rows).  grid = batch.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RR2_TS) void rr2_s11_kernel(Rr2Solve S, int pass) {
+  __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], tmp[64];
+  const long long b = blockIdx.x;
+  if (pass > 0 && S.si[2 * b] == 0) return;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int r = S.r, VL = S.VL;
+  const int* mt = S.meta + b * S.mstride;
+  const int nlive = mt[2 * S.rv];
+  double* V = S.V + b * S.vstride;
+  const double* zp = S.ZP + b * RR2_NG * (long long)VL;
+  for (int k = tid; k < ((nlive + 63) & ~63); k += nthr) {
+    double s = 0.0;
+    if (k < nlive) {
+      const int rho = S.perm[k];
+#pragma unroll
+      for (int g = 0; g < RR2_NG; ++g) s += zp[g * (long long)VL + rho];
+    }
+    va[k] = s; vb[k] = 0.0;
+  }
+  __syncthreads();
+  rr2_trsv_fwd(S.ws + b * S.stride, S.m64 + b * S.m64_stride, nlive, S.dd[4 * b + 2], va, vb, tmp);
+  for (int k = tid; k < r; k += nthr) V[V_RW * VL + k] = (k < nlive) ? vb[k] : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// S13: dw2 = T^-1 vv;  size of the correction; another pass while it still pays (the rule of ddmpc_nominal_rr_kernel: the error
+// left behind is about (size of this correction) x (size of the first one)); if so w += [dw1; dw2].  grid = batch.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RR2_TS) void rr2_s13_kernel(Rr2Solve S, int pass, int refine_max) {
+  __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], red[16 * 64], tmp[64];
+  const long long b = blockIdx.x;
+  if (pass > 0 && S.si[2 * b] == 0) return;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int nF = S.nF, nR = S.nR, r = S.r, VL = S.VL;
+  const int* mt = S.meta + b * S.mstride;
+  const int nRl = mt[2 * S.rv + 1];
+  double* V = S.V + b * S.vstride;
+  const double* T = S.ws + b * S.stride + S.toff;
+  const double* mT = S.m64 + b * S.m64_stride + S.m64T;
+  for (int i = tid; i < ((nRl + 63) & ~63); i += nthr) { va[i] = (i < nRl) ? V[V_VV * VL + i] : 0.0; vb[i] = 0.0; }
+  __syncthreads();
+  rr2_trsv_fwd(T, mT, nRl, S.dd[4 * b + 3], va, vb, tmp);
+  rr2_trsv_bwd(T, mT, nRl, S.dd[4 * b + 3], vb, va, red, tmp);              // va = dw2
+  double dmx = 0.0, wmx = 0.0;
+  for (int k = tid; k < r; k += nthr) {
+    const double dl = (k < nF) ? V[V_DW1 * VL + k] : ((k - nF) < nRl ? va[k - nF] : 0.0);
+    if (k >= nF) V[V_DW2 * VL + (k - nF)] = dl;
+    dmx = fmax(dmx, fabs(dl)); wmx = fmax(wmx, fabs(V[V_WK * VL + k]));
+  }
+  const double rel = rr2_block_max(dmx, tmp) / fmax(rr2_block_max(wmx, tmp), 1e-300);
+  const double rel0 = (pass == 0) ? rel : S.sc[4 * b + 1];
+  const double prevrel = S.sc[4 * b + 2];
+  const bool more = (pass + 1 < refine_max) && (rel * rel0 > 1e-9) && (rel < 0.25 * prevrel);
+  if (more)
+    for (int k = tid; k < r; k += nthr) V[V_WK * VL + k] += (k < nF) ? V[V_DW1 * VL + k] : ((k - nF) < nRl ? va[k - nF] : 0.0);
+  if (tid == 0) { S.sc[4 * b + 1] = rel0; S.sc[4 * b + 2] = rel; S.si[2 * b] = more ? 1 : 0; S.si[2 * b + 1] = pass + 1; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// S15: cost (the contributions of the free components, summed in a fixed order), the fixed components of optimal_u / z_ws,
+// status, and the final w = w + dw for a later ddmpc_get_solution.  grid = batch.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RR2_TS) void rr2_s15_kernel(Rr2Solve S, KParams P, int RPs, double feas_tol, double* __restrict__ u_opt,
+                                                        double* __restrict__ cost, int* __restrict__ status, int* __restrict__ iters,
+                                                        double* __restrict__ z_ws, int* __restrict__ rescued) {
+  __shared__ double red[RR2_TS];
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int nF = S.nF, nR = S.nR, r = S.r, VL = S.VL;
+  const int* mt = S.meta + b * S.mstride;
+  const int nRl = mt[2 * S.rv + 1];
+  double* V = S.V + b * S.vstride;
+  double part = 0.0;
+  for (int i = tid; i < nR; i += nthr) part += V[V_CP * VL + i];
+  red[tid] = part;
+  __syncthreads();
+  for (int off = RR2_TS / 2; off > 0; off >>= 1) {
+    if (tid < off) red[tid] += red[tid + off];
+    __syncthreads();
+  }
+  double* uo = u_opt + b * (long long)((P.Ln - P.npu / P.m) * P.m);
+  for (int k = tid; k < nF; k += nthr) {
+    const int rho = S.perm[k];
+    const int oidx = P.tabi[2 * RPs + rho];
+    const double fvk = V[V_FV * VL + k];
+    if (oidx >= 0) uo[oidx] = fvk;                                          // terminal inputs are part of optimal_u
+    if (z_ws) z_ws[b * (long long)P.rE + rho] = fvk;
+  }
+  for (int k = tid; k < r; k += nthr)                                       // the final w (ddmpc_get_solution: x = L_I^-T w, alpha = H' x)
+    V[V_WK * VL + k] += (k < nF) ? V[V_DW1 * VL + k] : ((k - nF) < nRl ? V[V_DW2 * VL + (k - nF)] : 0.0);
+  if (tid == 0) {
+    const double tot = red[0];
+    const double resid = __longlong_as_double((long long)S.resid[b]);
+    const bool feasible = resid <= feas_tol * S.sc[4 * b + 0];
+    cost[b] = tot;
+    status[b] = !(fabs(tot) < 1e300) ? 4 : (feasible ? 0 : 2);              // 2 = "infeasible"
+    if (iters) iters[b] = 1;
+    if (rescued) rescued[b] = 1;
+  }
+}
+
+// x = L_I^-T w of the final w, component order (on demand: ddmpc_get_solution).  grid = batch.
+__global__ __launch_bounds__(RR2_TS) void rr2_xws_kernel(Rr2Solve S, KParams P, double* __restrict__ x_ws) {
+  __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], red[16 * 64], tmp[64];
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int* mt = S.meta + b * S.mstride;
+  const int nlive = mt[2 * S.rv];
+  const double* V = S.V + b * S.vstride;
+  for (int i = tid; i < ((nlive + 63) & ~63); i += nthr) { va[i] = (i < nlive) ? V[V_WK * S.VL + i] : 0.0; vb[i] = 0.0; }
+  __syncthreads();
+  rr2_trsv_bwd(S.ws + b * S.stride, S.m64 + b * S.m64_stride, nlive, S.dd[4 * b + 2], va, vb, red, tmp);
+  for (int k = tid; k < S.r; k += nthr) x_ws[b * (long long)P.rE + S.perm[k]] = (k < nlive) ? vb[k] : 0.0;
+}
+
+}  // namespace ddmpc
