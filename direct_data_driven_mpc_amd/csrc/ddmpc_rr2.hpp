@@ -63,7 +63,7 @@ __device__ __forceinline__ double rr2_bits_to_double(unsigned long long v) { ret
 // The lag sums stay in the accumulators they were formed in; the window update of a whole 16x16 block is ONE MFMA with the
 // contraction index (tail term, -head term, 0, 0).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rr2_gram_kernel(KParams P, const double* __restrict__ u_d, const double* __restrict__ y_d,
+__global__ __launch_bounds__(256, 4) void rr2_gram_kernel(KParams P, const double* __restrict__ u_d, const double* __restrict__ y_d,
                                                        const int* __restrict__ iperm, double* __restrict__ ws, long long stride,
                                                        int n16, unsigned long long* __restrict__ dmaxbits) {
   __shared__ __attribute__((aligned(16))) double xc[RR2_XCAP];
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void rr2_gram_kernel(KParams P, const double* 
         const int nt = (c - t0) < TCH ? (c - t0) : TCH;
         const int nload = nt + Ln - 1;
         __syncthreads();
-        stage_trajectory<8>(P, ud, yd, t0, nload, xc);
+        stage_trajectory<4>(P, ud, yd, t0, nload, xc);
         __syncthreads();
         // lane (l15, l4): B operand x_b[t], A operand x_a[t + d], t = s4 + l4; terms t >= nt are masked by a zero in B (what
         // A reads there -- rows up to nload + 2 -- is finite: the region was zero-filled, later chunks leave older data)
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(256) void rr2_gram_kernel(KParams P, const double* 
         }
       }
       __syncthreads();
-      stage_trajectory<8>(P, ud, yd, 0, nw, xh);
-      stage_trajectory<8>(P, ud, yd, c, nw, xt);
+      stage_trajectory<4>(P, ud, yd, 0, nw, xh);
+      stage_trajectory<4>(P, ud, yd, c, nw, xt);
       __syncthreads();
       const double* xsel = (l4 == 0) ? xt : xh;
       const double sga = (l4 == 0) ? 1.0 : (l4 == 1 ? -1.0 : 0.0), sgb = (l4 < 2) ? 1.0 : 0.0;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void rr2_chol_update_kernel(Rr2Chol F, int 
 
 // Left-looking update of up to three tiles of the diagonal block by one wave (the tiles (S0,T0), (S1,T1), (S2,T2) of the block,
 // S >= T, -1: none; chosen so that a wave touches few distinct tile rows): P(s,t) = A(s,t) - sum_{j < c0, j live} L(s rows, j)
-// L(t rows, j)', operands one live chunk ahead, result into the LDS tile (strict upper triangle of a diagonal tile: zero).
+// L(t rows, j)', result into the LDS tile (strict upper triangle of a diagonal tile: zero).
 template <int S0, int T0, int S1, int T1, int S2, int T2>
 __device__ __forceinline__ void rr2_diag_update(const double* A, double (*Dt)[256], unsigned long long livemask, int c0, int n4) {
   constexpr int SS[3] = {S0, S1, S2};
@@ -296,38 +296,36 @@ __device__ __forceinline__ void rr2_diag_update(const double* A, double (*Dt)[25
   d4 acc[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) acc[k] = d4{0.0, 0.0, 0.0, 0.0};
-  d4 xr[2][4];
-  auto load = [&](int buf, int jc) __attribute__((always_inline)) {
+  // six live chunks per round, every load of the round in flight before its first MFMA (one chunk ahead of the MFMAs the
+  // loads of a chunk waited a full memory round trip for 12 MFMAs: 30 us of a late panel)
+  constexpr int GC = 6;
+  while (live != 0ull) {
+    d4 xr[GC][4];
+    int jj[GC];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      bool need = false;
+    for (int u = 0; u < GC; ++u) {
+      const bool ok = live != 0ull;
+      const int jc = ok ? __builtin_ctzll(live) : 0;
+      if (ok) live &= live - 1ull;
+      jj[u] = ok ? jc : -1;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) need = need || (SS[k] == t) || (SS[k] >= 0 && TT[k] == t);
-      if (need) xr[buf][t] = *reinterpret_cast<const d4*>(rowp[t] + 16 * jc);
+      for (int t = 0; t < 4; ++t) {
+        bool need = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) need = need || (SS[k] == t) || (SS[k] >= 0 && TT[k] == t);
+        if (need) xr[u][t] = *reinterpret_cast<const d4*>(rowp[t] + 16 * jc);
+      }
     }
-  };
-  auto fma = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      if (SS[k] < 0) continue;
-      if (SS[k] >= n4) continue;                                            // (wave-uniform) tile past the end of the matrix
+    for (int u = 0; u < GC; ++u) {
+      if (jj[u] < 0) continue;                                              // (wave-uniform)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[k] = rr2_mfma(xr[buf][TT[k]][e], xr[buf][SS[k]][e], acc[k]);
-    }
-  };
-  if (live != 0ull) {
-    int jc = __builtin_ctzll(live);
-    live &= live - 1ull;
-    load(0, jc);
-    for (;;) {
-      bool more = live != 0ull;
-      if (more) { jc = __builtin_ctzll(live); live &= live - 1ull; load(1, jc); }
-      fma(0);
-      if (!more) break;
-      more = live != 0ull;
-      if (more) { jc = __builtin_ctzll(live); live &= live - 1ull; load(0, jc); }
-      fma(1);
-      if (!more) break;
+      for (int k = 0; k < 3; ++k) {
+        if (SS[k] < 0) continue;
+        if (SS[k] >= n4) continue;                                          // (wave-uniform) tile past the end of the matrix
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[k] = rr2_mfma(xr[u][TT[k]][e], xr[u][SS[k]][e], acc[k]);
+      }
     }
   }
 #pragma unroll

@@ -20,7 +20,7 @@
 
 namespace ddmpc {
 
-constexpr int RR2_TS = 256;         // threads of the one-workgroup-per-instance kernels
+constexpr int RR2_TS = 512;         // threads of the one-workgroup-per-instance kernels
 constexpr int RR2_VMAX = 1088;      // LDS vector length: r <= 1024 rounded up to 64, + one block
 constexpr int RR2_NG = 6;           // workgroups per instance in the Hankel product
 
@@ -43,60 +43,63 @@ struct Rr2Solve {
 
 // ---------------------------------------------------------------------------------------------------------------
 // y = L^-1 rhs on the leading n x n block of a packed factor (skipped pivots: y = 0), by one workgroup of RR2_TS threads.
-// rhs, y: LDS, length >= n rounded up to 64; tmp: 64 doubles of LDS.  Thread (row = tid / 4, part = tid % 4) of a 64-row block:
-// the part's 32-byte pieces of the row for every live 16-column chunk in front of the block (8 pieces in flight), then
-// 16 entries of the row of Minv.
+// rhs, y: LDS, length >= n rounded up to 64; tmp: 64 doubles of LDS.  Eight threads per row of a 64-row block: thread
+// (part = tid % 4, half = tid / 4 % 2) takes the part's 32-byte piece of every other live 16-column chunk in front of the
+// block (8 pieces in flight: one round for 256 columns), then 8 entries of the row of Minv.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void rr2_trsv_fwd(const double* __restrict__ Lm, const double* __restrict__ m64, int n,
                                              unsigned long long live, const double* rhs, double* y, double* tmp) {
-  const int tid = threadIdx.x, row = tid >> 2, part = tid & 3;
+  const int tid = threadIdx.x, row = tid >> 3, part = tid & 3, half = (tid >> 2) & 1, sub = tid & 7;
   const int nb = (n + 63) >> 6;
   for (int b = 0; b < nb; ++b) {
     const int k0 = 64 * b, i = k0 + row;
     const bool rok = i < n;
     const double* Li = Lm + pk_row((size_t)(rok ? i : n - 1)) + 4 * part;
-    const double* Mr = m64 + (size_t)b * 4096 + row * 64 + 16 * part;
-    d4 mv[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) mv[q] = *reinterpret_cast<const d4*>(Mr + 4 * q);
+    const double* Mr = m64 + (size_t)b * 4096 + row * 64 + 8 * sub;          // 8 entries of the row of Minv
+    const d4 m0 = *reinterpret_cast<const d4*>(Mr), m1 = *reinterpret_cast<const d4*>(Mr + 4);
     unsigned long long lv = live & ((1ull << (4 * b)) - 1ull);              // (4 b <= 60)
     double s = 0.0;
     while (lv != 0ull) {
       d4 v[8];
       int jj[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const bool ok = lv != 0ull;
-        const int jc = ok ? __builtin_ctzll(lv) : 0;
-        if (ok) lv &= lv - 1ull;
-        jj[u] = ok ? jc : -1;
-        v[u] = *reinterpret_cast<const d4*>(Li + 16 * jc);
+      for (int u = 0; u < 8; ++u) {                                         // sixteen live chunks per round: this thread takes every other one
+        int jc[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const bool ok = lv != 0ull;
+          jc[hh] = ok ? __builtin_ctzll(lv) : -1;
+          if (ok) lv &= lv - 1ull;
+        }
+        const int mine = half ? jc[1] : jc[0];
+        jj[u] = mine;
+        v[u] = *reinterpret_cast<const d4*>(Li + 16 * (mine >= 0 ? mine : 0));
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (jj[u] >= 0) {                                                   // (wave-uniform)
+        if (jj[u] >= 0) {
           const double* yy = y + 16 * jj[u] + 4 * part;
           s += (v[u][0] * yy[0] + v[u][1] * yy[1]) + (v[u][2] * yy[2] + v[u][3] * yy[3]);
         }
     }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
-    if (part == 0) tmp[row] = rok ? rhs[i] - s : 0.0;
+    s += __shfl_xor(s, 4, 64);
+    if (sub == 0) tmp[row] = rok ? rhs[i] - s : 0.0;
     __syncthreads();
     double t = 0.0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) t += mv[q][e] * tmp[16 * part + 4 * q + e];   // (Minv is lower triangular: zeros above the diagonal)
+    for (int e = 0; e < 4; ++e) t += m0[e] * tmp[8 * sub + e] + m1[e] * tmp[8 * sub + 4 + e];   // (Minv is lower triangular: zeros above the diagonal)
     t += __shfl_xor(t, 1, 64);
     t += __shfl_xor(t, 2, 64);
-    if (part == 0) y[i] = rok ? t : 0.0;
+    t += __shfl_xor(t, 4, 64);
+    if (sub == 0) y[i] = rok ? t : 0.0;
     __syncthreads();
   }
 }
 
-// x = L^-T yv on the leading n x n block (skipped pivots: x = 0).  yv, x: LDS (x must not alias yv); red: 16 x 64 doubles, tmp: 64.
-// Thread (cq = tid % 16, rg = tid / 16): columns 4 cq .. + 3 of the block, rows rg, rg + 16, ... below it (8 in flight).
+// x = L^-T yv on the leading n x n block (skipped pivots: x = 0).  yv, x: LDS (x must not alias yv); red: 32 x 64 doubles, tmp: 64.
+// Thread (cq = tid % 16, rg = tid / 16): columns 4 cq .. + 3 of the block, rows rg, rg + 32, ... below it (12 in flight).
 __device__ __forceinline__ void rr2_trsv_bwd(const double* __restrict__ Lm, const double* __restrict__ m64, int n,
                                              unsigned long long live, const double* yv, double* x, double* red, double* tmp) {
   const int tid = threadIdx.x, cq = tid & 15, rg = tid >> 4;
@@ -105,22 +108,22 @@ __device__ __forceinline__ void rr2_trsv_bwd(const double* __restrict__ Lm, cons
   for (int b = nb - 1; b >= 0; --b) {
     const int k0 = 64 * b;
     const double* Mb = m64 + (size_t)b * 4096;
-    double mc[16];
+    double mc[8];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) mc[q] = Mb[(16 * pr + q) * 64 + c];        // column c of Minv, rows 16 pr .. + 15
+    for (int q = 0; q < 8; ++q) mc[q] = Mb[(8 * pr + q) * 64 + c];          // column c of Minv, rows 8 pr .. + 7
     d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-    for (int i0 = k0 + 64 + rg; i0 < n; i0 += 128) {
-      d4 v[8];
-      double xi[8];
+    for (int i0 = k0 + 64 + rg; i0 < n; i0 += 32 * 12) {
+      d4 v[12];
+      double xi[12];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + 16 * u;
+      for (int u = 0; u < 12; ++u) {
+        const int i = i0 + 32 * u;
         const bool ok = i < n && ((live >> (i >> 4)) & 1ull) != 0ull;
         v[u] = *reinterpret_cast<const d4*>(Lm + pk_row((size_t)(i < n ? i : n - 1)) + k0 + 4 * cq);
         xi[u] = ok ? x[i] : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { acc[0] += v[u][0] * xi[u]; acc[1] += v[u][1] * xi[u]; acc[2] += v[u][2] * xi[u]; acc[3] += v[u][3] * xi[u]; }
+      for (int u = 0; u < 12; ++u) { acc[0] += v[u][0] * xi[u]; acc[1] += v[u][1] * xi[u]; acc[2] += v[u][2] * xi[u]; acc[3] += v[u][3] * xi[u]; }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) red[rg * 64 + 4 * cq + e] = acc[e];
@@ -128,16 +131,21 @@ __device__ __forceinline__ void rr2_trsv_bwd(const double* __restrict__ Lm, cons
     if (tid < 64) {
       double s = 0.0;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) s += red[g * 64 + tid];
+      for (int g = 0; g < 32; ++g) s += red[g * 64 + tid];
       tmp[tid] = (k0 + tid < n) ? yv[k0 + tid] - s : 0.0;
     }
     __syncthreads();
     double t = 0.0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) t += mc[q] * tmp[16 * pr + q];             // (rows above the diagonal of column c: zeros)
+    for (int q = 0; q < 8; ++q) t += mc[q] * tmp[8 * pr + q];               // (rows above the diagonal of column c: zeros)
     red[pr * 64 + c] = t;
     __syncthreads();
-    if (tid < 64) x[k0 + tid] = (k0 + tid < n) ? (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]) : 0.0;
+    if (tid < 64) {
+      double s = 0.0;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) s += red[g * 64 + tid];
+      x[k0 + tid] = (k0 + tid < n) ? s : 0.0;
+    }
     __syncthreads();
   }
 }
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(512) void rr2_cols_kernel(Rr2Solve S, int pass) {
 // S4: (pass 0) w2 = T^-1 vv, w = [w1; w2];  (every pass) x = L_I^-T w in component order for the Hankel product.  grid = batch.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RR2_TS) void rr2_s4_kernel(Rr2Solve S, int pass) {
-  __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], red[16 * 64], tmp[64];
+  __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], red[32 * 64], tmp[64];
   const long long b = blockIdx.x;
   if (pass > 0 && S.si[2 * b] == 0) return;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(512) void rr2_hankel_kernel(Rr2Solve S, KParams P, 
 // component order for the second Hankel product;  dw1 = L_FF^-1 (f - z_ex,F).  grid = batch.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RR2_TS) void rr2_s8_kernel(Rr2Solve S, int pass) {
-  __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], red[16 * 64], tmp[64];
+  __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], red[32 * 64], tmp[64];
   const long long b = blockIdx.x;
   if (pass > 0 && S.si[2 * b] == 0) return;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -448,7 +456,7 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s11_kernel(Rr2Solve S, int pass) {
 // left behind is about (size of this correction) x (size of the first one)); if so w += [dw1; dw2].  grid = batch.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RR2_TS) void rr2_s13_kernel(Rr2Solve S, int pass, int refine_max) {
-  __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], red[16 * 64], tmp[64];
+  __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], red[32 * 64], tmp[64];
   const long long b = blockIdx.x;
   if (pass > 0 && S.si[2 * b] == 0) return;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -472,8 +480,12 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s13_kernel(Rr2Solve S, int pass, i
   const double rel0 = (pass == 0) ? rel : S.sc[4 * b + 1];
   const double prevrel = S.sc[4 * b + 2];
   const bool more = (pass + 1 < refine_max) && (rel * rel0 > 1e-9) && (rel < 0.25 * prevrel);
-  if (more)
-    for (int k = tid; k < r; k += nthr) V[V_WK * VL + k] += (k < nF) ? V[V_DW1 * VL + k] : ((k - nF) < nRl ? va[k - nF] : 0.0);
+  if (more)                                                                 // (V_W2 mirrors the free part of w: the next pass's multipliers read it)
+    for (int k = tid; k < r; k += nthr) {
+      const double dl = (k < nF) ? V[V_DW1 * VL + k] : ((k - nF) < nRl ? va[k - nF] : 0.0);
+      V[V_WK * VL + k] += dl;
+      if (k >= nF) V[V_W2 * VL + (k - nF)] += dl;
+    }
   if (tid == 0) { S.sc[4 * b + 1] = rel0; S.sc[4 * b + 2] = rel; S.si[2 * b] = more ? 1 : 0; S.si[2 * b + 1] = pass + 1; }
 }
 
@@ -522,7 +534,7 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s15_kernel(Rr2Solve S, KParams P, 
 
 // x = L_I^-T w of the final w, component order (on demand: ddmpc_get_solution).  grid = batch.
 __global__ __launch_bounds__(RR2_TS) void rr2_xws_kernel(Rr2Solve S, KParams P, double* __restrict__ x_ws) {
-  __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], red[16 * 64], tmp[64];
+  __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], red[32 * 64], tmp[64];
   const long long b = blockIdx.x;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int* mt = S.meta + b * S.mstride;

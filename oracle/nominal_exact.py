@@ -71,7 +71,28 @@ def solve_nominal_exact(spec: QPSpec, u_d, y_d, u_past, y_past, rank_tol: float 
                 residual=residual, rank=k)
 
 
-def solve_nominal_model_based(spec, plant, u_past, y_past):
+def solve_nominal_model_based_batch(spec, plant, u_past, y_past):
+    """solve_nominal_model_based for a batch of past windows of ONE plant (u_past [B, n*m], y_past [B, n*p]): the basis of the
+    trajectory space and its factorisations do not depend on the window, so they are formed once.  Returns
+    (optimal_u [B, L*m], cost [B], feas_residual [B]).  TEST INFRASTRUCTURE ONLY."""
+    u_past = np.atleast_2d(np.asarray(u_past, float)); y_past = np.atleast_2d(np.asarray(y_past, float))
+    B = u_past.shape[0]
+    one = solve_nominal_model_based(spec, plant, u_past[0], y_past[0], _parts=True)
+    Qb, F, R, W, zs, Uf, Sf, Vft, kf, fmap = (one[k] for k in ("Qb", "F", "R", "W", "zs", "Uf", "Sf", "Vft", "kf", "fmap"))
+    f = np.tile(one["f"][:, None], (1, B))                       # fixed values: the setpoint entries are the same, the past entries vary
+    for row, (kind, idx) in enumerate(fmap):
+        if kind == "u": f[row] = u_past[:, idx]
+        elif kind == "y": f[row] = y_past[:, idx]
+    c_p = Vft[:kf].T @ ((Uf[:, :kf].T @ f) / Sf[:kf, None]); Nn = Vft[kf:].T
+    sw = np.sqrt(W)
+    dd = np.linalg.lstsq(sw[:, None] * (Qb[R] @ Nn), sw[:, None] * (zs[:, None] - Qb[R] @ c_p), rcond=None)[0]
+    z = Qb @ (c_p + Nn @ dd)
+    n, m, Ln = spec.n, spec.m, spec.L + spec.n
+    return (z[:Ln * m][n * m:].T.copy(), np.sum(W[:, None] * (z[R] - zs[:, None]) ** 2, axis=0),
+            np.max(np.abs(Qb[F] @ c_p - f), axis=0))
+
+
+def solve_nominal_model_based(spec, plant, u_past, y_past, _parts=False):
     """The nominal QP on EXACT data restated on a basis of the plant's own trajectory space built from (A, B, C)
     (D = 0): every noise-free trajectory of length L+n is [u; y] = M [x_0; u], so range(H) = range(M) whenever the data
     are persistently exciting.  Not data-driven and well conditioned (no Hankel matrix, no Gram matrix): the yardstick
@@ -94,25 +115,27 @@ def solve_nominal_model_based(spec, plant, u_past, y_past):
         M[Ln * m + k * p: Ln * m + (k + 1) * p, :ns] = O[k]
         for j in range(k):
             M[Ln * m + k * p: Ln * m + (k + 1) * p, ns + j * m: ns + (j + 1) * m] = O[k - 1 - j] @ B_
-    F, R, f, W, zs = [], [], [], [], []
+    F, R, f, W, zs, fmap = [], [], [], [], [], []
     for k in range(Ln):
         kp = k - n
         for ch in range(m):
             i = k * m + ch
-            if kp < 0: F.append(i); f.append(u_past[k * m + ch])
-            elif spec.tec and kp >= Lh - n: F.append(i); f.append(u_s[ch])
+            if kp < 0: F.append(i); f.append(u_past[k * m + ch]); fmap.append(("u", k * m + ch))
+            elif spec.tec and kp >= Lh - n: F.append(i); f.append(u_s[ch]); fmap.append(("s", 0))
             else: R.append(i); W.append(rdiag[kp * m + ch]); zs.append(u_s[ch])
     for k in range(Ln):
         kp = k - n
         for ch in range(p):
             i = Ln * m + k * p + ch
-            if kp < 0: F.append(i); f.append(y_past[k * p + ch])
-            elif spec.tec and kp >= Lh - n: F.append(i); f.append(y_s[ch])
+            if kp < 0: F.append(i); f.append(y_past[k * p + ch]); fmap.append(("y", k * p + ch))
+            elif spec.tec and kp >= Lh - n: F.append(i); f.append(y_s[ch]); fmap.append(("s", 0))
             else: R.append(i); W.append(qdiag[kp * p + ch]); zs.append(y_s[ch])
     f, W, zs = np.array(f), np.array(W), np.array(zs)
     Qb, _ = np.linalg.qr(M)
     Uf, Sf, Vft = np.linalg.svd(Qb[F], True)
     kf = int(np.sum(Sf > Sf[0] * 1e-9))
+    if _parts:
+        return dict(Qb=Qb, F=F, R=R, W=W, zs=zs, Uf=Uf, Sf=Sf, Vft=Vft, kf=kf, fmap=fmap, f=f)
     c_p = Vft[:kf].T @ ((Uf[:, :kf].T @ f) / Sf[:kf]); Nn = Vft[kf:].T
     sw = np.sqrt(W)
     dd = np.linalg.lstsq(sw[:, None] * (Qb[R] @ Nn), sw * (zs - Qb[R] @ c_p), rcond=None)[0]

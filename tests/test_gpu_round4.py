@@ -81,3 +81,96 @@ def test_auto_refinement_of_the_affine_law_with_zero_setpoints(gpu):
     assert err["off"][0] > 10 * err["auto"][0], err          # the unrefined law is visibly worse: the probe did flag
     # the law itself: AUTO's equals ALWAYS's where it was refined (here: every instance)
     assert np.max(np.abs(gain["auto"] - gain["always"])) <= 1e-9 * np.max(np.abs(gain["always"]))
+
+
+# ------------------------------------------------------------------ cfg 5 at its stated batch, phase-kernel pipeline
+def test_config5_at_its_stated_batch(gpu):
+    # BASELINE configs[4] (nominal, m = p = 8, n = 8, L = 30, N = 2000, exact data; 608 rows, rank 312), ALL 512 instances, on
+    # the default path (phase kernels: ddmpc_rr2.hpp / ddmpc_rr2_solve.hpp), every one against the model-based solution of
+    # the same QP at the standard bars; ubar of the solution consistent with optimal_u
+    from test_gpu_round3 import _config5
+    from oracle.nominal_exact import solve_nominal_model_based_batch
+    B = 512
+    spec, plant, N, d, up, yp = _config5(B)
+    u_ref, c_ref, feas = solve_nominal_model_based_batch(spec, plant, up, yp)
+    assert np.max(feas) < 1e-10
+    with _spec_engine(spec, N, B) as eng:
+        eng.set_data(d["u_d"], d["y_d"])
+        u, cost, status, iters = eng.solve(up, yp)
+        ub = eng.get_solution("ubar")
+    assert np.all(status == 0) and np.all(iters == 1)
+    eu = np.max(np.max(np.abs(u - u_ref), axis=1) / np.max(np.abs(u_ref), axis=1))
+    ec = np.max(np.abs(cost - c_ref) / np.abs(c_ref))
+    assert eu < TOL_U and ec < TOL_COST, (eu, ec)
+    assert np.array_equal(ub[:, spec.n * spec.m:], u)
+
+
+def _exact_plant_case(seed, m, p, n, Lh, N, B):
+    rng = np.random.default_rng(seed)
+    ns = n
+    A = rng.normal(size=(ns, ns)); A *= 0.9 / max(abs(np.linalg.eigvals(A)))
+    plant = dict(A=A, B=rng.normal(size=(ns, m)), C=rng.normal(size=(p, ns)), D=np.zeros((p, m)), eps_max=0.0)
+    u_s = 0.1 * np.ones(m); y_s = (plant["C"] @ np.linalg.inv(np.eye(ns) - A) @ plant["B"]) @ u_s
+    spec = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=3.0 * np.eye(p * Lh), R=1e-4 * np.eye(m * Lh), u_s=u_s, y_s=y_s, robust=False,
+                      eps_max=0.0, lamb_alpha=0.0, lamb_sigma=0.0, c=0.0, slack="none", tec=True)
+    d = harness.generate_batch(range(B), N=N, plant=plant)
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    return spec, plant, d, up, yp
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 3, 60, 900), (2, 2, 4, 70, 700), (5, 4, 5, 40, 1200)],
+                         ids=["5ch-315rows", "4ch-296rows", "9ch-405rows"])
+def test_large_nominal_pipelines_agree(gpu, shape):
+    # NOMINAL controllers beyond the register-resident kernels on exact data of random stable plants -- channel counts that
+    # do not fill a 16-wide tile, row counts that are no multiple of 16 or 64, fixed blocks that end inside a panel: the phase
+    # kernels (default) and the one-workgroup kernels (DDMPC_OPT_LARGE_PIPELINE) must agree with each other far inside the
+    # bars and both meet the model-based solution of the same QP (controller.py:506-538,679-711)
+    from oracle.nominal_exact import solve_nominal_model_based_batch
+    m, p, n, Lh, N = shape
+    B = 5
+    # (plant seeds 4 / 125 / 142: dependent rows leave <= 1e-11 of the largest Gram diagonal as rounding residue, far below the
+    #  rank tolerance 1e-8; DESIGN.md section 9 records a 9-channel plant whose residue sits AT the tolerance)
+    spec, plant, d, up, yp = _exact_plant_case({9: 4, 5: 125, 4: 142}[m + p], m, p, n, Lh, N, B)
+    u_ref, c_ref, feas = solve_nominal_model_based_batch(spec, plant, up, yp)
+    assert np.max(feas) < 1e-10
+    res = {}
+    for mode in ("phases", "one_workgroup"):
+        with _spec_engine(spec, N, B) as eng:
+            assert (m + p) * (Lh + n) > 271 and "nominal_rr" in eng.kernel_name()
+            eng.set_large_pipeline(mode)
+            eng.set_data(d["u_d"], d["y_d"])
+            res[mode] = tuple(x.copy() for x in eng.solve(up, yp))
+            al = eng.get_solution("alpha"); ub = eng.get_solution("ubar"); yb = eng.get_solution("ybar")
+            # alpha (controller.py:434): H alpha reproduces [ubar; ybar]
+            Hu, Hy = orc.hankel_matrix(d["u_d"][0], spec.Ln), orc.hankel_matrix(d["y_d"][0], spec.Ln)
+            sc = max(np.max(np.abs(ub[0])), np.max(np.abs(yb[0])))
+            assert np.max(np.abs(Hu @ al[0] - ub[0])) < 1e-7 * sc and np.max(np.abs(Hy @ al[0] - yb[0])) < 1e-7 * sc, mode
+    for mode, (u, c, st, it) in res.items():
+        assert np.all(st == 0), mode
+        eu = np.max(np.max(np.abs(u - u_ref), axis=1) / np.max(np.abs(u_ref), axis=1))
+        ec = np.max(np.abs(c - c_ref) / np.abs(c_ref))
+        assert eu < TOL_U and ec < TOL_COST, (mode, eu, ec)
+    a, bq = res["phases"], res["one_workgroup"]
+    assert np.max(np.abs(a[0] - bq[0])) < 1e-8 * np.max(np.abs(bq[0])) and np.max(np.abs(a[1] - bq[1]) / np.abs(bq[1])) < 1e-10
+
+
+def test_large_nominal_infeasible_setpoint_and_refinement_cap(gpu):
+    # exact data and a terminal equality the plant cannot meet (a setpoint that is no equilibrium): CVXPY would report
+    # "infeasible" (controller.py:585-629), and so must both pipelines; with a true equilibrium the result does not depend on
+    # the cap on refinement passes (no instance of this data asks for a second one)
+    m, p, n, Lh, N, B = 3, 3, 4, 44, 900, 4
+    spec, plant, d, up, yp = _exact_plant_case(7, m, p, n, Lh, N, B)
+    bad = orc.QPSpec(**{**spec.__dict__, "y_s": spec.y_s + 0.3})
+    for mode in ("phases", "one_workgroup"):
+        with _spec_engine(bad, N, B) as eng:
+            eng.set_large_pipeline(mode)
+            eng.set_data(d["u_d"], d["y_d"])
+            _, _, st, _ = eng.solve(up, yp)
+            assert [L.STATUS_STRINGS[int(s)] for s in st] == ["infeasible"] * B, mode
+    out = {}
+    for cap in (1, 3):
+        with _spec_engine(spec, N, B) as eng:
+            eng.set_refinement("auto", max_passes=cap)
+            eng.set_data(d["u_d"], d["y_d"])
+            out[cap] = tuple(x.copy() for x in eng.solve(up, yp))
+    assert np.all(out[1][2] == 0) and np.array_equal(out[1][0], out[3][0]) and np.array_equal(out[1][1], out[3][1])

@@ -14,8 +14,12 @@ from direct_data_driven_mpc_amd.harness import generate_batch
 from oracle import ddmpc_oracle as orc
 from oracle.nominal_exact import solve_nominal_exact, solve_nominal_model_based
 
-ap = argparse.ArgumentParser(); ap.add_argument("--cases", type=int, default=24); a = ap.parse_args()
-worst = 0.0
+ap = argparse.ArgumentParser(); ap.add_argument("--cases", type=int, default=24)
+ap.add_argument("--pipeline", default=None, help="phases | one_workgroup (DDMPC_OPT_LARGE_PIPELINE; default: the library's)")
+ap.add_argument("--no-svd", action="store_true", help="compare with the model-based solution only (faster)")
+ap.add_argument("--large-only", action="store_true", help="only the cases beyond the register-resident kernels")
+a = ap.parse_args()
+worst = 0.0; bad = 0
 for case in range(a.cases):
     rng = np.random.default_rng(9000 + case)
     m, p = [(2, 2), (1, 3), (3, 1), (2, 3), (4, 2), (1, 1)][case % 6]
@@ -24,6 +28,7 @@ for case in range(a.cases):
     Lh = max(2 * n, rows // (m + p) - n)
     r = (m + p) * (Lh + n)
     N = (m + 1) * (Lh + 2 * n) + int(rng.integers(100, 300))
+    if a.large_only and r <= 271: continue
     A = rng.normal(size=(ns, ns)); A *= rng.uniform(0.5, 0.9) / max(abs(np.linalg.eigvals(A)))
     plant = dict(A=A, B=rng.normal(size=(ns, m)), C=rng.normal(size=(p, ns)), D=np.zeros((p, m)), eps_max=0.0)
     u_s = rng.uniform(-0.5, 0.5, m)
@@ -36,18 +41,20 @@ for case in range(a.cases):
     up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
     with BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=q, R=rw, u_s=u_s, y_s=y_s, batch=B, controller_type=L.NOMINAL) as eng:
         name = eng.kernel_name()
+        if a.pipeline: eng.set_large_pipeline(a.pipeline)
         eng.set_data(d["u_d"], d["y_d"])
         u, cost, status, _ = eng.solve(up, yp)
     e_svd = e_mod = 0.0; ok = True
     for b in range(B):
-        ref = solve_nominal_exact(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
         mod = solve_nominal_model_based(spec, plant, up[b], yp[b])
-        ok &= ref["status"] == "optimal" and L.STATUS_STRINGS[int(status[b])] == "optimal"
+        ref = mod if a.no_svd else solve_nominal_exact(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
+        ok &= (a.no_svd or ref["status"] == "optimal") and L.STATUS_STRINGS[int(status[b])] == "optimal"
         sc = max(np.max(np.abs(mod["optimal_u"])), 1e-3)
         e_svd = max(e_svd, np.max(np.abs(u[b] - ref["optimal_u"])) / sc)
         e_mod = max(e_mod, np.max(np.abs(u[b] - mod["optimal_u"])) / sc)
     worst = max(worst, e_mod)
     print("case %2d m=%d p=%d n=%d L=%3d N=%4d r=%3d %-32s status %s  rel err u: vs SVD solve %.1e, vs model-based %.1e" % (
         case, m, p, n, Lh, N, r, name, "ok" if ok else "MISMATCH " + str(status.tolist()), e_svd, e_mod), flush=True)
-    assert ok
-print("worst rel err vs the model-based solution over %d cases: %.2e" % (a.cases, worst))
+    bad += (not ok) or not (e_mod < 1e-8)
+print("worst rel err vs the model-based solution over %d cases: %.2e; cases off the bars (1e-8) or not optimal: %d" % (a.cases, worst, bad))
+assert bad == 0
