@@ -820,6 +820,7 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
     if (!rcl && rr_mode != 1) {
       h->rr2_x_pending = false;
       rcl = phases ? launch_rr2_solve(h, scratch, (long long)ndbl, up, yp, uo, cost, status, iters, 1e-7) : launch(ddmpc_nominal_rr_kernel<2>);
+      if (!rcl && phases && h->kp.refine_max > 1) rcl = launch(ddmpc_nominal_rr_kernel<2>);      // the instances the phase solve marked 4 (more passes)
     }
   }
   if (rcl) return rcl;
@@ -924,7 +925,10 @@ static int launch_rr2_solve(ddmpc_handle* h, double* scratch, long long ndbl, co
   hipLaunchKernelGGL(rr2_s1_kernel, dim3(B), dim3(RR2_TS), 0, st, S, k, RPs, up, yp);
   hipLaunchKernelGGL(rr2_rows_kernel<0>, dim3(grp(nF + nR, 32), B), dim3(256), 0, st, S, k, RPs, (double*)nullptr, (double*)nullptr, 0);
   hipLaunchKernelGGL(rr2_cols_kernel<0>, dim3(grp(nR, 64), B), dim3(512), 0, st, S, 0);
-  for (int pass = 0; pass < k.refine_max; ++pass) {
+  {
+    // one refinement pass for everybody; an instance whose correction says another pass would still pay (rr2_s13_kernel: the
+    // rule of ddmpc_nominal_rr_kernel) is marked and solved again, passes and all, by that kernel behind this sequence
+    const int pass = 0;
     hipLaunchKernelGGL(rr2_s4_kernel, dim3(B), dim3(RR2_TS), 0, st, S, pass);
     hipLaunchKernelGGL(rr2_hankel_kernel, dim3(RR2_NG, B), dim3(512), 0, st, S, k, h->ud, h->yd, (int)V_X, pass);
     hipLaunchKernelGGL(rr2_rows_kernel<1>, dim3(grp(nR, 32), B), dim3(256), 0, st, S, k, RPs, (double*)nullptr, (double*)nullptr, pass);

@@ -28,7 +28,7 @@ namespace ddmpc {
 constexpr int RR2_NB = 64;        // panel width of the lock-step Cholesky (four 16-column tiles)
 constexpr int RR2_SL = 5;         // lags per wave in the Gram kernel
 constexpr int RR2_XCAP = 4096;    // doubles of LDS the Gram kernel stages trajectory chunks in
-constexpr int RR2_UT = 4;         // row tiles per wave in the Cholesky update kernel
+constexpr int RR2_UT = 3;         // row tiles per wave in the Cholesky update kernel
 
 // D[a][b] += sum_k A[a][k] B[k][b] on v_mfma_f64_16x16x4: lane (l15, l4) passes A[a = l15][k = l4] and B[k = l4][b = l15];
 // register q of the accumulator holds D[l4 + 4q][l15].
@@ -156,13 +156,13 @@ __global__ __launch_bounds__(256, 4) void rr2_gram_kernel(KParams P, const doubl
 // (register q of lane (l4, l15) = entry [panel column l4 + 4q][row l15]), which makes a finished P tile directly the B operand
 // of the multiplication with Minv.  Per live 16-column chunk the panel's own 64 rows -- the operand every wave of every
 // workgroup of the instance needs -- are staged ONCE per workgroup in LDS (double-buffered, one barrier per chunk), the waves'
-// own rows are 32-byte pieces of packed rows loaded one chunk ahead of the MFMAs that consume them.  (As two kernels -- update
+// own rows are 32-byte pieces of packed rows loaded two chunks ahead of the MFMAs that consume them.  (As two kernels -- update
 // with a store of P, then a solve that read P back -- the panel went through HBM four times per step instead of twice.)
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int RR2_PLD = 18;         // doubles per staged panel row (16 + 2: the 16 rows of a tile land in different banks)
 template <int RT>
 __global__ __launch_bounds__(256, 2) void rr2_chol_update_kernel(Rr2Chol F, int c0) {
-  __shared__ __attribute__((aligned(16))) double pl[2][64 * RR2_PLD];
+  __shared__ __attribute__((aligned(16))) double pl[3][64 * RR2_PLD];
   __shared__ __attribute__((aligned(16))) double Mi[10][256];               // tile (t, u), u <= t, of Minv at index t (t + 1) / 2 + u, row-major
   const long long b = blockIdx.y;
   const int n16 = F.n_inst ? ((F.n_inst[b * F.n_stride] + 15) & ~15) : F.n16;
@@ -175,6 +175,11 @@ __global__ __launch_bounds__(256, 2) void rr2_chol_update_kernel(Rr2Chol F, int 
   if (tb + (int)blockIdx.x * 4 * RT >= nt) return;                          // (workgroup-uniform: no row tile left for this group)
   const int t0 = tb + ((int)blockIdx.x * 4 + wave) * RT;                    // first row tile of this wave (wave-uniform)
   unsigned long long live = F.live[b * F.l_stride] & ((1ull << tp) - 1ull);   // chunks in front of the panel (tp <= 63)
+  // Column order inside a 16-column tile of the accumulators: lane l15 feeds panel row pi(l15) = 4 (l15 % 4) + l15 / 4 as the
+  // A operand, so that register q of lane (l4, l15) holds panel column 4 l4 + q (not l4 + 4 q) of the tile: the FOUR registers
+  // of a lane are four consecutive entries of a packed row -- one 32-byte access per lane and tile in the epilogue instead of
+  // four 8-byte ones at a stride of four (with those the epilogue alone took ~100 us of a step: 117 us at 4 chunks of update).
+  const int pil = 4 * (l15 & 3) + (l15 >> 2);
   // staging role of this thread: 32 bytes of panel row (tid >> 2), columns 4 (tid & 3) .. + 3 of the chunk
   const int srow = tid >> 2, spart = tid & 3;
   const double* sptr = A + pk_row((size_t)(c0 + srow)) + 4 * spart;
@@ -204,21 +209,27 @@ __global__ __launch_bounds__(256, 2) void rr2_chol_update_kernel(Rr2Chol F, int 
 #pragma unroll
     for (int ti = 0; ti < 10; ++ti) Mi[ti][tid] = mv[ti];
   }
-  d4 xa[2][RT], sreg;
-  auto load = [&](int buf, int jc) __attribute__((always_inline)) {
-    sreg = *reinterpret_cast<const d4*>(sptr + 16 * jc);
+  // operands two live chunks ahead of the MFMAs that consume them (one chunk ahead every chunk waited out a memory round trip:
+  // 64 % of the wave-cycles parked, the matrix pipe 26 % busy)
+  d4 xa[3][RT], sreg[3];
+  auto load = [&](int buf) __attribute__((always_inline)) {                 // next live chunk -> buffer `buf`; false when there is none
+    if (live == 0ull) return false;
+    const int jc = __builtin_ctzll(live);
+    live &= live - 1ull;
+    sreg[buf] = *reinterpret_cast<const d4*>(sptr + 16 * jc);
 #pragma unroll
     for (int s = 0; s < RT; ++s) xa[buf][s] = *reinterpret_cast<const d4*>(mrow[s] + 16 * jc);
+    return true;
   };
   auto stage = [&](int buf) __attribute__((always_inline)) {
-    *reinterpret_cast<d2*>(&pl[buf][soff]) = d2{sreg[0], sreg[1]};
-    *reinterpret_cast<d2*>(&pl[buf][soff + 2]) = d2{sreg[2], sreg[3]};
+    *reinterpret_cast<d2*>(&pl[buf][soff]) = d2{sreg[buf][0], sreg[buf][1]};
+    *reinterpret_cast<d2*>(&pl[buf][soff + 2]) = d2{sreg[buf][2], sreg[buf][3]};
   };
   auto fma_chunk = [&](int buf) __attribute__((always_inline)) {
     if (!on[0]) return;                                                     // (wave-uniform) an idle wave only stages
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
-      const double* pp = &pl[buf][(16 * ct + l15) * RR2_PLD + 4 * l4];
+      const double* pp = &pl[buf][(16 * ct + pil) * RR2_PLD + 4 * l4];
       const d2 p0 = *reinterpret_cast<const d2*>(pp), p1 = *reinterpret_cast<const d2*>(pp + 2);
 #pragma unroll
       for (int s = 0; s < RT; ++s)
@@ -230,36 +241,33 @@ __global__ __launch_bounds__(256, 2) void rr2_chol_update_kernel(Rr2Chol F, int 
         }
     }
   };
-  if (live != 0ull) {
-    int jc = __builtin_ctzll(live);
-    live &= live - 1ull;
-    load(0, jc);
-    for (;;) {
-      stage(0);
-      __syncthreads();
-      bool more = live != 0ull;
-      if (more) { jc = __builtin_ctzll(live); live &= live - 1ull; load(1, jc); }
-      fma_chunk(0);
-      if (!more) break;
-      stage(1);
-      __syncthreads();
-      more = live != 0ull;
-      if (more) { jc = __builtin_ctzll(live); live &= live - 1ull; load(0, jc); }
-      fma_chunk(1);
-      if (!more) break;
+  {
+    int have = 0;                                                           // chunks loaded and not yet consumed (0 .. 2 here)
+    if (load(0)) have = 1;
+    if (have == 1 && load(1)) have = 2;
+    // steady state: buffer i % 3 is consumed while (i + 1) % 3 is in flight and (i + 2) % 3 is issued
+    while (have > 0) {
+      if (load(2)) ++have;
+      stage(0); __syncthreads(); fma_chunk(0); --have;
+      if (have == 0) break;
+      if (load(0)) ++have;
+      stage(1); __syncthreads(); fma_chunk(1); --have;
+      if (have == 0) break;
+      if (load(1)) ++have;
+      stage(2); __syncthreads(); fma_chunk(2); --have;
     }
   }
   __syncthreads();                                                          // Mi is in LDS (and every wave is through with pl)
-  // P' = A' - acc, then X' = Minv P' tile row by tile row, in place
+  // P' = A' - acc, then X' = Minv P' tile row by tile row, in place.  In the permuted column order both the contraction index
+  // (register e of lane (l4, .) = column 4 l4 + e of tile u) and the output index (row a of the MFMA = column pi(a) of tile ct)
+  // of the multiplication with Minv follow: the A operand is Minv(ct,u)[pi(l15)][4 l4 + e].
 #pragma unroll
   for (int s = 0; s < RT; ++s) {
     if (!on[s]) continue;
     const int i = 16 * (t0 + s) + l15;
-    double* Ai = A + pk_row((size_t)i) + c0;
+    double* Ai = A + pk_row((size_t)i) + c0 + 4 * l4;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[s][ct][q] = Ai[16 * ct + l4 + 4 * q] - acc[s][ct][q];
+    for (int ct = 0; ct < 4; ++ct) acc[s][ct] = *reinterpret_cast<const d4*>(Ai + 16 * ct) - acc[s][ct];
     d4 x[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) x[ct] = d4{0.0, 0.0, 0.0, 0.0};
@@ -269,11 +277,9 @@ __global__ __launch_bounds__(256, 2) void rr2_chol_update_kernel(Rr2Chol F, int 
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
-          if (ct >= u) x[ct] = rr2_mfma(Mi[ct * (ct + 1) / 2 + u][l15 * 16 + l4 + 4 * e], acc[s][u][e], x[ct]);
+          if (ct >= u) x[ct] = rr2_mfma(Mi[ct * (ct + 1) / 2 + u][pil * 16 + 4 * l4 + e], acc[s][u][e], x[ct]);
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Ai[16 * ct + l4 + 4 * q] = x[ct][q];
+    for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<d4*>(Ai + 16 * ct) = x[ct];
   }
 }
 
@@ -338,11 +344,58 @@ __device__ __forceinline__ void rr2_diag_update(const double* A, double (*Dt)[25
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int cc = l4 + 4 * q;
+      // a diagonal tile is kept FULL and symmetric (rr2_tile_factor works on the whole tile): the entry above the diagonal is
+      // the stored one mirrored (the accumulator is bitwise symmetric: both entries sum the same products in the same order)
       const bool lower = (SS[k] > TT[k]) || (cc <= l15);
-      const double av = Ai[lower ? cc : 0];
-      Dst[l15 * 16 + cc] = lower ? av - acc[k][q] : 0.0;
+      const double av = lower ? Ai[cc] : A[pk_row((size_t)(c0 + 16 * SS[k] + cc)) + c0 + 16 * TT[k] + l15];
+      Dst[l15 * 16 + cc] = av - acc[k][q];
     }
   }
+}
+
+// One wave factors a full symmetric 16 x 16 tile held row-major in LDS, right-looking with the tile in ONE accumulator
+// (register q of lane (l4, l15) = D[l4 + 4q][l15]): per column the pivot comes out of the accumulator by v_readlane, and the
+// rank-1 update of the whole tile is a single MFMA whose operands are row c of the tile itself -- it sits in register c / 4 of
+// the lanes with l4 = c % 4, exactly the lanes that feed contraction slot c % 4 -- scaled by 1 / sqrt(pivot).  No LDS round
+// trip on the chain (psd_tile_factor: two per column, ~550 cycles; here ~200).  Pivots <= tol are skipped (column zeroed).
+// Leaves L in the lower triangle of Dg (zeros above), Ms[k][m] = Mt[m][k] with Mt = S L~^-1, Dinv, the pivot flags.
+__device__ __forceinline__ void rr2_tile_factor(double* Dg, double* Ms, double* Dinv, double tol, int* skipout) {
+  const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  d4 acc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = Dg[(l4 + 4 * q) * 16 + l15];
+  static_for<16>([&](auto cc) __attribute__((always_inline)) {
+    constexpr int c = cc();
+    constexpr int q = c >> 2, slot = c & 3;
+    const double dk = lane_value_f64(acc[q], slot * 16 + c);               // D[c][c], the same in every lane
+    const bool sk = !(dk > tol);
+    const double dks = sk ? 1.0 : dk;
+    const double y0 = __builtin_amdgcn_rsq(dks);
+    const double ye = fma(-dks * y0, y0, 1.0);
+    const double y1 = fma(0.5 * y0, ye, y0);
+    const double ye1 = fma(-dks * y1, y1, 1.0);
+    const double inv = sk ? 0.0 : fma(0.5 * y1, ye1, y1);
+    const bool mine = l4 == slot;
+    const double u = (mine && l15 >= c) ? acc[q] * inv : 0.0;                // u_i = D[c][i] / sqrt(pivot), i = l15 >= c
+    if (mine) Dg[l15 * 16 + c] = u;                                          // L(i, c); zeros above the diagonal
+    acc = rr2_mfma(-u, u, acc);
+    if (lane == 0) { skipout[c] = sk ? 1 : 0; Dinv[c] = inv; }
+  });
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                     // in-wave hand-off through LDS
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 16) {                                     // column `lane` of L~^-1 by forward substitution, rows of skipped pivots zero
+    double y[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      double sacc = (c == lane) ? 1.0 : 0.0;
+#pragma unroll
+      for (int c1 = 0; c1 < c; ++c1) sacc -= Dg[c * 16 + c1] * y[c1];
+      y[c] = sacc * Dinv[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) Ms[lane * 16 + c] = y[c];          // Ms[k = lane][m = c] = Mt[c][lane]
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -377,7 +430,7 @@ __global__ __launch_bounds__(256) void rr2_chol_panel_kernel(Rr2Chol F, int c0) 
   for (int e = tid; e < 4 * 256; e += nthr) Ms[e >> 8][e & 255] = 0.0;
   __syncthreads();
   for (int t = 0; t < n4; ++t) {
-    if (wave == 0) psd_tile_factor(Dt[t * (t + 1) / 2 + t], Ms[t], Dinv + 16 * t, 16, tol, skipl + 16 * t);
+    if (wave == 0) rr2_tile_factor(Dt[t * (t + 1) / 2 + t], Ms[t], Dinv + 16 * t, tol, skipl + 16 * t);
     __syncthreads();
     // tiles below the diagonal tile: X(s,t) = P(s,t) Mt'   (X'[m][i] = sum_k Mt[m][k] P'[k][i])
     if (wave >= 1 && t + wave < n4) {

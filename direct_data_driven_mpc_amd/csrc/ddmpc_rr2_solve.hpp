@@ -526,7 +526,9 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s15_kernel(Rr2Solve S, KParams P, 
     const double resid = __longlong_as_double((long long)S.resid[b]);
     const bool feasible = resid <= feas_tol * S.sc[4 * b + 0];
     cost[b] = tot;
-    status[b] = !(fabs(tot) < 1e300) ? 4 : (feasible ? 0 : 2);              // 2 = "infeasible"
+    // (an instance that asked for another refinement pass is solved again, with all its passes, by ddmpc_nominal_rr_kernel<2>,
+    //  launched behind this kernel for the instances marked 4: the rare case does not cost the batch a launch sequence per pass)
+    status[b] = (S.si[2 * b] != 0 || !(fabs(tot) < 1e300)) ? 4 : (feasible ? 0 : 2);   // 2 = "infeasible"
     if (iters) iters[b] = 1;
     if (rescued) rescued[b] = 1;
   }
@@ -536,6 +538,7 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s15_kernel(Rr2Solve S, KParams P, 
 __global__ __launch_bounds__(RR2_TS) void rr2_xws_kernel(Rr2Solve S, KParams P, double* __restrict__ x_ws) {
   __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], red[32 * 64], tmp[64];
   const long long b = blockIdx.x;
+  if (S.si[2 * b] != 0) return;                                             // solved by ddmpc_nominal_rr_kernel<2>, which exported its own x
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int* mt = S.meta + b * S.mstride;
   const int nlive = mt[2 * S.rv];
