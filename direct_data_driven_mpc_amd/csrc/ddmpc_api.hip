@@ -922,6 +922,22 @@ static int launch_rr2_solve(ddmpc_handle* h, double* scratch, long long ndbl, co
   const int RPs = 16 * h->kc.NT, nF = S.nF, nR = S.nR;
   auto grp = [](int n, int per) { return (unsigned)((n + per - 1) / per < 1 ? 1 : (n + per - 1) / per); };
   hipStream_t st = h->stream;
+  // H (H' x): on the matrix pipe when the shape allows it (up to 16 channels, at most 8 tiles per half, LDS within reach)
+  int hk_ng = 0;
+  size_t hk_lds = 0;
+  if (k.nch <= 16) {
+    for (int ng = RR2_NG; ng >= 1 && hk_ng == 0; --ng) {                     // as many workgroups per instance as leave >= 64 columns each
+      const Rr2HankelGeom G = rr2_hankel_geom(k.c, k.Ln, k.nch, ng);
+      const size_t bytes = rr2_hankel_mfma_lds(G, k.Ln) * sizeof(double);
+      if ((G.cg >= 64 || ng == 1) && bytes <= 80 * 1024 && G.ntA <= 8 && G.ntZ <= 8) { hk_ng = ng; hk_lds = bytes; }
+    }
+    if (hk_ng && hk_lds > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute((const void*)rr2_hankel_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hk_lds));
+  }
+  auto hankel = [&](int slot, int pass) {
+    if (hk_ng) hipLaunchKernelGGL(rr2_hankel_mfma_kernel, dim3((unsigned)hk_ng, B), dim3(512), hk_lds, st, S, k, h->ud, h->yd, slot, pass, hk_ng);
+    else hipLaunchKernelGGL(rr2_hankel_kernel, dim3(RR2_NG, B), dim3(512), 0, st, S, k, h->ud, h->yd, slot, pass);
+  };
   hipLaunchKernelGGL(rr2_s1_kernel, dim3(B), dim3(RR2_TS), 0, st, S, k, RPs, up, yp);
   hipLaunchKernelGGL(rr2_rows_kernel<0>, dim3(grp(nF + nR, 32), B), dim3(256), 0, st, S, k, RPs, (double*)nullptr, (double*)nullptr, 0);
   hipLaunchKernelGGL(rr2_cols_kernel<0>, dim3(grp(nR, 64), B), dim3(512), 0, st, S, 0);
@@ -930,11 +946,11 @@ static int launch_rr2_solve(ddmpc_handle* h, double* scratch, long long ndbl, co
     // rule of ddmpc_nominal_rr_kernel) is marked and solved again, passes and all, by that kernel behind this sequence
     const int pass = 0;
     hipLaunchKernelGGL(rr2_s4_kernel, dim3(B), dim3(RR2_TS), 0, st, S, pass);
-    hipLaunchKernelGGL(rr2_hankel_kernel, dim3(RR2_NG, B), dim3(512), 0, st, S, k, h->ud, h->yd, (int)V_X, pass);
+    hankel((int)V_X, pass);
     hipLaunchKernelGGL(rr2_rows_kernel<1>, dim3(grp(nR, 32), B), dim3(256), 0, st, S, k, RPs, (double*)nullptr, (double*)nullptr, pass);
     hipLaunchKernelGGL(rr2_cols_kernel<1>, dim3(grp(nF, 64), B), dim3(512), 0, st, S, pass);
     hipLaunchKernelGGL(rr2_s8_kernel, dim3(B), dim3(RR2_TS), 0, st, S, pass);
-    hipLaunchKernelGGL(rr2_hankel_kernel, dim3(RR2_NG, B), dim3(512), 0, st, S, k, h->ud, h->yd, (int)V_VC, pass);
+    hankel((int)V_VC, pass);
     hipLaunchKernelGGL(rr2_rows_kernel<2>, dim3(grp(nR, 32), B), dim3(256), 0, st, S, k, RPs, (double*)nullptr, (double*)nullptr, pass);
     hipLaunchKernelGGL(rr2_s11_kernel, dim3(B), dim3(RR2_TS), 0, st, S, pass);
     hipLaunchKernelGGL(rr2_cols_kernel<2>, dim3(grp(nR, 64), B), dim3(512), 0, st, S, pass);

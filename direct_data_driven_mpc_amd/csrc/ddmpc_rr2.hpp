@@ -28,6 +28,9 @@ namespace ddmpc {
 constexpr int RR2_NB = 64;        // panel width of the lock-step Cholesky (four 16-column tiles)
 constexpr int RR2_SL = 5;         // lags per wave in the Gram kernel
 constexpr int RR2_XCAP = 4096;    // doubles of LDS the Gram kernel stages trajectory chunks in
+constexpr int RR2_TLD = 17;       // doubles per row of a 16 x 16 tile in LDS (16 + 1: a column of a tile spreads over the banks;
+                                  // with 16, 81 % of the panel kernel's LDS cycles were bank conflicts)
+constexpr int RR2_TSZ = 16 * RR2_TLD;
 constexpr int RR2_UT = 3;         // row tiles per wave in the Cholesky update kernel
 
 // D[a][b] += sum_k A[a][k] B[k][b] on v_mfma_f64_16x16x4: lane (l15, l4) passes A[a = l15][k = l4] and B[k = l4][b = l15];
@@ -163,7 +166,7 @@ constexpr int RR2_PLD = 18;         // doubles per staged panel row (16 + 2: the
 template <int RT>
 __global__ __launch_bounds__(256, 2) void rr2_chol_update_kernel(Rr2Chol F, int c0) {
   __shared__ __attribute__((aligned(16))) double pl[3][64 * RR2_PLD];
-  __shared__ __attribute__((aligned(16))) double Mi[10][256];               // tile (t, u), u <= t, of Minv at index t (t + 1) / 2 + u, row-major
+  __shared__ __attribute__((aligned(16))) double Mi[10][RR2_TSZ];           // tile (t, u), u <= t, of Minv at index t (t + 1) / 2 + u, row-major (RR2_TLD)
   const long long b = blockIdx.y;
   const int n16 = F.n_inst ? ((F.n_inst[b * F.n_stride] + 15) & ~15) : F.n16;
   if (c0 + RR2_NB >= n16) return;                                           // (workgroup-uniform) no row below the block
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void rr2_chol_update_kernel(Rr2Chol F, int 
       mv[ti] = m64[(16 * t + rr) * RR2_NB + 16 * u + cc];
     }
 #pragma unroll
-    for (int ti = 0; ti < 10; ++ti) Mi[ti][tid] = mv[ti];
+    for (int ti = 0; ti < 10; ++ti) Mi[ti][rr * RR2_TLD + cc] = mv[ti];
   }
   // operands two live chunks ahead of the MFMAs that consume them (one chunk ahead every chunk waited out a memory round trip:
   // 64 % of the wave-cycles parked, the matrix pipe 26 % busy)
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void rr2_chol_update_kernel(Rr2Chol F, int 
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
-          if (ct >= u) x[ct] = rr2_mfma(Mi[ct * (ct + 1) / 2 + u][pil * 16 + 4 * l4 + e], acc[s][u][e], x[ct]);
+          if (ct >= u) x[ct] = rr2_mfma(Mi[ct * (ct + 1) / 2 + u][pil * RR2_TLD + 4 * l4 + e], acc[s][u][e], x[ct]);
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<d4*>(Ai + 16 * ct) = x[ct];
   }
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void rr2_chol_update_kernel(Rr2Chol F, int 
 // S >= T, -1: none; chosen so that a wave touches few distinct tile rows): P(s,t) = A(s,t) - sum_{j < c0, j live} L(s rows, j)
 // L(t rows, j)', result into the LDS tile (strict upper triangle of a diagonal tile: zero).
 template <int S0, int T0, int S1, int T1, int S2, int T2>
-__device__ __forceinline__ void rr2_diag_update(const double* A, double (*Dt)[256], unsigned long long livemask, int c0, int n4) {
+__device__ __forceinline__ void rr2_diag_update(const double* A, double (*Dt)[RR2_TSZ], unsigned long long livemask, int c0, int n4) {
   constexpr int SS[3] = {S0, S1, S2};
   constexpr int TT[3] = {T0, T1, T2};
   const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
@@ -348,7 +351,7 @@ __device__ __forceinline__ void rr2_diag_update(const double* A, double (*Dt)[25
       // the stored one mirrored (the accumulator is bitwise symmetric: both entries sum the same products in the same order)
       const bool lower = (SS[k] > TT[k]) || (cc <= l15);
       const double av = lower ? Ai[cc] : A[pk_row((size_t)(c0 + 16 * SS[k] + cc)) + c0 + 16 * TT[k] + l15];
-      Dst[l15 * 16 + cc] = av - acc[k][q];
+      Dst[l15 * RR2_TLD + cc] = av - acc[k][q];
     }
   }
 }
@@ -363,7 +366,7 @@ __device__ __forceinline__ void rr2_tile_factor(double* Dg, double* Ms, double* 
   const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
   d4 acc;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) acc[q] = Dg[(l4 + 4 * q) * 16 + l15];
+  for (int q = 0; q < 4; ++q) acc[q] = Dg[(l4 + 4 * q) * RR2_TLD + l15];
   static_for<16>([&](auto cc) __attribute__((always_inline)) {
     constexpr int c = cc();
     constexpr int q = c >> 2, slot = c & 3;
@@ -377,7 +380,7 @@ __device__ __forceinline__ void rr2_tile_factor(double* Dg, double* Ms, double* 
     const double inv = sk ? 0.0 : fma(0.5 * y1, ye1, y1);
     const bool mine = l4 == slot;
     const double u = (mine && l15 >= c) ? acc[q] * inv : 0.0;                // u_i = D[c][i] / sqrt(pivot), i = l15 >= c
-    if (mine) Dg[l15 * 16 + c] = u;                                          // L(i, c); zeros above the diagonal
+    if (mine) Dg[l15 * RR2_TLD + c] = u;                                          // L(i, c); zeros above the diagonal
     acc = rr2_mfma(-u, u, acc);
     if (lane == 0) { skipout[c] = sk ? 1 : 0; Dinv[c] = inv; }
   });
@@ -389,11 +392,11 @@ __device__ __forceinline__ void rr2_tile_factor(double* Dg, double* Ms, double* 
     for (int c = 0; c < 16; ++c) {
       double sacc = (c == lane) ? 1.0 : 0.0;
 #pragma unroll
-      for (int c1 = 0; c1 < c; ++c1) sacc -= Dg[c * 16 + c1] * y[c1];
+      for (int c1 = 0; c1 < c; ++c1) sacc -= Dg[c * RR2_TLD + c1] * y[c1];
       y[c] = sacc * Dinv[c];
     }
 #pragma unroll
-    for (int c = 0; c < 16; ++c) Ms[lane * 16 + c] = y[c];          // Ms[k = lane][m = c] = Mt[c][lane]
+    for (int c = 0; c < 16; ++c) Ms[lane * RR2_TLD + c] = y[c];          // Ms[k = lane][m = c] = Mt[c][lane]
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
@@ -406,8 +409,8 @@ __device__ __forceinline__ void rr2_tile_factor(double* Dg, double* Ms, double* 
 // and for the substitutions of the solve), the pivot flags and the live-chunk bits.  grid = (1, batch), 256 threads: ONE workgroup per instance (the block is factored in place).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rr2_chol_panel_kernel(Rr2Chol F, int c0) {
-  __shared__ __attribute__((aligned(16))) double Dt[10][256];               // tile (s, t), s >= t, at index s (s + 1) / 2 + t, row-major
-  __shared__ __attribute__((aligned(16))) double Ms[4][256];                // Mt of the diagonal tiles, k-major
+  __shared__ __attribute__((aligned(16))) double Dt[10][RR2_TSZ];               // tile (s, t), s >= t, at index s (s + 1) / 2 + t, row-major
+  __shared__ __attribute__((aligned(16))) double Ms[4][RR2_TSZ];                // Mt of the diagonal tiles, k-major
   __shared__ double Dinv[64];
   __shared__ int skipl[64];
   const long long b = blockIdx.y;
@@ -421,13 +424,13 @@ __global__ __launch_bounds__(256) void rr2_chol_panel_kernel(Rr2Chol F, int c0) 
   const int n4 = (nt - tp) < 4 ? (nt - tp) : 4;                             // tiles across the panel
   const double tol = F.tol_rel * rr2_bits_to_double(F.dmax[b * F.d_stride]);
   // ---- the diagonal block, updated, into LDS (strict upper triangle of the diagonal tiles zero, absent tiles zero)
-  for (int e = tid; e < 10 * 256; e += nthr) Dt[e >> 8][e & 255] = 0.0;
+  for (int e = tid; e < 10 * RR2_TSZ; e += nthr) Dt[e / RR2_TSZ][e % RR2_TSZ] = 0.0;
   __syncthreads();
   if (wave == 0) rr2_diag_update<0, 0, 1, 0, 1, 1>(A, Dt, F.live[b * F.l_stride], c0, n4);
   else if (wave == 1) rr2_diag_update<2, 0, 2, 1, 2, 2>(A, Dt, F.live[b * F.l_stride], c0, n4);
   else if (wave == 2) rr2_diag_update<3, 0, 3, 1, -1, -1>(A, Dt, F.live[b * F.l_stride], c0, n4);
   else rr2_diag_update<3, 2, 3, 3, -1, -1>(A, Dt, F.live[b * F.l_stride], c0, n4);
-  for (int e = tid; e < 4 * 256; e += nthr) Ms[e >> 8][e & 255] = 0.0;
+  for (int e = tid; e < 4 * RR2_TSZ; e += nthr) Ms[e / RR2_TSZ][e % RR2_TSZ] = 0.0;
   __syncthreads();
   for (int t = 0; t < n4; ++t) {
     if (wave == 0) rr2_tile_factor(Dt[t * (t + 1) / 2 + t], Ms[t], Dinv + 16 * t, tol, skipl + 16 * t);
@@ -437,12 +440,12 @@ __global__ __launch_bounds__(256) void rr2_chol_panel_kernel(Rr2Chol F, int c0) 
       double* Pst = Dt[(t + wave) * (t + wave + 1) / 2 + t];
       double pv[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pv[q] = Pst[l15 * 16 + l4 + 4 * q];
+      for (int q = 0; q < 4; ++q) pv[q] = Pst[l15 * RR2_TLD + l4 + 4 * q];
       d4 x = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) x = rr2_mfma(Ms[t][(l4 + 4 * q) * 16 + l15], pv[q], x);
+      for (int q = 0; q < 4; ++q) x = rr2_mfma(Ms[t][(l4 + 4 * q) * RR2_TLD + l15], pv[q], x);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) Pst[l15 * 16 + l4 + 4 * q] = x[q];
+      for (int q = 0; q < 4; ++q) Pst[l15 * RR2_TLD + l4 + 4 * q] = x[q];
     }
     __syncthreads();
     // trailing tiles of the block: P(s,u) -= X(s,t) X(u,t)',  t < u <= s
@@ -455,10 +458,10 @@ __global__ __launch_bounds__(256) void rr2_chol_panel_kernel(Rr2Chol F, int c0) 
           const double* Xu = Dt[u * (u + 1) / 2 + t];
           d4 acc = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc = rr2_mfma(Xu[l15 * 16 + l4 + 4 * e], Xs[l15 * 16 + l4 + 4 * e], acc);
+          for (int e = 0; e < 4; ++e) acc = rr2_mfma(Xu[l15 * RR2_TLD + l4 + 4 * e], Xs[l15 * RR2_TLD + l4 + 4 * e], acc);
           double* Psu = Dt[s * (s + 1) / 2 + u];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) Psu[l15 * 16 + l4 + 4 * q] -= acc[q];
+          for (int q = 0; q < 4; ++q) Psu[l15 * RR2_TLD + l4 + 4 * q] -= acc[q];
         }
     }
     __syncthreads();
@@ -468,10 +471,10 @@ __global__ __launch_bounds__(256) void rr2_chol_panel_kernel(Rr2Chol F, int c0) 
   // With it the rows below the block are ONE multiplication X = P Minv' of independent MFMA chains (part 2) instead of a
   // forward substitution through four dependent tile solves, and a substitution with the finished factor advances 64 rows
   // per step (ddmpc_rr2_solve.hpp).  The Dt tiles of the diagonal (their factor is no longer needed in LDS form) are reused.
-  __shared__ __attribute__((aligned(16))) double Mi[10][256];               // tile (s, t) row-major
+  __shared__ __attribute__((aligned(16))) double Mi[10][RR2_TSZ];               // tile (s, t) row-major
   for (int e = tid; e < 4 * 256; e += nthr) {
     const int t = e >> 8, a = (e >> 4) & 15, bb = e & 15;
-    Mi[t * (t + 1) / 2 + t][a * 16 + bb] = Ms[t][bb * 16 + a];
+    Mi[t * (t + 1) / 2 + t][a * RR2_TLD + bb] = Ms[t][bb * RR2_TLD + a];
   }
   __syncthreads();
   for (int dist = 1; dist < n4; ++dist) {
@@ -482,14 +485,14 @@ __global__ __launch_bounds__(256) void rr2_chol_panel_kernel(Rr2Chol F, int c0) 
         const double* Lsu = Dt[s * (s + 1) / 2 + u];
         const double* Mut = Mi[u * (u + 1) / 2 + t];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w = rr2_mfma(Lsu[l15 * 16 + l4 + 4 * e], Mut[(l4 + 4 * e) * 16 + l15], w);
+        for (int e = 0; e < 4; ++e) w = rr2_mfma(Lsu[l15 * RR2_TLD + l4 + 4 * e], Mut[(l4 + 4 * e) * RR2_TLD + l15], w);
       }
       d4 x = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) x = rr2_mfma(Ms[s][(l4 + 4 * e) * 16 + l15], w[e], x);
+      for (int e = 0; e < 4; ++e) x = rr2_mfma(Ms[s][(l4 + 4 * e) * RR2_TLD + l15], w[e], x);
       double* Mst = Mi[s * (s + 1) / 2 + t];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) Mst[(l4 + 4 * q) * 16 + l15] = -x[q];
+      for (int q = 0; q < 4; ++q) Mst[(l4 + 4 * q) * RR2_TLD + l15] = -x[q];
     }
     __syncthreads();
   }
@@ -501,13 +504,13 @@ __global__ __launch_bounds__(256) void rr2_chol_panel_kernel(Rr2Chol F, int c0) 
     const int t = ti - s * (s + 1) / 2;
     if (s < n4) {
       const int i = c0 + 16 * s + rr, j = c0 + 16 * t + cc;
-      if (j <= i) A[pk_row((size_t)i) + j] = Dt[ti][rr * 16 + cc];
+      if (j <= i) A[pk_row((size_t)i) + j] = Dt[ti][rr * RR2_TLD + cc];
     }
   }
   double* m64 = F.m64 + b * F.m64_stride + (size_t)(c0 / RR2_NB) * (RR2_NB * RR2_NB);
   for (int e = tid; e < RR2_NB * RR2_NB; e += nthr) {                       // 64 x 64, row-major, zero above the diagonal tiles
     const int i = e >> 6, j = e & 63, s = i >> 4, t = j >> 4;
-    m64[e] = (t <= s && s < n4) ? Mi[s * (s + 1) / 2 + t][(i & 15) * 16 + (j & 15)] : 0.0;
+    m64[e] = (t <= s && s < n4) ? Mi[s * (s + 1) / 2 + t][(i & 15) * RR2_TLD + (j & 15)] : 0.0;
   }
   if (tid < 16 * n4 && c0 + tid < F.nflag) F.skip[b * F.s_stride + c0 + tid] = skipl[tid];
   if (tid == 0) {

@@ -22,7 +22,7 @@ namespace ddmpc {
 
 constexpr int RR2_TS = 512;         // threads of the one-workgroup-per-instance kernels
 constexpr int RR2_VMAX = 1088;      // LDS vector length: r <= 1024 rounded up to 64, + one block
-constexpr int RR2_NG = 6;           // workgroups per instance in the Hankel product
+constexpr int RR2_NG = 8;           // workgroups per instance in the Hankel product (at most)
 
 // per-instance vectors in the global workspace (position order unless noted), RR2 vector length VL = r rounded up to 64
 enum : int { V_FV = 0, V_W1, V_Z0, V_VV, V_W2, V_WK, V_X /* component order */, V_RZ, V_RBR, V_RA, V_VC /* component order */,
@@ -386,6 +386,164 @@ __global__ __launch_bounds__(512) void rr2_hankel_kernel(Rr2Solve S, KParams P, 
   __syncthreads();
   hankel_normal_times(Pg, ud, yd, xs, zs, pan);
   for (int k = tid; k < S.r; k += nthr) zp[k] = zs[k];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same product on the matrix pipe (channel counts up to 16).  Both halves of z = H (H' x) are correlations along the time
+// axis, and a correlation with a vector becomes a matrix product once the vector is expanded into 16 shifted copies:
+//   alpha_{16 a + b} = sum_{s, ch} X[16 a + s][ch] xs_b[s][ch],     xs_b[s] = x[s - b]         (16 a's x 16 b's per tile,
+//                                                                                               contraction over (s, ch))
+//   z[16 g + q][ch]  = sum_t X[t + 16 g][ch] as_q[t],               as_q[t] = alpha[t - q]     (rows (g, ch) x 16 q's,
+//                                                                                               contraction over t)
+// 2.4 M multiply-adds per call become ~700 MFMAs per workgroup (the vector-pipe version above: 225 us per call at cfg 5).
+// The trajectory slice is staged in LDS with the time steps grouped by residue mod 16 -- row t at ((t % 16) NBK + t / 16) RS,
+// RS = nch4 + 1 -- so that the 16 lanes of an operand read (consecutive a's, i.e. time steps 16 apart) are consecutive rows of
+// an odd-ish stride: conflict-free.  The contraction range is split over the 8 waves; partial tiles meet in LDS.
+// grid = (ng, batch), 512 threads, dynamic LDS (host: rr2_hankel_mfma_lds).
+// ---------------------------------------------------------------------------------------------------------------
+struct Rr2HankelGeom { int cg, NBK, RS, nch4, na, ntA, ntZ, ngz; };
+__host__ __device__ __forceinline__ Rr2HankelGeom rr2_hankel_geom(int c, int Ln, int nch, int ng) {
+  Rr2HankelGeom g;
+  g.cg = (((c + ng - 1) / ng) + 15) & ~15;               // columns per workgroup, a multiple of 16
+  g.nch4 = (nch + 3) & ~3;
+  g.RS = g.nch4 + 1;
+  g.NBK = (g.cg + Ln + 15 + 15) / 16 + 1;                 // blocks of 16 time steps staged (windows reach row cg + Ln + 14)
+  g.na = g.cg / 16;
+  g.ntA = (g.na + 15) / 16;
+  g.ngz = (Ln + 15) / 16;
+  g.ntZ = (g.ngz * nch + 15) / 16;
+  return g;
+}
+__host__ __device__ __forceinline__ size_t rr2_hankel_mfma_lds(const Rr2HankelGeom& g, int Ln) {   // doubles
+  return (size_t)16 * g.NBK * g.RS + (size_t)(Ln + 30) * g.RS + (size_t)(g.cg + 48) + 8 * 256;
+}
+__global__ __launch_bounds__(512) void rr2_hankel_mfma_kernel(Rr2Solve S, KParams P, const double* __restrict__ u_d,
+                                                             const double* __restrict__ y_d, int slot, int pass, int ng) {
+  extern __shared__ __attribute__((aligned(16))) double hk_lds[];
+  const long long b = blockIdx.y;
+  if (pass > 0 && S.si[2 * b] == 0) return;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nch = P.nch, m = P.m, p = P.p, Ln = P.Ln, r = P.r;
+  const Rr2HankelGeom G = rr2_hankel_geom(P.c, Ln, nch, ng);
+  const int g = blockIdx.x;
+  const int clo = g * G.cg;
+  double* zp = S.ZP + (b * RR2_NG + g) * (long long)S.VL;
+  if (clo >= P.c) { for (int k = tid; k < r; k += nthr) zp[k] = 0.0; return; }
+  const int cgw = (P.c - clo) < G.cg ? (P.c - clo) : G.cg;                 // columns of this workgroup
+  double* xT = hk_lds;                                                       // [16][NBK][RS]
+  double* xp = xT + 16 * G.NBK * G.RS;                                       // x, rows -15 .. Ln + 14, row stride RS
+  double* ap = xp + (Ln + 30) * G.RS;                                        // alpha, 15 zeros in front, >= 33 behind
+  double* part = ap + G.cg + 48;                                             // 8 x 256
+  const double* ud = u_d + b * (long long)P.N * m;
+  const double* yd = y_d + b * (long long)P.N * p;
+  const double* xin = S.V + b * S.vstride + (long long)slot * S.VL;
+  // ---- staging: trajectory rows clo .. clo + 16 NBK (zeros past the data and in the padding channels), x, zeros of alpha
+  const int nrows = 16 * G.NBK;
+  {
+    // branch-free, six loads per thread in flight (a load per loop trip waited out one memory round trip per trip: with eight
+    // rounds of workgroups per launch that was most of the kernel); the padding channels are zeroed separately
+    constexpr int SR = 6;
+    const int total = nrows * nch;
+    const long long dyu = reinterpret_cast<const char*>(yd) - reinterpret_cast<const char*>(ud);   // (one flat address space)
+    // (row, channel) of this thread's elements advance by (nthr / nch, nthr % nch) per element: no division in the loop
+    const int dt = nthr / nch, dc = nthr - dt * nch;
+    int t = tid / nch, ch = tid - t * nch;
+    for (int base = 0; base < total; base += SR * nthr) {
+      double v[SR], keep[SR];
+      int dst[SR];
+#pragma unroll
+      for (int e = 0; e < SR; ++e) {
+        const bool in = base + tid + e * nthr < total;
+        const int tt = in ? t : nrows - 1, cc = in ? ch : 0;
+        const int tg = clo + tt, tc = tg < P.N ? tg : P.N - 1;
+        keep[e] = tg < P.N ? 1.0 : 0.0;
+        dst[e] = in ? ((tt & 15) * G.NBK + (tt >> 4)) * G.RS + cc : -1;
+        const long long ou = ((long long)tc * m + cc) * 8, oy = dyu + ((long long)tc * p + (cc - m)) * 8;
+        v[e] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ud) + ((cc < m) ? ou : oy));
+        t += dt; ch += dc;
+        if (ch >= nch) { ch -= nch; ++t; }
+      }
+      __builtin_amdgcn_sched_barrier(0);                 // all SR loads are in flight before the first is touched
+#pragma unroll
+      for (int e = 0; e < SR; ++e)
+        if (dst[e] >= 0) xT[dst[e]] = v[e] * keep[e];
+    }
+    for (int e = tid; e < nrows * (G.RS - nch); e += nthr) {
+      const int t = e / (G.RS - nch), ch = nch + (e - t * (G.RS - nch));
+      xT[((t & 15) * G.NBK + (t >> 4)) * G.RS + ch] = 0.0;
+    }
+  }
+  for (int e = tid; e < (Ln + 30) * G.RS; e += nthr) {
+    const int k = e / G.RS - 15, ch = e - (k + 15) * G.RS;
+    xp[e] = (k >= 0 && k < Ln && ch < nch) ? xin[k * nch + ch] : 0.0;
+  }
+  for (int e = tid; e < G.cg + 48; e += nthr) ap[e] = 0.0;
+  __syncthreads();
+  // ---- alpha: wave = (tile of 16 a's, part of the contraction range)
+  {
+    const int kparts = 8 / G.ntA < 1 ? 1 : 8 / G.ntA;
+    const int ta = wave % G.ntA, kp = wave / G.ntA;
+    const int c4n = G.nch4 >> 2;
+    const int nS = Ln + 15;                                                  // s = 0 .. Ln + 14, split over the parts
+    const int per = (nS + kparts - 1) / kparts;
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+    if (kp < kparts) {
+      const int a = (16 * ta + l15) < (G.NBK - 4) ? (16 * ta + l15) : (G.NBK - 4);   // (a >= na: later columns -- not stored; kept inside the staged rows)
+      const int s1 = (kp + 1) * per < nS ? (kp + 1) * per : nS;
+      for (int sI = kp * per; sI < s1; ++sI) {
+        const double* pa = xT + ((sI & 15) * G.NBK + (a + (sI >> 4))) * G.RS + l4;
+        const double* pb = xp + (sI - l15 + 15) * G.RS + l4;
+        for (int c4 = 0; c4 < c4n; ++c4) acc = rr2_mfma(pa[4 * c4], pb[4 * c4], acc);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part[wave * 256 + (l4 + 4 * q) * 16 + l15] = (kp < kparts) ? acc[q] : 0.0;
+    __syncthreads();
+    for (int i = tid; i < cgw; i += nthr) {
+      const int a = i >> 4, bb = i & 15, t2 = a >> 4, la = a & 15;
+      double sacc = 0.0;
+      for (int k2 = 0; k2 < kparts; ++k2) sacc += part[(t2 + G.ntA * k2) * 256 + la * 16 + bb];
+      ap[15 + i] = sacc;
+    }
+    __syncthreads();
+  }
+  // ---- z: wave = (tile of 16 rows (g, ch), part of the column range)
+  {
+    const int kparts = 8 / G.ntZ < 1 ? 1 : 8 / G.ntZ;
+    const int tz = wave % G.ntZ, kp = wave / G.ntZ;
+    const int kblocks = (cgw + 15 + 15) >> 4;                                // t = 0 .. cgw + 14 in blocks of 16 (four MFMAs each)
+    const int per = (kblocks + kparts - 1) / kparts;
+    const int rho = 16 * tz + l15;
+    const bool rok = rho < G.ngz * nch;
+    const int gz = rok ? rho / nch : 0, ch = rok ? rho - gz * nch : 0;
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+    if (kp < kparts && wave < G.ntZ * kparts) {
+      // time step t + 16 gz with t = 16 kb + 4 j + l4 sits in residue block 4 j + l4, row kb + gz: four fixed bases, one stride
+      const double* pj[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pj[j] = xT + ((4 * j + l4) * G.NBK + gz) * G.RS + ch;
+      const double sel = rok ? 1.0 : 0.0;
+      const int k1 = (kp + 1) * per < kblocks ? (kp + 1) * per : kblocks;
+      const double* pa = ap + 15 + l4 - l15 + 16 * kp * per;
+      for (int kb = kp * per; kb < k1; ++kb, pa += 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = rr2_mfma(sel * pj[j][kb * G.RS], pa[4 * j], acc);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part[wave * 256 + (l4 + 4 * q) * 16 + l15] = acc[q];
+    __syncthreads();
+    for (int e = tid; e < r; e += nthr) {                                    // component e = k nch + ch, k = 16 g + q
+      const int k = e / nch, c2 = e - k * nch;
+      const int g2 = k >> 4, q2 = k & 15;
+      const int rr = g2 * nch + c2, t2 = rr >> 4, lr = rr & 15;
+      double sacc = 0.0;
+      for (int k2 = 0; k2 < kparts; ++k2) sacc += part[(t2 + G.ntZ * k2) * 256 + lr * 16 + q2];
+      zp[e] = sacc;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
