@@ -877,7 +877,10 @@ static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, 
     FT.n_inst = meta + 2 * rv + 1; FT.n_stride = mstride;
     FT.dmax = dd + 1; FT.d_stride = 4; FT.tol_rel = 1e-14; FT.skip = meta + rv; FT.s_stride = mstride; FT.nflag = nR;
     FT.live = dd + 3; FT.l_stride = 4; FT.m64 = (double*)h->d_rr2mt.p + m64G; FT.m64_stride = m64G + m64T;
-    cholesky(FT, nR16);
+    if (nR16 <= 384)            // a few panels: one launch, one workgroup per instance walks them (rr2_chol_small_kernel)
+      hipLaunchKernelGGL(rr2_chol_small_kernel<RR2_UT>, dim3((unsigned)B), dim3(256), 0, h->stream, FT);
+    else
+      cholesky(FT, nR16);
   }
   HIP_TRY(hipGetLastError());
   return DDMPC_OK;

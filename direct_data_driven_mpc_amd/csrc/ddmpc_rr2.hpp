@@ -163,20 +163,19 @@ __global__ __launch_bounds__(256, 4) void rr2_gram_kernel(KParams P, const doubl
 // with a store of P, then a solve that read P back -- the panel went through HBM four times per step instead of twice.)
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int RR2_PLD = 18;         // doubles per staged panel row (16 + 2: the 16 rows of a tile land in different banks)
+// `group`: which 4 RT row tiles below the block this workgroup takes; `mi_ready`: Minv of the block is already in Mi (the fused
+// kernel below), else it is read from F.m64.  pl: 3 x 64 x RR2_PLD doubles, Mi: 10 tiles of RR2_TSZ (LDS).  All 256 threads.
 template <int RT>
-__global__ __launch_bounds__(256, 2) void rr2_chol_update_kernel(Rr2Chol F, int c0) {
-  __shared__ __attribute__((aligned(16))) double pl[3][64 * RR2_PLD];
-  __shared__ __attribute__((aligned(16))) double Mi[10][RR2_TSZ];           // tile (t, u), u <= t, of Minv at index t (t + 1) / 2 + u, row-major (RR2_TLD)
-  const long long b = blockIdx.y;
-  const int n16 = F.n_inst ? ((F.n_inst[b * F.n_stride] + 15) & ~15) : F.n16;
+__device__ __forceinline__ void rr2_update_body(const Rr2Chol& F, long long b, int c0, int n16, int group, bool mi_ready,
+                                                double (*pl)[64 * RR2_PLD], double (*Mi)[RR2_TSZ]) {
   if (c0 + RR2_NB >= n16) return;                                           // (workgroup-uniform) no row below the block
   double* A = F.ws + b * F.stride + F.off;
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tp = c0 >> 4, nt = n16 >> 4;
   const int tb = tp + 4;                                                    // first row tile below the block
-  if (tb + (int)blockIdx.x * 4 * RT >= nt) return;                          // (workgroup-uniform: no row tile left for this group)
-  const int t0 = tb + ((int)blockIdx.x * 4 + wave) * RT;                    // first row tile of this wave (wave-uniform)
+  if (tb + group * 4 * RT >= nt) return;                                    // (workgroup-uniform: no row tile left for this group)
+  const int t0 = tb + (group * 4 + wave) * RT;                              // first row tile of this wave (wave-uniform)
   unsigned long long live = F.live[b * F.l_stride] & ((1ull << tp) - 1ull);   // chunks in front of the panel (tp <= 63)
   // Column order inside a 16-column tile of the accumulators: lane l15 feeds panel row pi(l15) = 4 (l15 % 4) + l15 / 4 as the
   // A operand, so that register q of lane (l4, l15) holds panel column 4 l4 + q (not l4 + 4 q) of the tile: the FOUR registers
@@ -200,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void rr2_chol_update_kernel(Rr2Chol F, int 
   for (int s = 0; s < RT; ++s)
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[s][ct] = d4{0.0, 0.0, 0.0, 0.0};
-  {   // Minv of the block (written by the panel kernel of this step): ten 8-byte loads per thread
+  if (!mi_ready) {   // Minv of the block (written by the panel kernel of this step): ten 8-byte loads per thread
     const double* m64 = F.m64 + b * F.m64_stride + (size_t)(c0 / RR2_NB) * (RR2_NB * RR2_NB);
     double mv[10];
     const int rr = (tid >> 4) & 15, cc = tid & 15;
@@ -284,6 +283,15 @@ __global__ __launch_bounds__(256, 2) void rr2_chol_update_kernel(Rr2Chol F, int 
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<d4*>(Ai + 16 * ct) = x[ct];
   }
+}
+
+template <int RT>
+__global__ __launch_bounds__(256, 2) void rr2_chol_update_kernel(Rr2Chol F, int c0) {
+  __shared__ __attribute__((aligned(16))) double pl[3][64 * RR2_PLD];
+  __shared__ __attribute__((aligned(16))) double Mi[10][RR2_TSZ];           // tile (t, u), u <= t, of Minv at index t (t + 1) / 2 + u, row-major (RR2_TLD)
+  const long long b = blockIdx.y;
+  const int n16 = F.n_inst ? ((F.n_inst[b * F.n_stride] + 15) & ~15) : F.n16;
+  rr2_update_body<RT>(F, b, c0, n16, (int)blockIdx.x, false, pl, Mi);
 }
 
 // Left-looking update of up to three tiles of the diagonal block by one wave (the tiles (S0,T0), (S1,T1), (S2,T2) of the block,
@@ -408,13 +416,8 @@ __device__ __forceinline__ void rr2_tile_factor(double* Dg, double* Ms, double* 
 // trailing tiles of the block by MFMA.  Stores the block's factor in place, the inverse Minv of the block in `m64` (for part 2
 // and for the substitutions of the solve), the pivot flags and the live-chunk bits.  grid = (1, batch), 256 threads: ONE workgroup per instance (the block is factored in place).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rr2_chol_panel_kernel(Rr2Chol F, int c0) {
-  __shared__ __attribute__((aligned(16))) double Dt[10][RR2_TSZ];               // tile (s, t), s >= t, at index s (s + 1) / 2 + t, row-major
-  __shared__ __attribute__((aligned(16))) double Ms[4][RR2_TSZ];                // Mt of the diagonal tiles, k-major
-  __shared__ double Dinv[64];
-  __shared__ int skipl[64];
-  const long long b = blockIdx.y;
-  const int n16 = F.n_inst ? ((F.n_inst[b * F.n_stride] + 15) & ~15) : F.n16;
+__device__ __forceinline__ void rr2_panel_body(const Rr2Chol& F, long long b, int c0, int n16, double (*Dt)[RR2_TSZ],
+                                               double (*Ms)[RR2_TSZ], double (*Mi)[RR2_TSZ], double* Dinv, int* skipl) {
   if (c0 >= n16) return;
   double* A = F.ws + b * F.stride + F.off;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -471,7 +474,6 @@ __global__ __launch_bounds__(256) void rr2_chol_panel_kernel(Rr2Chol F, int c0) 
   // With it the rows below the block are ONE multiplication X = P Minv' of independent MFMA chains (part 2) instead of a
   // forward substitution through four dependent tile solves, and a substitution with the finished factor advances 64 rows
   // per step (ddmpc_rr2_solve.hpp).  The Dt tiles of the diagonal (their factor is no longer needed in LDS form) are reused.
-  __shared__ __attribute__((aligned(16))) double Mi[10][RR2_TSZ];               // tile (s, t) row-major
   for (int e = tid; e < 4 * 256; e += nthr) {
     const int t = e >> 8, a = (e >> 4) & 15, bb = e & 15;
     Mi[t * (t + 1) / 2 + t][a * RR2_TLD + bb] = Ms[t][bb * RR2_TLD + a];
@@ -521,6 +523,42 @@ __global__ __launch_bounds__(256) void rr2_chol_panel_kernel(Rr2Chol F, int c0) 
       if (any) bits |= 1ull << (tp + t);
     }
     F.live[b * F.l_stride] |= bits;
+  }
+}
+
+__global__ __launch_bounds__(256) void rr2_chol_panel_kernel(Rr2Chol F, int c0) {
+  __shared__ __attribute__((aligned(16))) double Dt[10][RR2_TSZ];           // tile (s, t), s >= t, at index s (s + 1) / 2 + t, row-major
+  __shared__ __attribute__((aligned(16))) double Ms[4][RR2_TSZ];            // Mt of the diagonal tiles, k-major
+  __shared__ __attribute__((aligned(16))) double Mi[10][RR2_TSZ];           // Minv of the block, tile (s, t) row-major
+  __shared__ double Dinv[64];
+  __shared__ int skipl[64];
+  const long long b = blockIdx.y;
+  const int n16 = F.n_inst ? ((F.n_inst[b * F.n_stride] + 15) & ~15) : F.n16;
+  rr2_panel_body(F, b, c0, n16, Dt, Ms, Mi, Dinv, skipl);
+}
+
+// The whole factorisation of a SMALL matrix (the reduced normal matrix T: a few panels) in one launch: one workgroup per
+// instance walks the panels -- panel step, then the rows below it, group by group -- with workgroup barriers where the
+// lock-step pipeline has kernel boundaries.  (As separate launches the 168-row T of cfg 5 cost 270 us: three panel launches of
+// ~50 us each, two update launches, six launches that found nothing to do.)  The staging buffer of the update aliases the
+// panel step's tiles.  grid = batch, 256 threads.
+template <int RT>
+__global__ __launch_bounds__(256, 2) void rr2_chol_small_kernel(Rr2Chol F) {
+  __shared__ __attribute__((aligned(16))) double DtMs[14][RR2_TSZ];         // panel step: Dt (10 tiles) | Ms (4 tiles); update: the staging ring
+  __shared__ __attribute__((aligned(16))) double Mi[10][RR2_TSZ];
+  __shared__ double Dinv[64];
+  __shared__ int skipl[64];
+  static_assert(sizeof(double) * 14 * RR2_TSZ >= sizeof(double) * 3 * 64 * RR2_PLD, "the staging ring fits into the panel step's tiles");
+  const long long b = blockIdx.x;
+  const int n16 = F.n_inst ? ((F.n_inst[b * F.n_stride] + 15) & ~15) : F.n16;
+  for (int c0 = 0; c0 < n16; c0 += RR2_NB) {
+    rr2_panel_body(F, b, c0, n16, DtMs, DtMs + 10, Mi, Dinv, skipl);
+    __syncthreads();                                                        // the block's factor, Minv (LDS) and the live bits are in place
+    const int nbelow = (n16 >> 4) - (c0 >> 4) - 4;
+    for (int g = 0; g * 4 * RT < nbelow; ++g) {
+      rr2_update_body<RT>(F, b, c0, n16, g, true, reinterpret_cast<double (*)[64 * RR2_PLD]>(&DtMs[0][0]), Mi);
+      __syncthreads();
+    }
   }
 }
 
