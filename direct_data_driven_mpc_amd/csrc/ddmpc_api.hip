@@ -147,6 +147,10 @@ struct ddmpc_handle {
   DevBuf d_zws, d_resc, d_xws;             // NOMINAL rescue kernel: z per component, a per-instance "rescued" flag and x = L^-T w (ddmpc_get_solution)
   DevBuf d_rrmeta;                         // ... pivot pattern + live column counts of the factors it leaves in d_rr (2 rv + 2 ints per instance)
   DevBuf d_rr2v, d_rr2zp, d_rr2sc, d_wz;   // ... vectors, Hankel partial sums and scalars of the solve (ddmpc_rr2_solve.hpp); weights / targets
+  DevBuf d_gz, d_gres, d_zvirt;            // ... the affine law z(past) and the residuals of the dependent fixed rows (DDMPC_OPT_LARGE_AFFINE_LAW)
+  int large_affine = 0;                    // DDMPC_OPT_LARGE_AFFINE_LAW
+  bool large_gain_ready = false;           // ... the law of the current data set has been formed (ddmpc_prepare)
+  bool gain_step_last = false;             // ... the last solve was a step on the law (no w to form alpha from)
   bool rr2_x_pending = false;              // ... x = L^-T w of the last solve has not been formed yet (ddmpc_get_solution does it on demand)
   DevBuf d_rr2mt;                          // ... Minv of every 64 x 64 diagonal block of the two factors (ddmpc_rr2.hpp)
   DevBuf d_perm, d_rr2d;                   // phase kernels (ddmpc_rr2.hpp): fixed-first component order [perm | iperm]; per instance
@@ -557,7 +561,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_perm, &h->d_rr2d, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_perm, &h->d_rr2d, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz, &h->d_gz, &h->d_gres, &h->d_zvirt};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -619,6 +623,7 @@ int ddmpc_set_data(ddmpc_handle* h, const double* u_d, const double* y_d, int me
   h->have_data = true;
   h->solved = false;
   h->prepared = false;
+  h->large_gain_ready = false;
   return DDMPC_OK;
 }
 
@@ -887,11 +892,11 @@ static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, 
 }
 
 // The solve on those factors (what a control step repeats, controller.py:389-407), as phase kernels (ddmpc_rr2_solve.hpp).
-static int rr2_solve_desc(ddmpc_handle* h, double* scratch, long long ndbl, Rr2Solve* out) {
+static int rr2_solve_desc(ddmpc_handle* h, double* scratch, long long ndbl, Rr2Solve* out, size_t vbatch = 0) {
   const KParams& k = h->kp;
   const int r = k.r, n16 = (r + 15) & ~15, nR = h->n_free, nF = h->nF, nR16 = (nR + 15) & ~15;
   const int rv = (r + 1) & ~1, VL = (r + 63) & ~63;
-  const size_t B = (size_t)h->batch;
+  const size_t B = vbatch ? vbatch : (size_t)h->batch;           // (the gain build runs the solve on a virtual batch)
   const long long m64G = (long long)((n16 + RR2_NB - 1) / RR2_NB) * RR2_NB * RR2_NB;
   const long long m64T = (long long)((nR16 + RR2_NB - 1) / RR2_NB) * RR2_NB * RR2_NB;
   int rc;
@@ -911,17 +916,14 @@ static int rr2_solve_desc(ddmpc_handle* h, double* scratch, long long ndbl, Rr2S
   S.resid = (unsigned long long*)(S.sc + 4 * B);
   S.si = (int*)(S.resid + B);
   S.r = r; S.nF = nF; S.nR = nR;
+  S.fdiv = 1; S.unit = 0; S.ubase = 0;
   *out = S;
   return DDMPC_OK;
 }
 
-static int launch_rr2_solve(ddmpc_handle* h, double* scratch, long long ndbl, const double* up, const double* yp, double* uo,
-                            double* cost, int32_t* status, int32_t* iters, double feas_tol) {
-  Rr2Solve S;
-  int rc = rr2_solve_desc(h, scratch, ndbl, &S);
-  if (rc) return rc;
+static int rr2_solve_sequence(ddmpc_handle* h, const Rr2Solve& S, unsigned B, const double* up, const double* yp, double* uo,
+                              double* cost, int32_t* status, int32_t* iters, double* zws, int* resc, double feas_tol) {
   const KParams& k = h->kp;
-  const unsigned B = (unsigned)h->batch;
   const int RPs = 16 * h->kc.NT, nF = S.nF, nR = S.nR;
   auto grp = [](int n, int per) { return (unsigned)((n + per - 1) / per < 1 ? 1 : (n + per - 1) / per); };
   hipStream_t st = h->stream;
@@ -959,11 +961,51 @@ static int launch_rr2_solve(ddmpc_handle* h, double* scratch, long long ndbl, co
     hipLaunchKernelGGL(rr2_cols_kernel<2>, dim3(grp(nR, 64), B), dim3(512), 0, st, S, pass);
     hipLaunchKernelGGL(rr2_s13_kernel, dim3(B), dim3(RR2_TS), 0, st, S, pass, k.refine_max);
   }
-  hipLaunchKernelGGL(rr2_rows_kernel<3>, dim3(grp(nR, 32), B), dim3(256), 0, st, S, k, RPs, uo, (double*)h->d_zws.p, 0);
-  hipLaunchKernelGGL(rr2_s15_kernel, dim3(B), dim3(RR2_TS), 0, st, S, k, RPs, feas_tol, uo, cost, (int*)status, (int*)iters,
-                     (double*)h->d_zws.p, (int*)h->d_resc.p);
+  hipLaunchKernelGGL(rr2_rows_kernel<3>, dim3(grp(nR, 32), B), dim3(256), 0, st, S, k, RPs, uo, zws, 0);
+  hipLaunchKernelGGL(rr2_s15_kernel, dim3(B), dim3(RR2_TS), 0, st, S, k, RPs, feas_tol, uo, cost, (int*)status, (int*)iters, zws, resc);
   HIP_TRY(hipGetLastError());
+  return DDMPC_OK;
+}
+
+static int launch_rr2_solve(ddmpc_handle* h, double* scratch, long long ndbl, const double* up, const double* yp, double* uo,
+                            double* cost, int32_t* status, int32_t* iters, double feas_tol) {
+  Rr2Solve S;
+  int rc = rr2_solve_desc(h, scratch, ndbl, &S);
+  if (rc) return rc;
+  if ((rc = rr2_solve_sequence(h, S, (unsigned)h->batch, up, yp, uo, cost, status, iters, (double*)h->d_zws.p, (int*)h->d_resc.p, feas_tol)))
+    return rc;
   h->rr2_x_pending = true;
+  return DDMPC_OK;
+}
+
+// DDMPC_OPT_LARGE_AFFINE_LAW: the affine law z(past) of every instance (ddmpc_rr2_solve.hpp), formed by ddmpc_prepare from solves at
+// the zero window and the n(m+p) unit windows on a virtual batch, RR2_GAIN_CHUNK windows at a time.
+constexpr int RR2_GAIN_CHUNK = 16;
+static int launch_rr2_gain_build(ddmpc_handle* h, double* scratch, long long ndbl) {
+  const KParams& k = h->kp;
+  const int nf = h->prm.n * k.nch, nrhs = nf + 1, nFp = (h->nF + 63) & ~63;
+  if (nf > WARM_MAX_NF) return fail(DDMPC_ERR_UNSUPPORTED, "the affine law supports n*(m+p) <= %d", WARM_MAX_NF);
+  const size_t B = (size_t)h->batch, Bv = B * RR2_GAIN_CHUNK;
+  if (Bv > 65535) return fail(DDMPC_ERR_UNSUPPORTED, "batch too large for the affine law at this size (%zu instances x %d windows per launch)", B, RR2_GAIN_CHUNK);
+  int rc;
+  if ((rc = h->d_gz.ensure(B * (size_t)nrhs * k.r * sizeof(double))) || (rc = h->d_gres.ensure(B * (size_t)nrhs * nFp * sizeof(double))) ||
+      (rc = h->d_zvirt.ensure(Bv * (size_t)k.rE * sizeof(double))))
+    return rc;
+  Rr2Solve S;
+  if ((rc = rr2_solve_desc(h, scratch, ndbl, &S, Bv))) return rc;
+  S.fdiv = RR2_GAIN_CHUNK; S.unit = 1;
+  for (int j0 = 0; j0 < nrhs; j0 += RR2_GAIN_CHUNK) {
+    S.ubase = j0;
+    if ((rc = rr2_solve_sequence(h, S, (unsigned)Bv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)h->d_zvirt.p, nullptr, 1e-7)))
+      return rc;
+    hipLaunchKernelGGL(rr2_gain_collect_kernel, dim3((unsigned)Bv), dim3(256), 0, h->stream, S, k, (const double*)h->d_zvirt.p, nrhs, nFp,
+                       (double*)h->d_gz.p, (double*)h->d_gres.p);
+  }
+  const long long tz = (long long)B * nf * k.r, tr = (long long)B * nf * nFp;
+  hipLaunchKernelGGL(rr2_gain_finish_kernel, dim3((unsigned)((tz + 255) / 256)), dim3(256), 0, h->stream, (long long)B, nrhs, k.r, (double*)h->d_gz.p);
+  hipLaunchKernelGGL(rr2_gain_finish_kernel, dim3((unsigned)((tr + 255) / 256)), dim3(256), 0, h->stream, (long long)B, nrhs, nFp, (double*)h->d_gres.p);
+  HIP_TRY(hipGetLastError());
+  h->large_gain_ready = true;
   return DDMPC_OK;
 }
 
@@ -978,6 +1020,22 @@ static int launch_large_nominal_warm(ddmpc_handle* h, const double* up, const do
                                      int32_t* status, int32_t* iters) {
   h->beta_stale = false;
   h->ws_stale = false;
+  h->gain_step_last = false;
+  if (h->large_gain_ready && h->large_affine) {                        // the affine law of ddmpc_prepare: one HBM-bound launch
+    const KParams& k = h->kp;
+    const int nf = h->prm.n * k.nch, nFp = (h->nF + 63) & ~63;
+    int rcz = h->d_zws.ensure((size_t)h->batch * k.rE * sizeof(double));
+    if (!rcz) rcz = h->d_resc.ensure((size_t)h->batch * sizeof(int));
+    if (rcz) return rcz;
+    hipLaunchKernelGGL(rr2_gain_step_kernel, dim3((unsigned)h->batch), dim3(512), 0, h->stream, k, 16 * h->kc.NT, h->nF, nFp, nf + 1,
+                       (const double*)h->d_gz.p, (const double*)h->d_gres.p, up, yp, uo, cost, (int*)status, (int*)iters,
+                       (double*)h->d_zws.p, (int*)h->d_resc.p, 1e-7);
+    HIP_TRY(hipGetLastError());
+    h->rescue_ran = true;
+    h->rr2_x_pending = false;
+    h->gain_step_last = true;
+    return DDMPC_OK;
+  }
   HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)status, 4, (size_t)h->batch, h->stream));
   return launch_nominal_rescue(h, up, yp, uo, cost, status, iters, 2);
 }
@@ -1161,7 +1219,13 @@ int ddmpc_prepare(ddmpc_handle* h) {
     int rc = h->d_prep_status.ensure((size_t)h->batch * sizeof(int32_t));
     if (rc) return rc;
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)h->d_prep_status.p, 4, (size_t)h->batch, h->stream));
+    h->large_gain_ready = false;
     if ((rc = launch_nominal_rescue(h, h->ud, h->yd, nullptr, nullptr, (int32_t*)h->d_prep_status.p, nullptr, 1))) return rc;
+    if (h->large_affine && h->large_pipeline == DDMPC_PIPELINE_PHASES && h->batch <= 65535 && !h->stamps_on && h->d_rr.p) {
+      const size_t r_ = (size_t)h->kp.r, nR_ = (size_t)h->n_free;
+      const long long ndbl_ = (long long)(pk_size((r_ + 15) & ~(size_t)15) + pk_size((nR_ + 15) & ~(size_t)15));
+      if ((rc = launch_rr2_gain_build(h, (double*)h->d_rr.p, ndbl_))) return rc;
+    }
     h->prepared = true;
     return DDMPC_OK;
   }
@@ -1290,9 +1354,16 @@ int ddmpc_step(ddmpc_handle* h, const double* u_past, const double* y_past, doub
 
 int ddmpc_get_gain(ddmpc_handle* h, double* out, int mem) {
   if (!h || !out) return fail(DDMPC_ERR_INVALID, "null argument");
-  if (h->large) return fail(DDMPC_ERR_UNSUPPORTED, "no affine law at this problem size");
-  if (!h->prepared) return fail(DDMPC_ERR_NOT_READY, "ddmpc_prepare must be called before ddmpc_get_gain");
+  if (h->large && !(h->large_nominal && h->large_affine))
+    return fail(DDMPC_ERR_UNSUPPORTED, "no affine law at this problem size (NOMINAL controllers: DDMPC_OPT_LARGE_AFFINE_LAW)");
+  if (!h->prepared || (h->large && !h->large_gain_ready)) return fail(DDMPC_ERR_NOT_READY, "ddmpc_prepare must be called before ddmpc_get_gain");
   HIP_TRY(hipSetDevice(h->device));
+  if (h->large) {            // z = [ubar; ybar] (component order) = gain[:,0] + gain[:,1:]' [u_past; y_past]
+    const size_t bytesz = (size_t)h->batch * (h->prm.n * h->kp.nch + 1) * h->kp.r * sizeof(double);
+    HIP_TRY(hipMemcpyAsync(out, h->d_gz.p, bytesz, mem == DDMPC_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return DDMPC_OK;
+  }
   const size_t bytes = (size_t)h->batch * (h->prm.n * h->kp.nch + 1) * h->kp.r * sizeof(double);
   HIP_TRY(hipMemcpyAsync(out, h->d_gain.p, bytes, mem == DDMPC_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
                          h->stream));
@@ -1327,6 +1398,11 @@ int ddmpc_set_option(ddmpc_handle* h, int option, int value) {
       h->kp.refine_res = std::pow(10.0, -0.1 * (double)value);
       h->prepared = false;
       return DDMPC_OK;
+    case DDMPC_OPT_LARGE_AFFINE_LAW:
+      h->large_affine = value != 0;
+      h->prepared = false;
+      h->large_gain_ready = false;
+      return DDMPC_OK;
     case DDMPC_OPT_LARGE_PIPELINE:
       if (value != DDMPC_PIPELINE_ONE_WORKGROUP && value != DDMPC_PIPELINE_PHASES)
         return fail(DDMPC_ERR_INVALID, "pipeline must be DDMPC_PIPELINE_ONE_WORKGROUP or DDMPC_PIPELINE_PHASES");
@@ -1346,6 +1422,7 @@ int ddmpc_set_setpoints(ddmpc_handle* h, const double* u_s, const double* y_s) {
   h->prm.y_s = h->ys_h.data();
   h->solved = false;
   h->prepared = false;
+  h->large_gain_ready = false;
   HIP_TRY(hipStreamSynchronize(h->stream));
   return upload_params(h);
 }
@@ -1403,6 +1480,19 @@ int ddmpc_get_solution(ddmpc_handle* h, int what, double* out, int mem) {
   }
   // instances solved by the NOMINAL rescue kernel have no beta: ubar / ybar come from the z it exported, alpha = H' x from
   // the vector x it exported
+  if (h->large_nominal && h->gain_step_last && what == DDMPC_SOL_ALPHA) {
+    // the last solve was a step on the affine law, which keeps no w: solve once more on the factors at the same past window
+    const size_t B = (size_t)h->batch;
+    int rc;
+    if ((rc = h->d_uopt.ensure(B * h->prm.L * k.m * sizeof(double))) || (rc = h->d_cost.ensure(B * sizeof(double))) ||
+        (rc = h->d_status.ensure(B * sizeof(int32_t))) || (rc = h->d_iters.ensure(B * sizeof(int32_t))))
+      return rc;
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)h->d_status.p, 4, B, h->stream));
+    if ((rc = launch_nominal_rescue(h, h->last_up, h->last_yp, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int32_t*)h->d_status.p,
+                                    (int32_t*)h->d_iters.p, 2)))
+      return rc;
+    h->gain_step_last = false;
+  }
   const bool resc = h->rescue_ran && h->d_resc.p && h->d_zws.p;
   if (h->large_nominal && !resc) return fail(DDMPC_ERR_NOT_READY, "no solve to read a solution from");
   if (h->large_nominal && h->rr2_x_pending && what == DDMPC_SOL_ALPHA) {

@@ -26,7 +26,7 @@ constexpr int RR2_NG = 8;           // workgroups per instance in the Hankel pro
 
 // per-instance vectors in the global workspace (position order unless noted), RR2 vector length VL = r rounded up to 64
 enum : int { V_FV = 0, V_W1, V_Z0, V_VV, V_W2, V_WK, V_X /* component order */, V_RZ, V_RBR, V_RA, V_VC /* component order */,
-             V_RW, V_DW1, V_RDR, V_DW2, V_CP, V_NV };
+             V_RW, V_DW1, V_RDR, V_DW2, V_CP, V_RES /* f_i - L(i,:) w1 on the dependent fixed rows */, V_NV };
 // per-instance scalars (doubles): [0] max(1, |f|)  [1] rel0  [2] prevrel  [3] cost;  ints: [0] more (another pass)  [1] passes done
 struct Rr2Solve {
   const double* ws; long long stride; long long toff;        // factor of G at +0, factor of T at +toff of an instance's slice
@@ -39,6 +39,9 @@ struct Rr2Solve {
   double* ZP;                                                 // Hankel partial sums [batch][RR2_NG][VL], component order
   double* sc; int* si; unsigned long long* resid;             // scalars (4 doubles, 2 ints per instance), max residual of the dependent rows (bits)
   int r, nF, nR;
+  int fdiv;                                                   // virtual batch of the gain build: instance b solves on the factors of b / fdiv
+                                                              // with the past window e_{b % fdiv - 1} (0: the zero window); 1: a plain solve
+  int unit, ubase;                                            // unit != 0: past window e_{ubase + b % fdiv - 1}
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -169,6 +172,7 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s1_kernel(Rr2Solve S, KParams P, i
                                                        const double* __restrict__ y_past) {
   __shared__ __attribute__((aligned(16))) double fv[RR2_VMAX], y[RR2_VMAX], tmp[64];
   const long long b = blockIdx.x;
+  const long long bf = b / S.fdiv;                                          // the instance whose factors / data this (virtual) instance uses
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int nF = S.nF, n = P.npu / P.m;
   const double* up = u_past + b * (long long)P.npu;
@@ -179,14 +183,15 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s1_kernel(Rr2Solve S, KParams P, i
     if (i < nF) {
       const int rho = S.perm[i];
       const int pidx = P.tabi[1 * RPs + rho];
-      v = (pidx >= 0) ? ((pidx < P.npu) ? up[pidx] : yp[pidx - P.npu]) : P.tabd[2 * RPs + rho];
+      if (S.unit) v = (pidx >= 0) ? ((pidx == S.ubase + (int)(b - bf * S.fdiv) - 1) ? 1.0 : 0.0) : P.tabd[2 * RPs + rho];   // unit past window e_j (j = 0: zero)
+      else v = (pidx >= 0) ? ((pidx < P.npu) ? up[pidx] : yp[pidx - P.npu]) : P.tabd[2 * RPs + rho];
       fm = fmax(fm, fabs(v));
     }
     fv[i] = v; y[i] = 0.0;
   }
   fm = rr2_block_max(fm, tmp);
-  const double* G = S.ws + b * S.stride;
-  rr2_trsv_fwd(G, S.m64 + b * S.m64_stride, nF, S.dd[4 * b + 2], fv, y, tmp);
+  const double* G = S.ws + bf * S.stride;
+  rr2_trsv_fwd(G, S.m64 + bf * S.m64_stride, nF, S.dd[4 * bf + 2], fv, y, tmp);
   double* V = S.V + b * S.vstride;
   for (int i = tid; i < nF; i += nthr) { V[V_FV * S.VL + i] = fv[i]; V[V_W1 * S.VL + i] = y[i]; }
   if (tid == 0) { S.sc[4 * b + 0] = fm; S.sc[4 * b + 1] = 0.0; S.sc[4 * b + 2] = 1e300; S.si[2 * b + 0] = 1; S.si[2 * b + 1] = 0; S.resid[b] = 0ull; }
@@ -206,13 +211,14 @@ __global__ __launch_bounds__(256) void rr2_rows_kernel(Rr2Solve S, KParams P, in
                                                       double* __restrict__ z_ws, int pass) {
   __shared__ double xs[RR2_VMAX];
   const long long b = blockIdx.y;
+  const long long bf = b / S.fdiv;                                          // the instance whose factors / data this (virtual) instance uses
   if ((OP == 1 || OP == 2) && pass > 0 && S.si[2 * b] == 0) return;         // (workgroup-uniform) this instance takes no further pass
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int nF = S.nF, nR = S.nR, VL = S.VL;
-  const int* mt = S.meta + b * S.mstride;
+  const int* mt = S.meta + bf * S.mstride;
   const int nlive = mt[2 * S.rv];
   double* V = S.V + b * S.vstride;
-  const double* Lm = S.ws + b * S.stride;
+  const double* Lm = S.ws + bf * S.stride;
   const int nrows = (OP == 0) ? nF + nR : nR;
   const int row_lo = (int)blockIdx.x * 32;
   if (row_lo >= nrows) return;
@@ -249,7 +255,9 @@ __global__ __launch_bounds__(256) void rr2_rows_kernel(Rr2Solve S, KParams P, in
     if (t32 == 0) {
       if (OP == 0) {
         if (i < nF) {
-          if (mt[i]) atomicMax(S.resid + b, (unsigned long long)__double_as_longlong(fabs(V[V_FV * VL + i] - sacc)));
+          const double res = mt[i] ? V[V_FV * VL + i] - sacc : 0.0;
+          V[V_RES * VL + i] = res;
+          if (mt[i]) atomicMax(S.resid + b, (unsigned long long)__double_as_longlong(fabs(res)));
         } else V[V_Z0 * VL + (i - nF)] = sacc;
       } else if (OP == 1) {
         V[V_RBR * VL + i] = S.wz[i] * (V[V_Z0 * VL + i] + sacc - S.wz[S.rv + i]);
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(256) void rr2_rows_kernel(Rr2Solve S, KParams P, in
         V[V_CP * VL + i] = S.wz[i] * dlt * dlt;
         const int rho = S.perm[nF + i];
         const int oidx = P.tabi[2 * RPs + rho];
-        if (oidx >= 0) u_opt[b * (long long)((P.Ln - P.npu / P.m) * P.m) + oidx] = z;
+        if (oidx >= 0 && u_opt) u_opt[b * (long long)((P.Ln - P.npu / P.m) * P.m) + oidx] = z;
         if (z_ws) z_ws[b * (long long)P.rE + rho] = z;
       }
     }
@@ -281,13 +289,14 @@ __global__ __launch_bounds__(512) void rr2_cols_kernel(Rr2Solve S, int pass) {
   __shared__ double vs[RR2_VMAX];
   __shared__ double red[8 * 64];
   const long long b = blockIdx.y;
+  const long long bf = b / S.fdiv;                                          // the instance whose factors / data this (virtual) instance uses
   if (pass > 0 && S.si[2 * b] == 0) return;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int nF = S.nF, nR = S.nR, VL = S.VL;
-  const int* mt = S.meta + b * S.mstride;
+  const int* mt = S.meta + bf * S.mstride;
   const int nRl = mt[2 * S.rv + 1];
   double* V = S.V + b * S.vstride;
-  const double* Lm = S.ws + b * S.stride;
+  const double* Lm = S.ws + bf * S.stride;
   const int ncols = (OP == 1) ? nF : nRl;
   const int col0 = (OP == 1) ? 0 : nF;
   const int k0 = (int)blockIdx.x * 64;
@@ -333,20 +342,21 @@ __global__ __launch_bounds__(512) void rr2_cols_kernel(Rr2Solve S, int pass) {
 __global__ __launch_bounds__(RR2_TS) void rr2_s4_kernel(Rr2Solve S, int pass) {
   __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], red[32 * 64], tmp[64];
   const long long b = blockIdx.x;
+  const long long bf = b / S.fdiv;                                          // the instance whose factors / data this (virtual) instance uses
   if (pass > 0 && S.si[2 * b] == 0) return;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int nF = S.nF, nR = S.nR, r = S.r, VL = S.VL;
-  const int* mt = S.meta + b * S.mstride;
+  const int* mt = S.meta + bf * S.mstride;
   const int nlive = mt[2 * S.rv], nRl = mt[2 * S.rv + 1];
   double* V = S.V + b * S.vstride;
-  const double* G = S.ws + b * S.stride;
+  const double* G = S.ws + bf * S.stride;
   if (pass == 0) {
     const double* T = G + S.toff;
-    const double* mT = S.m64 + b * S.m64_stride + S.m64T;
+    const double* mT = S.m64 + bf * S.m64_stride + S.m64T;
     for (int i = tid; i < ((nRl + 63) & ~63); i += nthr) { va[i] = (i < nRl) ? V[V_VV * VL + i] : 0.0; vb[i] = 0.0; }
     __syncthreads();
-    rr2_trsv_fwd(T, mT, nRl, S.dd[4 * b + 3], va, vb, tmp);                 // vb = T^-1 (forward)
-    rr2_trsv_bwd(T, mT, nRl, S.dd[4 * b + 3], vb, va, red, tmp);            // va = w2
+    rr2_trsv_fwd(T, mT, nRl, S.dd[4 * bf + 3], va, vb, tmp);                 // vb = T^-1 (forward)
+    rr2_trsv_bwd(T, mT, nRl, S.dd[4 * bf + 3], vb, va, red, tmp);            // va = w2
     for (int a = tid; a < nR; a += nthr) {
       const double w2 = (a < nRl) ? va[a] : 0.0;
       V[V_W2 * VL + a] = w2; V[V_WK * VL + nF + a] = w2;
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s4_kernel(Rr2Solve S, int pass) {
   }
   for (int i = tid; i < ((nlive + 63) & ~63); i += nthr) { va[i] = (i < nlive) ? V[V_WK * VL + i] : 0.0; vb[i] = 0.0; }
   __syncthreads();
-  rr2_trsv_bwd(G, S.m64 + b * S.m64_stride, nlive, S.dd[4 * b + 2], va, vb, red, tmp);
+  rr2_trsv_bwd(G, S.m64 + bf * S.m64_stride, nlive, S.dd[4 * bf + 2], va, vb, red, tmp);
   for (int k = tid; k < r; k += nthr) V[V_X * VL + S.perm[k]] = (k < nlive) ? vb[k] : 0.0;
 }
 
@@ -369,6 +379,7 @@ __global__ __launch_bounds__(512) void rr2_hankel_kernel(Rr2Solve S, KParams P, 
                                                         const double* __restrict__ y_d, int slot, int pass) {
   __shared__ __attribute__((aligned(16))) double xs[RR2_VMAX], zs[RR2_VMAX], pan[PSD_PAN];
   const long long b = blockIdx.y;
+  const long long bf = b / S.fdiv;                                          // the instance whose factors / data this (virtual) instance uses
   if (pass > 0 && S.si[2 * b] == 0) return;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int g = blockIdx.x;
@@ -379,8 +390,8 @@ __global__ __launch_bounds__(512) void rr2_hankel_kernel(Rr2Solve S, KParams P, 
   KParams Pg = P;
   Pg.c = (P.c - clo) < cg ? (P.c - clo) : cg;
   Pg.N = P.N - clo;
-  const double* ud = u_d + (b * (long long)P.N + clo) * P.m;
-  const double* yd = y_d + (b * (long long)P.N + clo) * P.p;
+  const double* ud = u_d + (bf * (long long)P.N + clo) * P.m;
+  const double* yd = y_d + (bf * (long long)P.N + clo) * P.p;
   const double* xin = S.V + b * S.vstride + (long long)slot * S.VL;
   for (int k = tid; k < S.r; k += nthr) xs[k] = xin[k];
   __syncthreads();
@@ -421,6 +432,7 @@ __global__ __launch_bounds__(512) void rr2_hankel_mfma_kernel(Rr2Solve S, KParam
                                                              const double* __restrict__ y_d, int slot, int pass, int ng) {
   extern __shared__ __attribute__((aligned(16))) double hk_lds[];
   const long long b = blockIdx.y;
+  const long long bf = b / S.fdiv;                                          // the instance whose factors / data this (virtual) instance uses
   if (pass > 0 && S.si[2 * b] == 0) return;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
@@ -436,8 +448,8 @@ __global__ __launch_bounds__(512) void rr2_hankel_mfma_kernel(Rr2Solve S, KParam
   double* xp = xT + 16 * G.NBK * G.RS;                                       // x, rows -15 .. Ln + 14, row stride RS
   double* ap = xp + (Ln + 30) * G.RS;                                        // alpha, 15 zeros in front, >= 33 behind
   double* part = ap + G.cg + 48;                                             // 8 x 256
-  const double* ud = u_d + b * (long long)P.N * m;
-  const double* yd = y_d + b * (long long)P.N * p;
+  const double* ud = u_d + bf * (long long)P.N * m;
+  const double* yd = y_d + bf * (long long)P.N * p;
   const double* xin = S.V + b * S.vstride + (long long)slot * S.VL;
   // ---- staging: trajectory rows clo .. clo + 16 NBK (zeros past the data and in the padding channels), x, zeros of alpha
   const int nrows = 16 * G.NBK;
@@ -553,13 +565,14 @@ __global__ __launch_bounds__(512) void rr2_hankel_mfma_kernel(Rr2Solve S, KParam
 __global__ __launch_bounds__(RR2_TS) void rr2_s8_kernel(Rr2Solve S, int pass) {
   __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], red[32 * 64], tmp[64];
   const long long b = blockIdx.x;
+  const long long bf = b / S.fdiv;                                          // the instance whose factors / data this (virtual) instance uses
   if (pass > 0 && S.si[2 * b] == 0) return;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int nF = S.nF, r = S.r, VL = S.VL;
-  const int* mt = S.meta + b * S.mstride;
+  const int* mt = S.meta + bf * S.mstride;
   double* V = S.V + b * S.vstride;
-  const double* G = S.ws + b * S.stride;
-  const double* mG = S.m64 + b * S.m64_stride;
+  const double* G = S.ws + bf * S.stride;
+  const double* mG = S.m64 + bf * S.m64_stride;
   const double* zp = S.ZP + b * RR2_NG * (long long)VL;
   for (int k = tid; k < r; k += nthr) {
     const int rho = S.perm[k];
@@ -570,7 +583,7 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s8_kernel(Rr2Solve S, int pass) {
   }
   for (int i = tid; i < ((nF + 63) & ~63); i += nthr) { va[i] = (i < nF) ? V[V_RA * VL + i] : 0.0; vb[i] = 0.0; }
   __syncthreads();
-  rr2_trsv_bwd(G, mG, nF, S.dd[4 * b + 2], va, vb, red, tmp);               // vb = mu
+  rr2_trsv_bwd(G, mG, nF, S.dd[4 * bf + 2], va, vb, red, tmp);               // vb = mu
   for (int k = tid; k < r; k += nthr) {
     const double v = (k < nF) ? (mt[k] ? 0.0 : vb[k]) : S.wz[k - nF] * (V[V_RZ * VL + k] - S.wz[S.rv + k - nF]);
     V[V_VC * VL + S.perm[k]] = v;
@@ -578,7 +591,7 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s8_kernel(Rr2Solve S, int pass) {
   __syncthreads();
   for (int i = tid; i < ((nF + 63) & ~63); i += nthr) { va[i] = (i < nF) ? V[V_FV * VL + i] - V[V_RZ * VL + i] : 0.0; vb[i] = 0.0; }
   __syncthreads();
-  rr2_trsv_fwd(G, mG, nF, S.dd[4 * b + 2], va, vb, tmp);
+  rr2_trsv_fwd(G, mG, nF, S.dd[4 * bf + 2], va, vb, tmp);
   for (int i = tid; i < nF; i += nthr) V[V_DW1 * VL + i] = vb[i];
 }
 
@@ -588,10 +601,11 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s8_kernel(Rr2Solve S, int pass) {
 __global__ __launch_bounds__(RR2_TS) void rr2_s11_kernel(Rr2Solve S, int pass) {
   __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], tmp[64];
   const long long b = blockIdx.x;
+  const long long bf = b / S.fdiv;                                          // the instance whose factors / data this (virtual) instance uses
   if (pass > 0 && S.si[2 * b] == 0) return;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int r = S.r, VL = S.VL;
-  const int* mt = S.meta + b * S.mstride;
+  const int* mt = S.meta + bf * S.mstride;
   const int nlive = mt[2 * S.rv];
   double* V = S.V + b * S.vstride;
   const double* zp = S.ZP + b * RR2_NG * (long long)VL;
@@ -605,7 +619,7 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s11_kernel(Rr2Solve S, int pass) {
     va[k] = s; vb[k] = 0.0;
   }
   __syncthreads();
-  rr2_trsv_fwd(S.ws + b * S.stride, S.m64 + b * S.m64_stride, nlive, S.dd[4 * b + 2], va, vb, tmp);
+  rr2_trsv_fwd(S.ws + bf * S.stride, S.m64 + bf * S.m64_stride, nlive, S.dd[4 * bf + 2], va, vb, tmp);
   for (int k = tid; k < r; k += nthr) V[V_RW * VL + k] = (k < nlive) ? vb[k] : 0.0;
 }
 
@@ -616,18 +630,19 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s11_kernel(Rr2Solve S, int pass) {
 __global__ __launch_bounds__(RR2_TS) void rr2_s13_kernel(Rr2Solve S, int pass, int refine_max) {
   __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], red[32 * 64], tmp[64];
   const long long b = blockIdx.x;
+  const long long bf = b / S.fdiv;                                          // the instance whose factors / data this (virtual) instance uses
   if (pass > 0 && S.si[2 * b] == 0) return;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int nF = S.nF, nR = S.nR, r = S.r, VL = S.VL;
-  const int* mt = S.meta + b * S.mstride;
+  const int* mt = S.meta + bf * S.mstride;
   const int nRl = mt[2 * S.rv + 1];
   double* V = S.V + b * S.vstride;
-  const double* T = S.ws + b * S.stride + S.toff;
-  const double* mT = S.m64 + b * S.m64_stride + S.m64T;
+  const double* T = S.ws + bf * S.stride + S.toff;
+  const double* mT = S.m64 + bf * S.m64_stride + S.m64T;
   for (int i = tid; i < ((nRl + 63) & ~63); i += nthr) { va[i] = (i < nRl) ? V[V_VV * VL + i] : 0.0; vb[i] = 0.0; }
   __syncthreads();
-  rr2_trsv_fwd(T, mT, nRl, S.dd[4 * b + 3], va, vb, tmp);
-  rr2_trsv_bwd(T, mT, nRl, S.dd[4 * b + 3], vb, va, red, tmp);              // va = dw2
+  rr2_trsv_fwd(T, mT, nRl, S.dd[4 * bf + 3], va, vb, tmp);
+  rr2_trsv_bwd(T, mT, nRl, S.dd[4 * bf + 3], vb, va, red, tmp);              // va = dw2
   double dmx = 0.0, wmx = 0.0;
   for (int k = tid; k < r; k += nthr) {
     const double dl = (k < nF) ? V[V_DW1 * VL + k] : ((k - nF) < nRl ? va[k - nF] : 0.0);
@@ -656,9 +671,10 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s15_kernel(Rr2Solve S, KParams P, 
                                                         double* __restrict__ z_ws, int* __restrict__ rescued) {
   __shared__ double red[RR2_TS];
   const long long b = blockIdx.x;
+  const long long bf = b / S.fdiv;                                          // the instance whose factors / data this (virtual) instance uses
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int nF = S.nF, nR = S.nR, r = S.r, VL = S.VL;
-  const int* mt = S.meta + b * S.mstride;
+  const int* mt = S.meta + bf * S.mstride;
   const int nRl = mt[2 * S.rv + 1];
   double* V = S.V + b * S.vstride;
   double part = 0.0;
@@ -674,7 +690,7 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s15_kernel(Rr2Solve S, KParams P, 
     const int rho = S.perm[k];
     const int oidx = P.tabi[2 * RPs + rho];
     const double fvk = V[V_FV * VL + k];
-    if (oidx >= 0) uo[oidx] = fvk;                                          // terminal inputs are part of optimal_u
+    if (oidx >= 0 && u_opt) uo[oidx] = fvk;                                  // terminal inputs are part of optimal_u
     if (z_ws) z_ws[b * (long long)P.rE + rho] = fvk;
   }
   for (int k = tid; k < r; k += nthr)                                       // the final w (ddmpc_get_solution: x = L_I^-T w, alpha = H' x)
@@ -683,10 +699,10 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s15_kernel(Rr2Solve S, KParams P, 
     const double tot = red[0];
     const double resid = __longlong_as_double((long long)S.resid[b]);
     const bool feasible = resid <= feas_tol * S.sc[4 * b + 0];
-    cost[b] = tot;
+    if (cost) cost[b] = tot;
     // (an instance that asked for another refinement pass is solved again, with all its passes, by ddmpc_nominal_rr_kernel<2>,
     //  launched behind this kernel for the instances marked 4: the rare case does not cost the batch a launch sequence per pass)
-    status[b] = (S.si[2 * b] != 0 || !(fabs(tot) < 1e300)) ? 4 : (feasible ? 0 : 2);   // 2 = "infeasible"
+    if (status) status[b] = (S.si[2 * b] != 0 || !(fabs(tot) < 1e300)) ? 4 : (feasible ? 0 : 2);   // 2 = "infeasible"
     if (iters) iters[b] = 1;
     if (rescued) rescued[b] = 1;
   }
@@ -696,15 +712,99 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s15_kernel(Rr2Solve S, KParams P, 
 __global__ __launch_bounds__(RR2_TS) void rr2_xws_kernel(Rr2Solve S, KParams P, double* __restrict__ x_ws) {
   __shared__ __attribute__((aligned(16))) double va[RR2_VMAX], vb[RR2_VMAX], red[32 * 64], tmp[64];
   const long long b = blockIdx.x;
+  const long long bf = b / S.fdiv;                                          // the instance whose factors / data this (virtual) instance uses
   if (S.si[2 * b] != 0) return;                                             // solved by ddmpc_nominal_rr_kernel<2>, which exported its own x
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int* mt = S.meta + b * S.mstride;
+  const int* mt = S.meta + bf * S.mstride;
   const int nlive = mt[2 * S.rv];
   const double* V = S.V + b * S.vstride;
   for (int i = tid; i < ((nlive + 63) & ~63); i += nthr) { va[i] = (i < nlive) ? V[V_WK * S.VL + i] : 0.0; vb[i] = 0.0; }
   __syncthreads();
-  rr2_trsv_bwd(S.ws + b * S.stride, S.m64 + b * S.m64_stride, nlive, S.dd[4 * b + 2], va, vb, red, tmp);
+  rr2_trsv_bwd(S.ws + bf * S.stride, S.m64 + bf * S.m64_stride, nlive, S.dd[4 * bf + 2], va, vb, red, tmp);
   for (int k = tid; k < S.r; k += nthr) x_ws[b * (long long)P.rE + S.perm[k]] = (k < nlive) ? vb[k] : 0.0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The affine control law of a NOMINAL controller beyond the register-resident kernels (DDMPC_OPT_LARGE_AFFINE_LAW): with the
+// data fixed, z = [ubar; ybar] and the residuals of the dependent fixed rows are affine in the past window [u_past; y_past]
+// (one refinement pass, no data-dependent branch), so ddmpc_prepare solves for the zero window and the n(m+p) unit windows --
+// the phase kernels above on a VIRTUAL batch: instance b uses the factors of b / fdiv and the window e_{ubase + b % fdiv - 1} --
+// and ddmpc_step evaluates  z = g_0 + sum_j past_j g_j  (controller.py:389-407 once the data stand).
+// Gz [batch][nrhs][r] component order, Gres [batch][nrhs][nFp] position order.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void rr2_gain_collect_kernel(Rr2Solve S, KParams P, const double* __restrict__ z_virt, int nrhs, int nFp,
+                                        double* __restrict__ Gz, double* __restrict__ Gres) {
+  const long long bv = blockIdx.x, b = bv / S.fdiv;
+  const int j = S.ubase + (int)(bv - b * S.fdiv);
+  if (j >= nrhs) return;
+  const double* V = S.V + bv * S.vstride;
+  double* gz = Gz + (b * nrhs + j) * (long long)S.r;
+  double* gr = Gres + (b * nrhs + j) * (long long)nFp;
+  for (int e = threadIdx.x; e < S.r; e += blockDim.x) gz[e] = z_virt[bv * (long long)P.rE + e];
+  for (int i = threadIdx.x; i < nFp; i += blockDim.x) gr[i] = (i < S.nF) ? V[V_RES * S.VL + i] : 0.0;
+}
+__global__ void rr2_gain_finish_kernel(long long batch, int nrhs, int len, double* __restrict__ G) {     // columns 1.. minus column 0
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long per = (long long)(nrhs - 1) * len;
+  if (idx >= batch * per) return;
+  const long long b = idx / per, rem = idx - b * per;
+  const int j = 1 + (int)(rem / len), e = (int)(rem - (long long)(j - 1) * len);
+  G[(b * nrhs + j) * (long long)len + e] -= G[(b * nrhs) * (long long)len + e];
+}
+// One control step on the law: HBM-bound (the (nrhs)(r + nFp) doubles of an instance are read once).  grid = batch, 512 threads.
+__global__ __launch_bounds__(512) void rr2_gain_step_kernel(KParams P, int RPs, int nF, int nFp, int nrhs, const double* __restrict__ Gz,
+                                                           const double* __restrict__ Gres, const double* __restrict__ u_past,
+                                                           const double* __restrict__ y_past, double* __restrict__ u_opt,
+                                                           double* __restrict__ cost, int* __restrict__ status, int* __restrict__ iters,
+                                                           double* __restrict__ z_ws, int* __restrict__ rescued, double feas_tol) {
+  __shared__ double past[WARM_MAX_NF];
+  __shared__ double red[512], redm[16];
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int nf = nrhs - 1, r = P.r, n = P.npu / P.m;
+  for (int j = tid; j < nf; j += nthr) past[j] = (j < P.npu) ? u_past[b * (long long)P.npu + j] : y_past[b * (long long)(n * P.p) + (j - P.npu)];
+  __syncthreads();
+  double part = 0.0, fm = 1.0, rm = 0.0;
+  double* uo = u_opt + b * (long long)((P.Ln - n) * P.m);
+  for (int e = tid; e < r + nFp; e += nthr) {
+    const bool isz = e < r;
+    const int len = isz ? r : nFp, ee = isz ? e : e - r;
+    const double* g = (isz ? Gz : Gres) + (b * nrhs) * (long long)len + ee;
+    double s0 = g[0], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int j = 0;
+    for (; j + 8 <= nf; j += 8) {
+      const double g0 = g[(long long)(j + 1) * len], g1 = g[(long long)(j + 2) * len], g2 = g[(long long)(j + 3) * len], g3 = g[(long long)(j + 4) * len],
+                   g4 = g[(long long)(j + 5) * len], g5 = g[(long long)(j + 6) * len], g6 = g[(long long)(j + 7) * len], g7 = g[(long long)(j + 8) * len];
+      s0 += g0 * past[j] + g4 * past[j + 4]; s1 += g1 * past[j + 1] + g5 * past[j + 5];
+      s2 += g2 * past[j + 2] + g6 * past[j + 6]; s3 += g3 * past[j + 3] + g7 * past[j + 7];
+    }
+    for (; j < nf; ++j) s0 += g[(long long)(j + 1) * len] * past[j];
+    const double v = (s0 + s1) + (s2 + s3);
+    if (isz) {
+      const int kind = P.tabi[0 * RPs + e];
+      if (kind == K_UFREE || kind == K_YFREE) { const double dlt = v - P.tabd[2 * RPs + e]; part += P.tabd[3 * RPs + e] * dlt * dlt; }
+      else fm = fmax(fm, fabs(v));
+      const int oidx = P.tabi[2 * RPs + e];
+      if (oidx >= 0) uo[oidx] = v;
+      if (z_ws) z_ws[b * (long long)P.rE + e] = v;
+    } else rm = fmax(rm, fabs(v));
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int off = 256; off > 0; off >>= 1) {
+    if (tid < off) red[tid] += red[tid + off];
+    __syncthreads();
+  }
+  fm = rr2_block_max(fm, redm);
+  rm = rr2_block_max(rm, redm);
+  if (tid == 0) {
+    const double tot = red[0];
+    cost[b] = tot;
+    status[b] = !(fabs(tot) < 1e300) ? 4 : (rm <= feas_tol * fm ? 0 : 2);
+    if (iters) iters[b] = 1;
+    if (rescued) rescued[b] = 1;
+  }
 }
 
 }  // namespace ddmpc

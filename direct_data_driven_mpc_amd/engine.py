@@ -251,6 +251,11 @@ class BatchedDDMPC:
         L.check(self._lib.ddmpc_set_option(self._h, L.OPT_LARGE_PIPELINE,
                                            {"one_workgroup": L.PIPELINE_ONE_WORKGROUP, "phases": L.PIPELINE_PHASES}[mode]))
 
+    def set_large_affine_law(self, on: bool) -> None:
+        """NOMINAL controllers beyond the register-resident kernels: `prepare` also forms the affine law z(past) and `step`
+        evaluates it (DDMPC_OPT_LARGE_AFFINE_LAW; default off: `step` repeats the solve on the kept factors)."""
+        L.check(self._lib.ddmpc_set_option(self._h, L.OPT_LARGE_AFFINE_LAW, 1 if on else 0))
+
     def closed_loop(self, A, B, Cm, D, x0, u_past, y_past, w, n_mpc_step: int = 1):
         """Batched closed loop on the device (controller_operation.py:259-305 for every instance).
 

@@ -110,6 +110,12 @@ extern "C" {
 #define DDMPC_PIPELINE_ONE_WORKGROUP 0 /* one workgroup per instance runs every phase (ddmpc_nominal_rr_kernel<1>) */
 #define DDMPC_PIPELINE_PHASES 1        /* default: one kernel per phase over the whole batch in lock step, several workgroups
                                          per instance, Cholesky by 64-column panels (ddmpc_rr2.hpp) */
+#define DDMPC_OPT_LARGE_AFFINE_LAW 7   /* NOMINAL controllers beyond the register-resident kernels, phase-kernel pipeline: 1 = ddmpc_prepare also
+                                         forms the affine control law z(past) (solves at the zero window and the n(m+p) unit windows,
+                                         once per data set) and ddmpc_step evaluates it in one HBM-bound launch; ddmpc_get_gain then
+                                         returns it as [batch][n(m+p)+1][(m+p)(L+n)], z = [ubar; ybar] per component = gain[0] +
+                                         gain[1:]' [u_past; y_past].  0 (default): ddmpc_step repeats the solve on the kept factors,
+                                         bit-equal to ddmpc_solve (controller.py:389-407) */
 #define DDMPC_REFINE_RES_DEFAULT 107  /* 2e-11: benchmark data stays below ~2e-12, the parity bars are missed from ~1.3e-10 on */
 
 typedef struct ddmpc_handle ddmpc_handle;

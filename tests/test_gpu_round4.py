@@ -174,3 +174,58 @@ def test_large_nominal_infeasible_setpoint_and_refinement_cap(gpu):
             eng.set_data(d["u_d"], d["y_d"])
             out[cap] = tuple(x.copy() for x in eng.solve(up, yp))
     assert np.all(out[1][2] == 0) and np.array_equal(out[1][0], out[3][0]) and np.array_equal(out[1][1], out[3][1])
+
+
+# ------------------------------------------------------------------ the affine law beyond the register-resident kernels
+def test_large_nominal_affine_law(gpu):
+    # DDMPC_OPT_LARGE_AFFINE_LAW on the cfg-5 shape: ddmpc_prepare forms z(past) from solves at the zero window and the n(m+p)
+    # unit windows; ddmpc_step then evaluates it -- within the bars of the cold solve (controller.py:389-407 with the data fixed)
+    # for consistent past windows, "infeasible" for a window no trajectory of the plant explains; ddmpc_get_gain returns the
+    # law itself: z = [ubar; ybar] per component; the per-step closed loop on the law follows the one on the kept factors
+    from test_gpu_round3 import _config5
+    B = 6
+    spec, plant, N, d, up, yp = _config5(B)
+    n, m, p = spec.n, spec.m, spec.p
+    up2 = d["u_d"][:, 100:100 + n, :].reshape(B, -1).copy(); yp2 = d["y_d"][:, 100:100 + n, :].reshape(B, -1).copy()
+    bad_y = yp2 + 0.05                                                   # no trajectory of the plant has this past window
+    with _spec_engine(spec, N, B) as eng:
+        with pytest.raises(L.DDMPCError):
+            eng.gain()                                                   # no law without the option
+        eng.set_large_affine_law(True)
+        eng.set_data(d["u_d"], d["y_d"])
+        cold = tuple(x.copy() for x in eng.solve(up2, yp2))
+        cold_bad = tuple(x.copy() for x in eng.solve(up2, bad_y))
+        eng.prepare()
+        warm = tuple(x.copy() for x in eng.step(up2, yp2))
+        ub, yb = eng.get_solution("ubar"), eng.get_solution("ybar")
+        al = eng.get_solution("alpha")                                   # (a full solve on the factors behind the scenes)
+        warm_bad = tuple(x.copy() for x in eng.step(up2, bad_y))
+        warm1 = tuple(x.copy() for x in eng.step(up, yp))
+        g = eng.gain()
+    assert np.all(cold[2] == 0) and np.all(warm[2] == 0)
+    sc = np.max(np.abs(cold[0]), axis=1)
+    assert np.max(np.max(np.abs(warm[0] - cold[0]), axis=1) / sc) < TOL_U
+    assert np.max(np.abs(warm[1] - cold[1]) / np.abs(cold[1])) < TOL_COST
+    assert [L.STATUS_STRINGS[int(s)] for s in cold_bad[2]] == ["infeasible"] * B == [L.STATUS_STRINGS[int(s)] for s in warm_bad[2]]
+    assert np.all(warm1[2] == 0) and not np.array_equal(warm1[0], warm[0])
+    # the law itself: component order (time-major, the m + p channels of a step adjacent)
+    nf, r = n * (m + p), (m + p) * (spec.L + n)
+    assert g.shape == (B, nf + 1, r)
+    past = np.concatenate([up2, yp2], axis=1)
+    z = g[:, 0, :] + np.einsum("bjr,bj->br", g[:, 1:, :], past)
+    zz = z.reshape(B, spec.L + n, m + p)
+    assert np.max(np.abs(zz[:, :, :m].reshape(B, -1) - ub)) < 1e-9 * np.max(np.abs(ub))
+    assert np.max(np.abs(zz[:, :, m:].reshape(B, -1) - yb)) < 1e-9 * np.max(np.abs(yb))
+    assert np.array_equal(ub[:, n * m:], warm[0]) and np.all(np.isfinite(al))
+    # closed loop: on the law vs on the kept factors
+    n_steps = 16
+    w = np.zeros((B, n_steps, p))
+    out = {}
+    for law in (False, True):
+        with _spec_engine(spec, N, B) as eng:
+            eng.set_large_affine_law(law)
+            eng.set_data(d["u_d"], d["y_d"])
+            out[law] = eng.closed_loop(plant["A"], plant["B"], plant["C"], plant["D"], d["x_end"], up, yp, w, n_mpc_step=1)
+    assert np.all(out[True][2] == 0)
+    assert np.max(np.abs(out[True][0] - out[False][0])) < 1e-7 * np.max(np.abs(out[False][0]))
+    assert np.max(np.abs(out[True][1] - out[False][1])) < 1e-7 * np.max(np.abs(out[False][1]))

@@ -77,6 +77,18 @@ def case(tag, m, p, n, Lh, N, B, eps, seed, dump=False, timeit=False):
                     eng.step(upt, ypt, *w)
                 torch.cuda.synchronize(); ds = (time.perf_counter() - t0) / 5
                 print("  %-14s B=%d: cold %.3f ms (%.3e solves/s), prepare %.3f ms, step %.3f ms" % (mode, B, dt * 1e3, B / dt, tp * 1e3, ds * 1e3), flush=True)
+                if mode == "phases":
+                    eng.set_large_affine_law(True)
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    eng.prepare()
+                    torch.cuda.synchronize(); tp = time.perf_counter() - t0
+                    wl = eng.step(upt, ypt)
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    for _ in range(20):
+                        eng.step(upt, ypt, *wl)
+                    torch.cuda.synchronize(); ds = (time.perf_counter() - t0) / 20
+                    eu = float((wl[0] - out[0]).abs().max() / out[0].abs().max())
+                    print("  %-14s B=%d: affine law: prepare %.2f ms, step %.4f ms (%.3e steps/s), max rel diff vs cold u %.2e" % (mode, B, tp * 1e3, ds * 1e3, B / ds, eu), flush=True)
     a, bq = res["one_workgroup"], res["phases"]
     sc = np.max(np.abs(a[0]), axis=1)
     du = float(np.max(np.max(np.abs(a[0] - bq[0]), axis=1) / sc))
