@@ -229,3 +229,31 @@ def test_large_nominal_affine_law(gpu):
     assert np.all(out[True][2] == 0)
     assert np.max(np.abs(out[True][0] - out[False][0])) < 1e-7 * np.max(np.abs(out[False][0]))
     assert np.max(np.abs(out[True][1] - out[False][1])) < 1e-7 * np.max(np.abs(out[False][1]))
+
+
+# ------------------------------------------------------------------ cfg 5 against a reference-formulation oracle beyond fp64
+def test_config5_against_the_extended_precision_golden_solutions(gpu):
+    # tests/golden/cfg5_extended.npz: sixteen instances of BASELINE configs[4] -- among them 283, the one on which the fp64 SVD
+    # route and the model-based solution disagree at the 1e-8 level -- solved from the DATA alone (the reference's formulation,
+    # controller.py:506-538,549-629,679-711; no (A, B, C)) in 80-bit arithmetic with orthogonal factorisations
+    # (tests/golden/make_golden_cfg5.py, good to ~1e-13).  The GPU (default path: phase kernels) against THAT at the standard bars.
+    from test_gpu_round3 import _config5
+    z = np.load(os.path.join(ROOT, "tests", "golden", "cfg5_extended.npz"))
+    inst = [int(b) for b in z["instances"]]
+    B = 512
+    spec, plant, N, d, up, yp = _config5(B)
+    with _spec_engine(spec, N, B) as eng:
+        eng.set_data(d["u_d"], d["y_d"])
+        u, cost, status, _ = eng.solve(up, yp)
+        res = {}
+        for mode in ("one_workgroup",):
+            eng.set_large_pipeline(mode)
+            res[mode] = tuple(x.copy() for x in eng.solve(up, yp))
+    assert np.all(status == 0)
+    eu = np.array([np.max(np.abs(u[b] - z["optimal_u"][k])) / np.max(np.abs(z["optimal_u"][k])) for k, b in enumerate(inst)])
+    ec = np.array([abs(cost[b] - z["cost"][k]) / z["cost"][k] for k, b in enumerate(inst)])
+    print("cfg 5 vs extended-precision golden: max rel err u %.2e (instance 283: %.2e), cost %.2e" % (eu.max(), eu[0], ec.max()))
+    assert inst[0] == 283 and eu.max() < TOL_U and ec.max() < TOL_COST, (eu, ec)
+    uo = res["one_workgroup"][0]
+    eo = max(np.max(np.abs(uo[b] - z["optimal_u"][k])) / np.max(np.abs(z["optimal_u"][k])) for k, b in enumerate(inst))
+    assert eo < TOL_U, eo

@@ -159,3 +159,27 @@ def test_nominal_exact_oracle():
     spec.y_s = (Cm @ np.linalg.inv(np.eye(4) - A) @ Bm + D) @ spec.u_s
     r = solve_nominal_exact(spec, d["u_d"][0], d["y_d"][0], up, yp)
     assert r["status"] == "optimal" and r["residual"] < 1e-12 and r["cost"] > 0.1
+
+
+def test_nominal_oracles_against_the_extended_precision_golden_solutions():
+    # tests/golden/cfg5_extended.npz: BASELINE configs[4] solved from the DATA alone in 80-bit arithmetic with orthogonal
+    # factorisations (make_golden_cfg5.py; the reference's formulation, controller.py:506-538,679-711).  The fp64 checkers the GPU
+    # tests use on exact data -- the SVD route and the model-based solution -- must sit inside the parity bar of it.
+    import os
+    from direct_data_driven_mpc_amd.harness import generate_batch
+    from oracle.nominal_exact import solve_nominal_exact, solve_nominal_model_based
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(sys_path, "cfg5_extended.npz"))
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("make_golden_cfg5", os.path.join(sys_path, "make_golden_cfg5.py"))
+    g = importlib.util.module_from_spec(spec_); spec_.loader.exec_module(g)
+    spec, plant, N = g.config5(512)
+    n = spec.n
+    for k, b in list(enumerate(z["instances"]))[:3]:                 # (283 first; a few seconds each)
+        d = generate_batch([int(b)], N=N, plant=plant)
+        up = d["u_d"][0, -n:, :].reshape(-1); yp = d["y_d"][0, -n:, :].reshape(-1)
+        sc = np.max(np.abs(z["optimal_u"][k]))
+        mod = solve_nominal_model_based(spec, plant, up, yp)
+        assert np.max(np.abs(mod["optimal_u"] - z["optimal_u"][k])) < 1e-8 * sc and abs(mod["cost"] - z["cost"][k]) < 1e-9 * z["cost"][k]
+        svd = solve_nominal_exact(spec, d["u_d"][0], d["y_d"][0], up, yp)
+        assert svd["status"] == "optimal" and np.max(np.abs(svd["optimal_u"] - z["optimal_u"][k])) < 2e-8 * sc
