@@ -83,3 +83,22 @@ if __name__ == "__main__":
         wms = e0.elapsed_time(e1) / a.steps
         print("warm: ddmpc_prepare %.2f ms once per data set; ddmpc_step %.2f ms per batch, %.3e steps/s (bit-equal to ddmpc_solve: %s)"
               % (prep_ms, wms, B / wms * 1e3, same))
+        if not a.robust:
+            eng.set_large_affine_law(True)             # DDMPC_OPT_LARGE_AFFINE_LAW: the law z(past), one HBM-bound launch per step
+            torch.cuda.synchronize()
+            e0.record()
+            eng.prepare()
+            e1.record(); torch.cuda.synchronize()
+            prep_ms = e0.elapsed_time(e1)
+            w = eng.step(up, yp)
+            eng.step(up, yp, *w)
+            e0.record()
+            for _ in range(20):
+                eng.step(up, yp, *w)
+            e1.record(); torch.cuda.synchronize()
+            wms = e0.elapsed_time(e1) / 20
+            nf, r, nFp = n * (m + p), (m + p) * (Lh + n), 2 * n * (m + p)
+            gbytes = 8.0 * (nf + 1) * (r + nFp)
+            print("affine law: ddmpc_prepare %.1f ms once per data set; ddmpc_step %.4f ms per batch, %.3e steps/s, %.0f GB/s of law = %.2f of "
+                  "the 8 TB/s HBM peak; max rel diff vs ddmpc_solve u %.2e" % (prep_ms, wms, B / wms * 1e3, gbytes * B / wms / 1e6,
+                                                                          gbytes * B / wms / 1e6 / 8000.0, float((w[0] - out[0]).abs().max() / out[0].abs().max())))

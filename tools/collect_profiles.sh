@@ -55,16 +55,9 @@ timeout -k 10 200 python tools/cfg5_time.py --warm > "$OUT/cfg5_time.log" 2>&1
 timeout -k 10 200 python tools/cfg5_time.py --robust --warm >> "$OUT/cfg5_time.log" 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg5_stats" -- \
     python tools/cfg5_time.py --steps 3 > "$OUT/cfg5_stats.log" 2>&1
-pass5() {  # name, counters...
-    local name=$1; shift
-    timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/cfg5_pmc_$name" -- \
-        python tools/cfg5_time.py --steps 2 > "$OUT/cfg5_pmc_$name.log" 2>&1
-    echo "[collect] cfg5 pmc $name done"
-}
-pass5 fetch FETCH_SIZE
-pass5 write WRITE_SIZE
-pass5 sq SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES SQ_WAVE_CYCLES
-timeout -k 10 200 python tools/rr_stamps.py > "$OUT/cfg5_phase_stamps.log" 2>&1
+# counters of the phase kernels (ddmpc_rr2.hpp, ddmpc_rr2_solve.hpp): separate --pmc passes, totals per kernel over three solves
+bash tools/pmc_rr2.sh "gpurun_out/$TAG/cfg5_pmc" sq sq2 tcc fetch write > "$OUT/cfg5_pmc_totals.txt" 2>&1
+timeout -k 10 600 python tools/nominal_fuzz.py --cases 96 --no-svd --large-only > "$OUT/nominal_fuzz.log" 2>&1
 timeout -k 10 400 python tools/config5_check.py --check 512 > "$OUT/cfg5_parity.log" 2>&1
 timeout -k 10 600 python tools/config5_check.py --robust --check 512 > "$OUT/cfg5size_robust_parity.log" 2>&1
 timeout -k 10 400 python tools/large_fuzz.py --cases 12 > "$OUT/large_kernel_fuzz.log" 2>&1

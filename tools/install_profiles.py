@@ -37,21 +37,12 @@ for name in ("cfg5_time.log", "cfg5_phase_stamps.log", "cfg5_parity.log", "cfg5s
         shutil.copy(os.path.join(src, name), os.path.join(dst, tag.replace("_final", "") + "_" + name))
 if glob.glob(os.path.join(src, "cfg5_stats/*/*_kernel_stats.csv")):
     shutil.copy(one("cfg5_stats/*/*_kernel_stats.csv"), os.path.join(dst, tag.replace("_final", "") + "_cfg5_kernel_stats.csv"))
-    for name in ("fetch", "write", "sq"):
-        f = one("cfg5_pmc_%s/*/*_counter_collection.csv" % name)
-        rows = [r for r in csv.DictReader(open(f)) if "ddmpc_nominal_rr_kernel" in r["Kernel_Name"]]
-        with open(os.path.join(dst, "%s_cfg5_pmc_%s.csv" % (tag.replace("_final", ""), name)), "w", newline="") as out:
-            wr = csv.DictWriter(out, fieldnames=list(rows[0].keys()))
-            wr.writeheader()
-            wr.writerows(rows)
-        acc = collections.defaultdict(list)
-        for r in rows:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        print("cfg5 pmc %-5s VGPR %s scratch %s B/lane: %s" % (name, rows[0]["VGPR_Count"], rows[0]["Scratch_Size"],
-              ", ".join("%s %.6g" % (k, sum(v) / len(v)) for k, v in acc.items())))
+    for name in ("cfg5_pmc_totals.txt", "nominal_fuzz.log"):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, tag.replace("_final", "") + "_" + name))
     for row in csv.DictReader(open(one("cfg5_stats/*/*_kernel_stats.csv"))):
-        if "ddmpc_nominal_rr_kernel" in row["Name"]:
-            print("cfg5 rocprof: %s calls, avg %.2f ms" % (row["Calls"], float(row["AverageNs"]) / 1e6))
+        if "rr" in row["Name"]:
+            print("cfg5 rocprof: %-60s %5s calls, avg %9.2f us" % (row["Name"][:60], row["Calls"], float(row["AverageNs"]) / 1e3))
 
 b = json.load(open(os.path.join(src, "bench.json")))
 print("bench: %.3e solves/s, %.4f ms/step, kernel %.4f ms, %.2f TFLOP/s = %.1f %% of peak" % (
