@@ -61,6 +61,17 @@ struct DevBuf {
     bytes = 0;
     HIP_TRY(hipMalloc(&p, need));
     bytes = need;
+    // debugging aid: DDMPC_POISON=1 fills every fresh device buffer with NaN bit patterns, so that a read of something no
+    // kernel has written shows up in the results of a single run instead of depending on what the allocator handed back
+    // (DDMPC_POISON=<byte>: that byte instead -- 63 gives small finite doubles, which flow through where a NaN is dropped by a comparison)
+    static const int poison = getenv("DDMPC_POISON") ? atoi(getenv("DDMPC_POISON")) : 0;
+    static const int only = getenv("DDMPC_POISON_ONLY") ? atoi(getenv("DDMPC_POISON_ONLY")) : -1;   // (just the n-th allocation of the process)
+    static int serial = 0;
+    const int id = serial++;
+    if (poison && (only < 0 || only == id)) {
+      HIP_TRY(hipMemset(p, poison == 1 ? 0xFF : poison, need));
+      if (only >= 0) fprintf(stderr, "[ddmpc] poisoned allocation #%d (%zu bytes)\n", id, need);
+    }
     return DDMPC_OK;
   }
   void release() {
@@ -153,7 +164,7 @@ struct ddmpc_handle {
   bool gain_step_last = false;             // ... the last solve was a step on the law (no w to form alpha from)
   bool rr2_x_pending = false;              // ... x = L^-T w of the last solve has not been formed yet (ddmpc_get_solution does it on demand)
   DevBuf d_rr2mt;                          // ... Minv of every 64 x 64 diagonal block of the two factors (ddmpc_rr2.hpp)
-  DevBuf d_perm, d_rr2d;                   // phase kernels (ddmpc_rr2.hpp): fixed-first component order [perm | iperm]; per instance
+  DevBuf d_perm, d_rr2d, d_rr2res;                   // phase kernels (ddmpc_rr2.hpp): fixed-first component order [perm | iperm]; per instance
                                            // [max diag of G | max diag of T | live chunks of G | live chunks of T]
   int nF = 0;                              // fixed components (hard constraints), nominal scheme
   int large_pipeline = DDMPC_PIPELINE_PHASES;   // DDMPC_OPT_LARGE_PIPELINE
@@ -561,7 +572,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_perm, &h->d_rr2d, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz, &h->d_gz, &h->d_gres, &h->d_zvirt};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_perm, &h->d_rr2d, &h->d_rr2res, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz, &h->d_gz, &h->d_gres, &h->d_zvirt};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -845,8 +856,11 @@ static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, 
   const long long m64G = (long long)((n16 + RR2_NB - 1) / RR2_NB) * RR2_NB * RR2_NB;       // Minv blocks of G's factor per instance
   const long long m64T = (long long)((nR16 + RR2_NB - 1) / RR2_NB) * RR2_NB * RR2_NB;      // ... and of T's factor, behind them
   int rc;
-  if ((rc = h->d_rr2d.ensure(B * 4 * sizeof(unsigned long long))) || (rc = h->d_rr2mt.ensure(B * (size_t)(m64G + m64T) * sizeof(double)))) return rc;
+  const long long rstride = (long long)n16 + 2;              // per instance: two words of retired-tile bits, then the residual diagonal
+  if ((rc = h->d_rr2d.ensure(B * 4 * sizeof(unsigned long long))) || (rc = h->d_rr2mt.ensure(B * (size_t)(m64G + m64T) * sizeof(double))) ||
+      (rc = h->d_rr2res.ensure(B * (size_t)rstride * sizeof(double)))) return rc;
   HIP_TRY(hipMemsetAsync(h->d_rr2d.p, 0, B * 4 * sizeof(unsigned long long), h->stream));
+  HIP_TRY(hipMemset2DAsync(h->d_rr2res.p, (size_t)rstride * sizeof(double), 0, 2 * sizeof(unsigned long long), B, h->stream));
   unsigned long long* dd = (unsigned long long*)h->d_rr2d.p;
   int* meta = (int*)h->d_rrmeta.p;
   const int* perm = (const int*)h->d_perm.p;
@@ -868,6 +882,7 @@ static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, 
   FG.ws = scratch; FG.stride = ndbl; FG.off = 0; FG.n16 = n16; FG.n_inst = nullptr; FG.n_stride = 0;
   FG.dmax = dd + 0; FG.d_stride = 4; FG.tol_rel = rank_tol; FG.skip = meta; FG.s_stride = mstride; FG.nflag = r;
   FG.live = dd + 2; FG.l_stride = 4; FG.m64 = (double*)h->d_rr2mt.p; FG.m64_stride = m64G + m64T;
+  FG.res = (double*)h->d_rr2res.p + 2; FG.res_stride = rstride; FG.dead = (unsigned long long*)h->d_rr2res.p; FG.dead_stride = rstride;
   cholesky(FG, n16);
   hipLaunchKernelGGL(rr2_meta_kernel, dim3((unsigned)B), dim3(256), 0, h->stream, meta, mstride, rv, r, nF, nR);
   if (nR > 0) {
@@ -883,7 +898,7 @@ static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, 
     FT.dmax = dd + 1; FT.d_stride = 4; FT.tol_rel = 1e-14; FT.skip = meta + rv; FT.s_stride = mstride; FT.nflag = nR;
     FT.live = dd + 3; FT.l_stride = 4; FT.m64 = (double*)h->d_rr2mt.p + m64G; FT.m64_stride = m64G + m64T;
     if (nR16 <= 384)            // a few panels: one launch, one workgroup per instance walks them (rr2_chol_small_kernel)
-      hipLaunchKernelGGL(rr2_chol_small_kernel<RR2_UT>, dim3((unsigned)B), dim3(256), 0, h->stream, FT);
+      hipLaunchKernelGGL(rr2_chol_small_kernel<2>, dim3((unsigned)B), dim3(256), 0, h->stream, FT);
     else
       cholesky(FT, nR16);
   }
@@ -940,7 +955,10 @@ static int rr2_solve_sequence(ddmpc_handle* h, const Rr2Solve& S, unsigned B, co
       HIP_TRY(hipFuncSetAttribute((const void*)rr2_hankel_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hk_lds));
   }
   auto hankel = [&](int slot, int pass) {
-    if (hk_ng) hipLaunchKernelGGL(rr2_hankel_mfma_kernel, dim3((unsigned)hk_ng, B), dim3(512), hk_lds, st, S, k, h->ud, h->yd, slot, pass, hk_ng);
+    // (RR2_NG workgroups per instance whatever hk_ng is: the consumers sum RR2_NG partial results, and a workgroup past the
+    //  last column group writes the zeros they expect -- launched with hk_ng < RR2_NG workgroups, short trajectories summed
+    //  whatever the allocator had left in the other slots)
+    if (hk_ng) hipLaunchKernelGGL(rr2_hankel_mfma_kernel, dim3((unsigned)RR2_NG, B), dim3(512), hk_lds, st, S, k, h->ud, h->yd, slot, pass, hk_ng);
     else hipLaunchKernelGGL(rr2_hankel_kernel, dim3(RR2_NG, B), dim3(512), 0, st, S, k, h->ud, h->yd, slot, pass);
   };
   hipLaunchKernelGGL(rr2_s1_kernel, dim3(B), dim3(RR2_TS), 0, st, S, k, RPs, up, yp);

@@ -31,6 +31,7 @@ constexpr int RR2_XCAP = 4096;    // doubles of LDS the Gram kernel stages traje
 constexpr int RR2_TLD = 17;       // doubles per row of a 16 x 16 tile in LDS (16 + 1: a column of a tile spreads over the banks;
                                   // with 16, 81 % of the panel kernel's LDS cycles were bank conflicts)
 constexpr int RR2_TSZ = 16 * RR2_TLD;
+constexpr double RR2_RETIRE = 1e-12;   // Rr2Chol::res
 constexpr int RR2_UT = 3;         // row tiles per wave in the Cholesky update kernel
 
 // D[a][b] += sum_k A[a][k] B[k][b] on v_mfma_f64_16x16x4: lane (l15, l4) passes A[a = l15][k = l4] and B[k = l4][b = l15];
@@ -55,6 +56,23 @@ struct Rr2Chol {
   long long l_stride;
   double* m64;                      // per instance: Minv = S L~^-1 of every 64 x 64 diagonal block, row-major, block k at m64 + 4096 k
   long long m64_stride;
+  // Early retirement of dependent rows (lock-step pipeline only; nullptr: off).  res[i] = G(i,i) - sum_{j done} L(i,j)^2, the
+  // residual diagonal of row i below the current block, kept up to date by the update launches.  It can only shrink, and
+  // (positive semi-definite matrix) the squares of the rest of row i of L sum to at most res[i]: once res[i] <= RR2_RETIRE * dmax
+  // for all 16 rows of a tile the tile is retired -- its remaining columns are written as zeros, later update launches pass
+  // over it and the panel step treats it as zero rows.  With exact data (BASELINE configs[4]: rank 312 of 608, the 176 output
+  // rows of the free steps all dependent) that is a third of the rows.
+  // RR2_RETIRE is NOT the pivot tolerance (1e-8): zeroing what is left of a row perturbs it by up to sqrt(res[i]), and a
+  // dependent row can sit at a genuine 1e-10 * dmax for a few panels before the column that completes it arrives (a SISO plant
+  // of the fuzz set: retiring at 1e-8 cost it four digits, 7e-13 -> 1.4e-8 in u).  At 1e-12 only rows at the rounding floor of
+  // their own residue go (numpy, configs[4] and that plant: nothing lies between 1e-14 and 1e-12), rows above it are simply
+  // carried to their pivot as before.
+  // dead: two words per instance, bit t = row tile t retired; the launches of block k read word k & 1 and write the other one
+  // (every workgroup of a launch sees the same set).
+  double* res;
+  long long res_stride;
+  unsigned long long* dead;
+  long long dead_stride;
 };
 
 __device__ __forceinline__ double rr2_bits_to_double(unsigned long long v) { return __longlong_as_double((long long)v); }
@@ -101,6 +119,10 @@ __global__ __launch_bounds__(256, 4) void rr2_gram_kernel(KParams P, const doubl
       for (int sl = 0; sl < RR2_SL; ++sl) acc[sl] = d4{0.0, 0.0, 0.0, 0.0};
       const int ca = (16 * at + l15 < nch) ? 16 * at + l15 : nch - 1;       // clamped: entries past nch are not stored
       const int cb = (16 * bt + l15 < nch) ? 16 * bt + l15 : nch - 1;
+      // (Staging with all of a thread's 16 loads of a chunk in flight at once, or in two rounds of eight, or issued ahead of
+      //  the previous chunk's MFMA loop: 562 / 562 / 710 us against 565 as it stands -- the first two spill 28 - 120 B, the
+      //  last 228 B: with the accumulators the kernel sits at 113 of the 128 registers four waves per SIMD leave.  The staging
+      //  is not what the launch waits for: knocked out, the lag sums alone take 413 us = 72 % of the matrix pipe at ~2.0 GHz.)
       for (int t0 = 0; t0 < c; t0 += TCH) {
         const int nt = (c - t0) < TCH ? (c - t0) : TCH;
         const int nload = nt + Ln - 1;
@@ -165,7 +187,7 @@ __global__ __launch_bounds__(256, 4) void rr2_gram_kernel(KParams P, const doubl
 constexpr int RR2_PLD = 18;         // doubles per staged panel row (16 + 2: the 16 rows of a tile land in different banks)
 // `group`: which 4 RT row tiles below the block this workgroup takes; `mi_ready`: Minv of the block is already in Mi (the fused
 // kernel below), else it is read from F.m64.  pl: 3 x 64 x RR2_PLD doubles, Mi: 10 tiles of RR2_TSZ (LDS).  All 256 threads.
-template <int RT>
+template <int RT, bool TRACK>
 __device__ __forceinline__ void rr2_update_body(const Rr2Chol& F, long long b, int c0, int n16, int group, bool mi_ready,
                                                 double (*pl)[64 * RR2_PLD], double (*Mi)[RR2_TSZ]) {
   if (c0 + RR2_NB >= n16) return;                                           // (workgroup-uniform) no row below the block
@@ -173,9 +195,17 @@ __device__ __forceinline__ void rr2_update_body(const Rr2Chol& F, long long b, i
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tp = c0 >> 4, nt = n16 >> 4;
-  const int tb = tp + 4;                                                    // first row tile below the block
-  if (tb + group * 4 * RT >= nt) return;                                    // (workgroup-uniform: no row tile left for this group)
-  const int t0 = tb + (group * 4 + wave) * RT;                              // first row tile of this wave (wave-uniform)
+  const int tb = tp + 4;                                                    // first row tile below the block (<= 63)
+  // the row tiles below the block that are not retired, dealt RT at a time to the waves of the groups
+  constexpr bool track = TRACK;                                             // (Rr2Chol::res)
+  const int par = (c0 / RR2_NB) & 1;
+  unsigned long long* deadw = track ? F.dead + b * F.dead_stride : nullptr;
+  const unsigned long long dead = track ? deadw[par] : 0ull;
+  if (track && group == 0 && tid == 0 && dead != 0ull) atomicOr(deadw + (par ^ 1), dead);      // the set only grows
+  unsigned long long cand = ((nt >= 64) ? ~0ull : ((1ull << nt) - 1ull)) & ~((1ull << tb) - 1ull) & ~dead;
+  if (__builtin_popcountll(cand) <= group * 4 * RT) return;                 // (workgroup-uniform: no row tile left for this group)
+  for (int q = (group * 4 + wave) * RT; q > 0 && cand != 0ull; --q) cand &= cand - 1ull;       // (wave-uniform)
+  int Ts[RT];
   unsigned long long live = F.live[b * F.l_stride] & ((1ull << tp) - 1ull);   // chunks in front of the panel (tp <= 63)
   // Column order inside a 16-column tile of the accumulators: lane l15 feeds panel row pi(l15) = 4 (l15 % 4) + l15 / 4 as the
   // A operand, so that register q of lane (l4, l15) holds panel column 4 l4 + q (not l4 + 4 q) of the tile: the FOUR registers
@@ -190,8 +220,10 @@ __device__ __forceinline__ void rr2_update_body(const Rr2Chol& F, long long b, i
   bool on[RT];
 #pragma unroll
   for (int s = 0; s < RT; ++s) {
-    on[s] = t0 + s < nt;
-    const int T = on[s] ? t0 + s : nt - 1;
+    on[s] = cand != 0ull;
+    const int T = on[s] ? __builtin_ctzll(cand) : nt - 1;
+    if (on[s]) cand &= cand - 1ull;
+    Ts[s] = T;
     mrow[s] = A + (size_t)128 * T * (T + 1) + (size_t)l15 * 16 * (T + 1) + 4 * l4;
   }
   d4 acc[RT][4];
@@ -266,7 +298,7 @@ __device__ __forceinline__ void rr2_update_body(const Rr2Chol& F, long long b, i
 #pragma unroll
   for (int s = 0; s < RT; ++s) {
     if (!on[s]) continue;
-    const int i = 16 * (t0 + s) + l15;
+    const int i = 16 * Ts[s] + l15;
     double* Ai = A + pk_row((size_t)i) + c0 + 4 * l4;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[s][ct] = *reinterpret_cast<const d4*>(Ai + 16 * ct) - acc[s][ct];
@@ -282,6 +314,25 @@ __device__ __forceinline__ void rr2_update_body(const Rr2Chol& F, long long b, i
           if (ct >= u) x[ct] = rr2_mfma(Mi[ct * (ct + 1) / 2 + u][pil * RR2_TLD + 4 * l4 + e], acc[s][u][e], x[ct]);
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<d4*>(Ai + 16 * ct) = x[ct];
+    if (track) {                                                            // residual diagonal of these 16 rows; retire the tile?
+      double ss = 0.0;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss = fma(x[ct][e], x[ct][e], ss);
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      double* res = F.res + b * F.res_stride;
+      const double d = ((c0 == 0) ? A[pk_row((size_t)i) + i] : res[i]) - ss;
+      if (l4 == 0) res[i] = d;
+      const double tol = RR2_RETIRE * rr2_bits_to_double(F.dmax[b * F.d_stride]);
+      if (__builtin_amdgcn_ballot_w64(d > tol) == 0ull) {                    // (wave-uniform) every row of the tile is at its rounding floor
+        const int rowlen = 16 * (Ts[s] + 1);
+        double* Ar = A + pk_row((size_t)i);
+        for (int col = c0 + RR2_NB + 4 * l4; col < rowlen; col += 16) *reinterpret_cast<d4*>(Ar + col) = d4{0.0, 0.0, 0.0, 0.0};
+        if (lane == 0) atomicOr(deadw + (par ^ 1), 1ull << Ts[s]);
+      }
+    }
   }
 }
 
@@ -291,7 +342,8 @@ __global__ __launch_bounds__(256, 2) void rr2_chol_update_kernel(Rr2Chol F, int 
   __shared__ __attribute__((aligned(16))) double Mi[10][RR2_TSZ];           // tile (t, u), u <= t, of Minv at index t (t + 1) / 2 + u, row-major (RR2_TLD)
   const long long b = blockIdx.y;
   const int n16 = F.n_inst ? ((F.n_inst[b * F.n_stride] + 15) & ~15) : F.n16;
-  rr2_update_body<RT>(F, b, c0, n16, (int)blockIdx.x, false, pl, Mi);
+  if (F.res != nullptr) rr2_update_body<RT, true>(F, b, c0, n16, (int)blockIdx.x, false, pl, Mi);
+  else rr2_update_body<RT, false>(F, b, c0, n16, (int)blockIdx.x, false, pl, Mi);
 }
 
 // Left-looking update of up to three tiles of the diagonal block by one wave (the tiles (S0,T0), (S1,T1), (S2,T2) of the block,
@@ -426,6 +478,14 @@ __device__ __forceinline__ void rr2_panel_body(const Rr2Chol& F, long long b, in
   const int tp = c0 >> 4, nt = n16 >> 4;
   const int n4 = (nt - tp) < 4 ? (nt - tp) : 4;                             // tiles across the panel
   const double tol = F.tol_rel * rr2_bits_to_double(F.dmax[b * F.d_stride]);
+  // retired row tiles of the block (Rr2Chol::res): their rows hold zeros from the column they were retired at and count as zero
+  const unsigned dmask = F.res ? (unsigned)((F.dead[b * F.dead_stride + ((c0 / RR2_NB) & 1)] >> tp) & ((1ull << n4) - 1ull)) : 0u;
+  if (dmask == (1u << n4) - 1u) {                                           // (workgroup-uniform) nothing left to factor
+    if (tid < 16 * n4 && c0 + tid < F.nflag) F.skip[b * F.s_stride + c0 + tid] = 1;
+    double* m64 = F.m64 + b * F.m64_stride + (size_t)(c0 / RR2_NB) * (RR2_NB * RR2_NB);
+    for (int e = tid; e < RR2_NB * RR2_NB; e += nthr) m64[e] = 0.0;
+    return;
+  }
   // ---- the diagonal block, updated, into LDS (strict upper triangle of the diagonal tiles zero, absent tiles zero)
   for (int e = tid; e < 10 * RR2_TSZ; e += nthr) Dt[e / RR2_TSZ][e % RR2_TSZ] = 0.0;
   __syncthreads();
@@ -435,6 +495,16 @@ __device__ __forceinline__ void rr2_panel_body(const Rr2Chol& F, long long b, in
   else rr2_diag_update<3, 2, 3, 3, -1, -1>(A, Dt, F.live[b * F.l_stride], c0, n4);
   for (int e = tid; e < 4 * RR2_TSZ; e += nthr) Ms[e / RR2_TSZ][e % RR2_TSZ] = 0.0;
   __syncthreads();
+  if (dmask != 0u) {                                                        // (workgroup-uniform)
+    for (int e = tid; e < 10 * RR2_TSZ; e += nthr) {
+      const int ti = e / RR2_TSZ;
+      int s = 0;
+      while ((s + 1) * (s + 2) / 2 <= ti) ++s;
+      const int t = ti - s * (s + 1) / 2;
+      if (((dmask >> s) | (dmask >> t)) & 1u) Dt[ti][e % RR2_TSZ] = 0.0;
+    }
+    __syncthreads();
+  }
   for (int t = 0; t < n4; ++t) {
     if (wave == 0) rr2_tile_factor(Dt[t * (t + 1) / 2 + t], Ms[t], Dinv + 16 * t, tol, skipl + 16 * t);
     __syncthreads();
@@ -556,7 +626,7 @@ __global__ __launch_bounds__(256, 2) void rr2_chol_small_kernel(Rr2Chol F) {
     __syncthreads();                                                        // the block's factor, Minv (LDS) and the live bits are in place
     const int nbelow = (n16 >> 4) - (c0 >> 4) - 4;
     for (int g = 0; g * 4 * RT < nbelow; ++g) {
-      rr2_update_body<RT>(F, b, c0, n16, g, true, reinterpret_cast<double (*)[64 * RR2_PLD]>(&DtMs[0][0]), Mi);
+      rr2_update_body<RT, false>(F, b, c0, n16, g, true, reinterpret_cast<double (*)[64 * RR2_PLD]>(&DtMs[0][0]), Mi);
       __syncthreads();
     }
   }

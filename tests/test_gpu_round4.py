@@ -257,3 +257,23 @@ def test_config5_against_the_extended_precision_golden_solutions(gpu):
     uo = res["one_workgroup"][0]
     eo = max(np.max(np.abs(uo[b] - z["optimal_u"][k])) / np.max(np.abs(z["optimal_u"][k])) for k, b in enumerate(inst))
     assert eo < TOL_U, eo
+
+
+@pytest.mark.gpu
+def test_results_do_not_depend_on_what_the_allocator_hands_back():
+    """Every work buffer is written before it is read: the same solves with fresh device buffers pre-filled with two different
+    byte patterns (DDMPC_POISON, ddmpc_api.hip DevBuf::ensure) and not pre-filled give bit-identical outputs.  (A short
+    trajectory used to leave three of the eight partial-sum slots of H(H'x) unwritten and summed: correct on a fresh box,
+    where device memory comes back zeroed, off by up to 1e-8 after other controllers had used the memory.)"""
+    import os, subprocess, sys
+    digests = []
+    for poison in ("", "63", "1"):
+        env = dict(os.environ)
+        env.pop("DDMPC_POISON", None)
+        if poison:
+            env["DDMPC_POISON"] = poison
+        out = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_poison_probe.py")], env=env, capture_output=True,
+                             text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert out.returncode == 0, out.stdout + out.stderr
+        digests.append([ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1] == digests[2], digests
