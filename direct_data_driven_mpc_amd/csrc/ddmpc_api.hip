@@ -164,6 +164,8 @@ struct ddmpc_handle {
   bool gain_step_last = false;             // ... the last solve was a step on the law (no w to form alpha from)
   bool rr2_x_pending = false;              // ... x = L^-T w of the last solve has not been formed yet (ddmpc_get_solution does it on demand)
   DevBuf d_rr2mt;                          // ... Minv of every 64 x 64 diagonal block of the two factors (ddmpc_rr2.hpp)
+  DevBuf d_gpre;                          // Gram tiles of ddmpc_gram_tiles_kernel (structured Gram, m + p != 4), see gram_pre_launch
+  bool gram_pre = false, gpre_valid = false;
   DevBuf d_perm, d_rr2d, d_rr2res;                   // phase kernels (ddmpc_rr2.hpp): fixed-first component order [perm | iperm]; per instance
                                            // [max diag of G | max diag of T | live chunks of G | live chunks of T]
   int nF = 0;                              // fixed components (hard constraints), nominal scheme
@@ -462,15 +464,15 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   // <= ~1e-12 with errors ~1e-12 (never flagged); the random-plant sweep misses the cost bar from ~1.3e-10 on and errors
   // stay below ~30x the residual (tools/auto_flag_calib_cpu.py, profiles/r03_refine_calib.log)
   k.refine_res = std::pow(10.0, -0.1 * DDMPC_REFINE_RES_DEFAULT);
-  if (p.gram_mode == DDMPC_GRAM_STRUCTURED && k.nch != 4) {
-    delete h;
-    return fail(DDMPC_ERR_UNSUPPORTED, "DDMPC_GRAM_STRUCTURED needs m + p == 4 (got %d); use DDMPC_GRAM_AUTO", k.nch);
-  }
   if (p.gram_mode != DDMPC_GRAM_AUTO && p.gram_mode != DDMPC_GRAM_DENSE && p.gram_mode != DDMPC_GRAM_STRUCTURED) {
     delete h;
     return fail(DDMPC_ERR_INVALID, "unknown gram_mode %d", p.gram_mode);
   }
+  // Structured Gram (AUTO / STRUCTURED): inside the cold-solve kernel for four channels, from ddmpc_gram_tiles_kernel ahead of
+  // it for any other count (gram_pre below; the kernel's own fallback for those stays the dense product)
   k.gram_dense = (p.gram_mode == DDMPC_GRAM_DENSE || k.nch != 4) ? 1 : 0;
+  k.gpre = nullptr;
+  k.gpre_stride = 0;
 
   const int rows_needed = k.rE + 1;
   const KernelChoice* kc = nullptr;
@@ -536,6 +538,8 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
     delete h;
     return fail(DDMPC_ERR_UNSUPPORTED, "trajectory too long for LDS staging: needs %zu bytes of LDS", h->lds_bytes);
   }
+  h->gram_pre = p.gram_mode != DDMPC_GRAM_DENSE && k.nch != 4 &&
+                gram_tiles_lds_doubles(k.xs_len, k.r, k.nch, h->kc.NT) * sizeof(double) <= 150 * 1024;
   if (p.n * k.nch > h->kc.max_past) {       // (implied by L >= n and the instance table; kept as a guard of the LDS aliasing)
     delete h;
     return fail(DDMPC_ERR_UNSUPPORTED, "past window of n (m+p) = %d entries exceeds the %d the kernel stages", p.n * k.nch, h->kc.max_past);
@@ -572,7 +576,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_perm, &h->d_rr2d, &h->d_rr2res, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz, &h->d_gz, &h->d_gres, &h->d_zvirt};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_gpre, &h->d_perm, &h->d_rr2d, &h->d_rr2res, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz, &h->d_gz, &h->d_gres, &h->d_zvirt};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -635,6 +639,7 @@ int ddmpc_set_data(ddmpc_handle* h, const double* u_d, const double* y_d, int me
   h->solved = false;
   h->prepared = false;
   h->large_gain_ready = false;
+  h->gpre_valid = false;
   return DDMPC_OK;
 }
 
@@ -656,6 +661,28 @@ static int next_refine_epoch(ddmpc_handle* h) {
 
 // large_mode (ROBUST controllers beyond the register-resident kernels only): 0 whole solve, 1 the data-dependent part alone
 // (ddmpc_prepare), 2 a solve on what that left in the workspace (ddmpc_step) -- see ddmpc_large_solve_kernel.
+// Structured Gram for channel counts other than four: the Gram tiles of `nb` instances (data at ud / yd) into slots b0 .. of
+// the handle's buffer, and the pointers into `kq`.  cacheable: the data set is the handle's (h->ud / h->yd) -- one launch serves
+// every cold-kernel launch until the data may have changed (ddmpc_set_data, ddmpc_solve, ddmpc_solve_from_host, ddmpc_prepare
+// clear gpre_valid; ddmpc_step and ddmpc_get_solution work on the data ddmpc_prepare / the last solve saw).
+static int gram_pre_launch(ddmpc_handle* h, KParams& kq, const double* ud, const double* yd, size_t nb, size_t b0, bool cacheable) {
+  if (!h->gram_pre) return DDMPC_OK;
+  const int NT = h->kc.NT;
+  const long long stride = (long long)(NT * (NT + 1) / 2) * 256;
+  int rc;
+  if ((rc = h->d_gpre.ensure((size_t)h->batch * (size_t)stride * sizeof(double)))) return rc;
+  kq.gpre = (const double*)h->d_gpre.p + (long long)b0 * stride;
+  kq.gpre_stride = stride;
+  if (cacheable && h->gpre_valid) return DDMPC_OK;
+  const size_t lds = gram_tiles_lds_doubles(h->kp.xs_len, h->kp.r, h->kp.nch, NT) * sizeof(double);
+  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_gram_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(ddmpc_gram_tiles_kernel, dim3((unsigned)nb), dim3(256), lds, h->stream, h->kp, NT, ud, yd,
+                     (double*)h->d_gpre.p + (long long)b0 * stride, stride);
+  HIP_TRY(hipGetLastError());
+  if (cacheable) h->gpre_valid = true;
+  return DDMPC_OK;
+}
+
 static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
                        int32_t* status, int32_t* iters, double* lfac = nullptr, const int* only = nullptr,
                        const KParams* kp_override = nullptr, bool want_ws = true, double* lfacT = nullptr, int large_mode = 0) {
@@ -706,6 +733,7 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
   // variant in a short persistent launch (it reads one counter word and leaves when nothing was flagged).  The decision
   // is taken per solve: nothing about a data set is remembered, so borrowed device data may change between solves.
   KParams kq = kp_override ? *kp_override : h->kp;
+  if ((rc = gram_pre_launch(h, kq, h->ud, h->yd, (size_t)h->batch, 0, true))) return rc;
   const int mode = (lfac != nullptr || kq.lam == 0.0) ? DDMPC_REFINE_OFF : kq.refine;
   if (mode == DDMPC_REFINE_ALWAYS) {
     hipLaunchKernelGGL(h->kc.fn2r, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
@@ -1118,6 +1146,7 @@ static int solve_impl(ddmpc_handle* h, const double* u_past, const double* y_pas
 
 int ddmpc_solve(ddmpc_handle* h, const double* u_past, const double* y_past, double* u_opt, double* cost,
                 int32_t* status, int32_t* iters, int mem) {
+  if (h) h->gpre_valid = false;           // (borrowed device data may have changed since the last call)
   return solve_impl(h, u_past, y_past, u_opt, cost, status, iters, mem, &launch_cold_plain);
 }
 
@@ -1126,6 +1155,7 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
   if (!h || !u_d || !y_d || !u_past || !y_past || !u_opt || !cost || !status)
     return fail(DDMPC_ERR_INVALID, "null argument");
   if (h->batch > 0x7fffffffLL) return fail(DDMPC_ERR_INVALID, "batch too large for one launch");
+  h->gpre_valid = false;
   if (h->large) {                         // no chunked cold launches at this size: plain upload + solve
     int rcs = ddmpc_set_data(h, u_d, y_d, DDMPC_MEM_HOST);
     return rcs ? rcs : ddmpc_solve(h, u_past, y_past, u_opt, cost, status, iters, DDMPC_MEM_HOST);
@@ -1185,12 +1215,19 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
       rcl = fail(DDMPC_ERR_HIP, "ddmpc_solve_from_host: upload of chunk %zu failed", k);
       break;
     }
-    hipLaunchKernelGGL(always ? h->kc.fn2r : h->kc.fn2, dim3((unsigned)nb), dim3(64 * h->kc.W), h->lds_bytes, h->stream, kchunk,
+    KParams kck = kchunk;
+    if ((rcl = gram_pre_launch(h, kck, (const double*)(dud + b0 * su), (const double*)(dyd + b0 * sy), nb, b0, false))) break;
+    hipLaunchKernelGGL(always ? h->kc.fn2r : h->kc.fn2, dim3((unsigned)nb), dim3(64 * h->kc.W), h->lds_bytes, h->stream, kck,
                        (const double*)(dud + b0 * su), (const double*)(dyd + b0 * sy), (const double*)(dup + b0 * sup),
                        (const double*)(dyp + b0 * syp), duo + b0 * suo, dco + b0, (int*)(dst + b0), (int*)(dit + b0),
                        (double*)nullptr, (signed char*)nullptr, (unsigned long long*)nullptr, (double*)nullptr,
                        (double*)nullptr, rflag ? rflag + b0 : (int*)nullptr, (const int*)nullptr, 0LL, rflag ? rflag + B : (int*)nullptr);
     if (hipGetLastError() != hipSuccess) rcl = fail(DDMPC_ERR_HIP, "ddmpc_solve_from_host: launch of chunk %zu failed", k);
+  }
+  if (rcl == DDMPC_OK && h->gram_pre) {           // every chunk's Gram tiles are in place: they serve the launches below
+    h->gpre_valid = true;
+    h->ud = dud; h->yd = dyd;
+    rcl = gram_pre_launch(h, kchunk, dud, dyd, B, 0, true);
   }
   if (rcl == DDMPC_OK && rflag) {
     KParams kq = kchunk;
@@ -1229,6 +1266,7 @@ int ddmpc_prepare(ddmpc_handle* h) {
   if (!h->have_data) return fail(DDMPC_ERR_NOT_READY, "ddmpc_set_data must be called before ddmpc_prepare");
   if (h->batch > 0x7fffffffLL) return fail(DDMPC_ERR_INVALID, "batch too large for one launch");
   if (h->prepared) return DDMPC_OK;
+  h->gpre_valid = false;
   if (h->large_nominal) {
     // no affine law at this size, but everything that depends on the data alone -- Gram, its rank-revealing factor, the
     // reduced normal matrix and its factor, 70 % of a solve -- is formed once and kept in the workspace; ddmpc_step and
@@ -1289,6 +1327,7 @@ int ddmpc_prepare(ddmpc_handle* h) {
     HIP_TRY(hipMemsetAsync(h->d_need.p, 0, (B + 1) * sizeof(int), h->stream));
     KParams kprobe = k0;
     kprobe.epoch = h->prep_epoch;
+    if ((rc = gram_pre_launch(h, kprobe, h->ud, h->yd, B, 0, true))) return rc;
     hipLaunchKernelGGL(h->kc.fn2, dim3((unsigned)B), dim3(64 * h->kc.W), h->lds_bytes, h->stream, kprobe, h->ud, h->yd,
                        (const double*)pu, (const double*)py, (double*)h->d_uopt.p, (double*)h->d_cost.p, (int*)h->d_status.p,
                        (int*)nullptr, (double*)nullptr, (signed char*)nullptr, (unsigned long long*)nullptr, (double*)nullptr,
@@ -1338,6 +1377,7 @@ int ddmpc_prepare(ddmpc_handle* h) {
       } else {
         if ((rc = h->d_act.ensure(B * k.rE))) return rc;
         kr.epoch = h->prep_epoch;
+        if ((rc = gram_pre_launch(h, kr, h->ud, h->yd, B, 0, true))) return rc;
         hipLaunchKernelGGL(h->kc.fn2r, dim3((unsigned)(B < 768 ? B : 768)), dim3(64 * h->kc.W), h->lds_bytes, h->stream, kr, h->ud,
                            h->yd, (const double*)pu, (const double*)py, (double*)h->d_uopt.p, (double*)h->d_cost.p,
                            (int*)h->d_prep_status.p, (int*)nullptr, (double*)h->d_beta.p, (signed char*)h->d_act.p,
@@ -1767,7 +1807,7 @@ int ddmpc_cost_model(ddmpc_handle* h, double* flops_per_solve, double* bytes_per
   // (DESIGN.md "Roofline accounting").  Dense Gram: symmetric H H', multiply-add = 2
   // flops, half the entries.  Structured Gram: nch^2*(L+n) base dot products of length c
   // plus the 4-flop sliding-window update of every entry of the lower triangle.
-  const double gram = k.gram_dense ? r * r * c : 2.0 * k.nch * k.nch * (double)k.Ln * c + 4.0 * r * r / 2.0;
+  const double gram = (k.gram_dense && !h->gram_pre) ? r * r * c : 2.0 * k.nch * k.nch * (double)k.Ln * c + 4.0 * r * r / 2.0;
   if (flops_per_solve) *flops_per_solve = gram + r * r * r / 3.0 + 2.0 * r * r;
   // compulsory HBM traffic: trajectories in, past window in, optimal_u + cost + status out
   if (bytes_per_solve)

@@ -323,6 +323,133 @@ __global__ void ddmpc_tail_past_kernel(long long batch, int N, int m, int p, int
   if (i < npu) up[b * npu + i] = u_d[(b * N + (N - n)) * m + i];
   else yp[b * npy + (i - npu)] = y_d[(b * N + (N - n)) * p + (i - npu)];
 }
+__host__ __device__ inline size_t gram_tiles_lds_doubles(int xs_len, int r, int nch, int NT) {   // LDS of ddmpc_gram_tiles_kernel
+  return (size_t)xs_len + (size_t)r * nch + 2 + (size_t)16 * NT;           // xs | ctab | offA, offB
+}
+// ---------------------------------------------------------------------------------------------------------------
+// G = H H' of every instance for the register-resident kernels, through the Hankel structure, for ANY channel count
+// (hankel_matrix.py:5-53 is generic in the channel count; the in-kernel lag-block + tile-walk Gram of ddmpc_cold2.hpp needs
+// m + p == 4: its walk moves a whole 16 x 16 tile by 16 rows = 4 time steps, and for a channel count that does not divide 16
+// a shift by 16 rows is not a shift in time).  Rows in the kernel's order rho = (time, channel), x[rho + i nch] = H[rho][i]:
+//     K[rho + nch][sig + nch] = K[rho][sig] + x[rho + c nch] x[sig + c nch] - x[rho] x[sig]                (window slides by one)
+// so only the entries with sig < nch need the full length-c sum -- the first nch rows of tile column 0 of the dense product --
+// and every other entry is two multiply-adds on top of its neighbour one time step up the diagonal.  One workgroup per
+// instance: trajectory into LDS as the cold-solve kernel holds it, those rows on the matrix pipe (tile I on wave I mod 4),
+// then the chains.  Output in the accumulator layout of the cold-solve kernel (KParams::gpre): register j of lane (l4, l15) of
+// tile (I, J), I >= J, holds K[16 J + l4 + 4 j][16 I + l15]; diagonal tiles are filled on both sides; rows past r are not written
+// (the kernel's fix-up overwrites them).  LDS: gram_tiles_lds_doubles().  grid = batch, 256 threads.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ddmpc_gram_tiles_kernel(KParams P, int NT, const double* __restrict__ u_d,
+                                                               const double* __restrict__ y_d, double* __restrict__ gpre,
+                                                               long long gstride) {
+  extern __shared__ __attribute__((aligned(16))) double gt_lds[];
+  double* xs = gt_lds;
+  double* ctab = gt_lds + P.xs_len;                                         // ctab[rho * nch + b] = K[rho][b], b < nch
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nch = P.nch, c = P.c, r = P.r, Ln = P.Ln;
+  {
+    const double* ud = u_d + b * (long long)P.N * P.m;
+    const double* yd = y_d + b * (long long)P.N * P.p;
+    const int nu = P.N * P.m, ny = P.N * P.p;
+    for (int i = tid; i < nu; i += 256) {
+      const int t = i / P.m, ch = i - t * P.m;
+      xs[t * nch + ch] = ud[i];
+    }
+    for (int i = tid; i < ny; i += 256) {
+      const int t = i / P.p, ch = i - t * P.p;
+      xs[t * nch + P.m + ch] = yd[i];
+    }
+    for (int i = P.N * nch + tid; i < P.xs_len; i += 256) xs[i] = 0.0;
+  }
+  __syncthreads();
+  {
+    // First nch rows of tile column 0 on v_mfma_f64_4x4x4 (four independent 4x4x4 products per instruction, ~16 clk: a
+    // quarter of a 16x16x4 -- of whose 16 output rows only nch would be used, 2 of 16 for a SISO plant).  Block blk of the
+    // instruction for (row group sg, tile t): D[i][j] = K[4 sg + i][16 t + 4 blk + j]; lane = 16 k + 4 blk + i holds
+    // A[i][k] = H[4 sg + i][i0 + k], lane = 16 k + 4 blk + j holds B[k][j] = H[16 t + 4 blk + j][i0 + k] (the same A in all four
+    // blocks); D[i][j] comes back in lane 16 i + 4 blk + j (layout probed in tools/mfma_f64_4x4_probe.hip).
+    constexpr int TW = 5, SG = 4;                                           // tiles per wave (NT <= 17 on four waves), row groups (nch <= 16)
+    const int nsg = (nch + 3) >> 2;
+    double acc[SG][TW];
+#pragma unroll
+    for (int g = 0; g < SG; ++g)
+#pragma unroll
+      for (int t = 0; t < TW; ++t) acc[g][t] = 0.0;
+    const int kq = lane >> 4, ij = lane & 3;
+    const int cfull = c & ~3;
+    const double* pa = xs + kq * nch + ij;                                  // + 4 sg: A of row group sg
+    const double* pb = xs + kq * nch + 16 * wave + (lane & 15);             // + 64 t: B of tile wave + 4 t
+    auto kstep = [&](bool kok) __attribute__((always_inline)) {
+      double av[SG], bv[TW];
+#pragma unroll
+      for (int g = 0; g < SG; ++g) av[g] = (g < nsg && kok) ? pa[4 * g] : 0.0;
+#pragma unroll
+      for (int t = 0; t < TW; ++t) bv[t] = (wave + 4 * t < NT && kok) ? pb[64 * t] : 0.0;
+#pragma unroll
+      for (int g = 0; g < SG; ++g)
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+          if (g < nsg && wave + 4 * t < NT) acc[g][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[g], bv[t], acc[g][t], 0, 0, 0);   // (wave-uniform)
+    };
+    for (int i0 = 0; i0 < cfull; i0 += 4, pa += 4 * nch, pb += 4 * nch) kstep(true);
+    if (cfull < c) kstep(cfull + kq < c);
+#pragma unroll
+    for (int g = 0; g < SG; ++g)
+#pragma unroll
+      for (int t = 0; t < TW; ++t) {
+        const int sig = 4 * g + (lane >> 4), rho = 16 * (wave + 4 * t) + (lane & 15);
+        if (g < nsg && wave + 4 * t < NT && sig < nch && rho < r) ctab[rho * nch + sig] = acc[g][t];
+      }
+  }
+  // The chains: chain (rho0, b), rho0 = d nch + a, runs through the entries (sig, rho) = (b + k nch, rho0 + k nch), rho < r.
+  // The lanes of a wave take consecutive rho0 of one b: at a given step they read broadcast values x[sig], x[sig + c nch] and
+  // consecutive x[rho], x[rho + c nch], and their 16 stores into a tile of the output fall into four cache lines.  A thread
+  // takes the chains rho0 = t and r - 1 - t of its b: Ln + 1 entries whatever t is.
+  // Measured per 4096 instances of ~136 rows (SISO / 3x2 / 2x1 / 4x4 plants; phases knocked out one at a time): the launch
+  // 197 / 307 / 199 / 327 us, of which the lag sums 63 / 66 / 46 / 124, the chains 90 / 150 / 86 / 133 (their stores 22 / 78 / 24 /
+  // 58), staging and launch 44 / 91 / 67 / 70 -- no single bound; the bytes alone are 84 us.  Variants that lost: one chain
+  // per thread (idle threads), tile rows gathered in LDS and written as whole lines (300 - 330 us: more instructions than
+  // the write transactions they save), a row-major output (the four 8-byte loads per tile it needs in the cold-solve kernel
+  // cost that kernel 116 B of scratch), 16x16x4 MFMAs for the lag sums (2 of 16 output rows used for a SISO plant).
+  // Offset of entry (sig, rho) in the output = offA[rho] + offB[sig]: tile (rho / 16, sig / 16) at (I (I + 1) / 2 + J) * 256,
+  // inside it double 4 * (16 * (sig % 4) + rho % 16) + (sig % 16) / 4.
+  int* offA = reinterpret_cast<int*>(ctab + ((r * nch + 1) & ~1));
+  int* offB = offA + 16 * NT;
+  for (int i = tid; i < 16 * NT; i += 256) {
+    const int T = i >> 4, l = i & 15;
+    offA[i] = (T * (T + 1) / 2) * 256 + 4 * l;
+    offB[i] = T * 256 + ((l & 3) << 6) + (l >> 2);
+  }
+  __syncthreads();
+  const int cn = c * nch, half = (r + 1) >> 1;
+  double* G = gpre + b * gstride;
+  for (int e = tid; e < half * nch; e += 256) {
+    const int bb = e / half, t = e - bb * half;
+#pragma unroll 1
+    for (int part = 0; part < 2; ++part) {
+      int rho = part == 0 ? t : r - 1 - t;
+      if (part == 1 && rho == t) break;                                     // (odd r: the middle chain once)
+      int sig = bb;
+      if (rho < sig) continue;                                              // (lag 0, a < b: the pair (b, a) covers it)
+      double s = ctab[rho * nch + bb];
+      if (rho - sig >= 16) {                                                // never in a diagonal tile
+        for (; rho < r; rho += nch, sig += nch) {
+          G[offA[rho] + offB[sig]] = s;
+          s += xs[rho + cn] * xs[sig + cn] - xs[rho] * xs[sig];
+        }
+      } else {
+        for (; rho < r; rho += nch, sig += nch) {
+          G[offA[rho] + offB[sig]] = s;
+          if ((rho >> 4) == (sig >> 4) && rho != sig) G[offA[sig] + offB[rho]] = s;      // diagonal tile: both sides
+          s += xs[rho + cn] * xs[sig + cn] - xs[rho] * xs[sig];
+        }
+      }
+    }
+  }
+}
+
 // flags of the probe solve (their own buffer, same stamp) joined into the flags of the factor-export solve; word `batch` of
 // both buffers is the largest stamp that flagged anything
 __global__ void ddmpc_or_flags_kernel(long long batch, int epoch, const int* __restrict__ probe, int* __restrict__ flags) {

@@ -212,7 +212,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
                                            double* __restrict__ beta_ws, signed char* __restrict__ act_ws,
                                            unsigned long long* __restrict__ stamps, double* __restrict__ lfac,
                                            double* __restrict__ lfacT, int* __restrict__ refine_flag,
-                                           int* __restrict__ refine_count) {
+                                           int* __restrict__ refine_count, const double* __restrict__ gpre) {
   using TM = TileMap2<NT, W>;
   using WT = WaveTiles2<NT, W, WAVE>;
   using LD = Lds2<NT, W>;
@@ -451,7 +451,17 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         });
       }
     };
-    if (P.gram_dense) {
+    if (gpre != nullptr) {
+      // ---- G = H H' formed ahead of the launch (KParams::gpre: the Hankel-structured Gram for any channel count)
+      // (one 32-byte load per lane and tile.  Four 8-byte loads per tile from a row-major matrix -- cheaper to produce -- moved
+      //  the register allocation of the whole kernel: 168 VGPRs and 116 B of scratch for <9,4> instead of 162 and none)
+      static_for<WT::tab.n>([&](auto K) __attribute__((always_inline)) {
+        constexpr int I = WT::tab.I[K], J = WT::tab.J[K];
+        acc[TM::slot(I, J)] = *reinterpret_cast<const d4*>(gpre + (I * (I + 1) / 2 + J) * 256 + 4 * lane);
+      });
+      stamp();   // 2
+      stamp();   // 3
+    } else if (P.gram_dense) {
       // ---- G = H H' by fp64 MFMA over the implicit Hankel operand (k-major: rows of tile column J are the A operand)
       static_for<TM::MAXS>([&](auto S) __attribute__((always_inline)) { acc[S] = d4{0.0, 0.0, 0.0, 0.0}; });
       const int c = P.c;
@@ -1393,7 +1403,8 @@ __global__ __launch_bounds__(64 * W, DDMPC_MIN_WAVES(NT, W)) void ddmpc_cold_sol
   static_for<W>([&](auto WV) {
     if (wave == WV)
       wave_body2<NT, W, WV, REF>(P, sm, up, yp, uo, cost + b, status + b, it, bw, aw, st, lf, lft,
-                                 refine_flag ? refine_flag + b : nullptr, REF ? nullptr : refine_count);
+                                 refine_flag ? refine_flag + b : nullptr, REF ? nullptr : refine_count,
+                                 P.gpre ? P.gpre + b * P.gpre_stride : nullptr);
   });
   if constexpr (REF) __syncthreads();          // persistent grid: LDS is reused by the next instance
   }

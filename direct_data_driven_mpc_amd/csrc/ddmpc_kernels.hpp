@@ -53,7 +53,7 @@ struct KParams {
   int npu;          // n * m              length of u_past
   int convex;
   int max_iter;
-  int gram_dense;   // 1: dense MFMA Gram, 0: structured (nch == 4 only)
+  int gram_dense;   // 1: dense MFMA Gram, 0: structured (in the kernel for nch == 4, else from `gpre`)
   int xs_len;       // doubles reserved for xflat in LDS
   double lam;       // lamb_alpha * eps_max (0 for nominal)
   double lamb_sigma;
@@ -69,6 +69,12 @@ struct KParams {
   int epoch;            // launch counter of the handle (AUTO refinement: flags / last-flagged stamp carry it, nothing is cleared)
   int dense_w;          // 1: dense weighting matrices -> lam * W^-1 is the full [RP][RP] matrix `dmat`
   const double* dmat;   //    (shared by the batch, zero outside the weighted components), tabd D0 = D1 = 0
+  // Structured Gram for channel counts other than 4: G = H H' of every instance comes from ddmpc_gram_tiles_kernel
+  // (ddmpc_aux_kernels.hpp) in the accumulator layout of the cold-solve kernel -- tile (I, J), I >= J, at
+  // gpre + b * gpre_stride + (I (I + 1) / 2 + J) * 256, double 4 * lane + j of it = register j of that lane -- and the
+  // Gram phase of the kernel is one 32-byte load per lane and tile.  nullptr: the kernel forms G itself.
+  const double* gpre;
+  long long gpre_stride;
 };
 
 template <int N, class F>

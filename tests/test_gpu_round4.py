@@ -277,3 +277,54 @@ def test_results_do_not_depend_on_what_the_allocator_hands_back():
         assert out.returncode == 0, out.stdout + out.stderr
         digests.append([ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][-1])
     assert digests[0] == digests[1] == digests[2], digests
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,p", [(1, 1), (2, 1), (1, 2), (3, 2), (2, 3), (3, 3), (4, 4), (5, 3)])
+def test_structured_gram_for_any_channel_count(m, p):
+    """hankel_matrix.py:5-53 is generic in the channel count, and so is the Hankel-structured Gram now: for m + p != 4 the
+    register-resident kernels take G = H H' from ddmpc_gram_tiles_kernel (first rows by MFMA, the rest by the sliding-window
+    recurrence) instead of the dense r^2 c product.  Both Gram modes against the full-space oracle and against each other,
+    ROBUST with the slack box (active-set iterations reload the tiles) and without, through ddmpc_solve, the chunked
+    ddmpc_solve_from_host and ddmpc_prepare / ddmpc_step."""
+    from direct_data_driven_mpc_amd.harness import generate_batch
+    rng = np.random.default_rng(40 + 7 * m + p)
+    ns = n = 3
+    nch = m + p
+    Lh = max(2 * n, 132 // nch - n)                       # ~130 rows: the 9-tile instance of the kernels (or the one below it)
+    N = (m + 1) * (Lh + 2 * n) + 150
+    A = rng.normal(size=(ns, ns)); A *= 0.85 / max(abs(np.linalg.eigvals(A)))
+    plant = dict(A=A, B=rng.normal(size=(ns, m)), C=rng.normal(size=(p, ns)), D=np.zeros((p, m)), eps_max=0.002)
+    B = 5
+    d = generate_batch(range(B), N=N, plant=plant)
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    for slack in ("none", "convex"):
+        spec = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=2.0 * np.eye(p * Lh), R=0.05 * np.eye(m * Lh), u_s=rng.uniform(-0.5, 0.5, m),
+                          y_s=rng.uniform(-0.5, 0.5, p), robust=True, eps_max=0.002, lamb_alpha=20.0, lamb_sigma=500.0, c=1.0,
+                          slack=slack, tec=True)
+        res = {}
+        for mode in (L.GRAM_DENSE, L.GRAM_STRUCTURED, L.GRAM_AUTO):
+            with BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=2.0, R=0.05, u_s=spec.u_s, y_s=spec.y_s, batch=B, controller_type=L.ROBUST,
+                              slack_type=L.SLACK_CONVEX if slack == "convex" else L.SLACK_NONE, eps_max=0.002, lamb_alpha=20.0,
+                              lamb_sigma=500.0, c=1.0, gram_mode=mode) as eng:
+                assert "cold" in eng.kernel_name()
+                eng.set_refinement("always")
+                eng.set_data(d["u_d"], d["y_d"])
+                u, cost, status, iters = eng.solve(up, yp)
+                uh = eng.solve_from_host(d["u_d"], d["y_d"], up, yp)
+                eng.set_data(d["u_d"], d["y_d"])
+                uw = eng.step(up, yp)
+                flops, _ = eng.cost_model()
+            res[mode] = (u, cost, status, iters, flops)
+            assert np.array_equal(uh[0], u) and np.array_equal(uh[2], status)
+            assert np.max(np.abs(uw[0] - u)) <= 1e-8 * np.max(np.abs(u)) and np.array_equal(uw[2], status)
+            for b in range(B):
+                sol = orc.solve_fullspace(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
+                assert L.STATUS_STRINGS[int(status[b])] == sol.status == "optimal"
+                assert np.max(np.abs(u[b] - sol.optimal_u)) / max(np.max(np.abs(sol.optimal_u)), 1e-3) < 1e-8, (mode, b)
+                assert abs(cost[b] - sol.cost) <= 1e-8 * max(abs(sol.cost), 1e-6), (mode, b)
+        dn, st = res[L.GRAM_DENSE], res[L.GRAM_STRUCTURED]
+        assert np.array_equal(dn[3], st[3])                                    # the same active-set iterations in both modes
+        assert np.max(np.abs(dn[0] - st[0])) <= 1e-9 * np.max(np.abs(dn[0]))
+        assert np.array_equal(res[L.GRAM_AUTO][0], st[0])                      # AUTO is the structured Gram for every channel count
+        assert dn[4] > 1.5 * st[4]                                             # the dense Gram is charged r^2 c flops
