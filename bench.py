@@ -269,6 +269,21 @@ def other_configs_device(jobs, dev, steps=10):
             wms = timed(lambda: eng.step(up, yp, *w), steps)
             rec["warm_step"] = dict(ms_per_step=wms, value=B / (wms * 1e-3), unit="control steps/s", prepare_ms=prep_ms,
                                     max_rel_diff_vs_cold_u=float((w[0] - res[0]).abs().max() / res[0].abs().max()))
+            # ... and as an affine law of the past window (DDMPC_OPT_LARGE_AFFINE_LAW): one launch per step that streams the law
+            # of every instance once -- n (m+p) + 1 columns for the r rows of z and the 2 n (m+p) rows of the feasibility residual
+            eng.set_large_affine_law(True)
+            torch.cuda.synchronize(); tp = time.perf_counter()
+            eng.prepare()
+            torch.cuda.synchronize(); lprep_ms = (time.perf_counter() - tp) * 1e3
+            wl = eng.step(up, yp)
+            lms = timed(lambda: eng.step(up, yp, *wl), max(steps, 20))
+            nf, r = n * (m + p), (m + p) * (c5["L"] + n)
+            law_bytes = 8.0 * (nf + 1) * (r + 2 * nf)
+            gbps = law_bytes * B / (lms * 1e-3) / 1e9
+            rec["affine_law_step"] = dict(ms_per_step=lms, value=B / (lms * 1e-3), unit="control steps/s", prepare_ms=lprep_ms,
+                                          law_bytes_per_instance=law_bytes,
+                                          roofline={"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS},
+                                          max_rel_diff_vs_cold_u=float((wl[0] - res[0]).abs().max() / res[0].abs().max()))
         out.append(rec)
         eng.close()
         del eng, ud, yd, up, yp

@@ -57,6 +57,22 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
     python tools/cfg5_time.py --steps 3 > "$OUT/cfg5_stats.log" 2>&1
 # counters of the phase kernels (ddmpc_rr2.hpp, ddmpc_rr2_solve.hpp): separate --pmc passes, totals per kernel over three solves
 bash tools/pmc_rr2.sh "gpurun_out/$TAG/cfg5_pmc" sq sq2 tcc fetch write > "$OUT/cfg5_pmc_totals.txt" 2>&1
+# the affine-law step (rr2_gain_step_kernel): bytes per launch
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d "$OUT/cfg5_law_$C" -- python tools/cfg5_time.py --warm --steps 2 > "$OUT/cfg5_law_$C.log" 2>&1
+done
+python - "$OUT" > "$OUT/cfg5_law_pmc.txt" <<'PY'
+import csv, glob, sys
+out = sys.argv[1]
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(out + "/cfg5_law_%s/*/*_counter_collection.csv" % c)
+    rows = [r for r in csv.DictReader(open(f[0])) if "rr2_gain_step_kernel" in r["Kernel_Name"]] if f else []
+    v = [float(r["Counter_Value"]) for r in rows]
+    if v: print("rr2_gain_step_kernel %s: %d launches, mean %.1f KB per launch%s" % (c, len(v), sum(v) / len(v), " (x2 on gfx950 = %.1f MB)" % (2 * sum(v) / len(v) / 1e3) if c == "FETCH_SIZE" else ""))
+PY
+timeout -k 10 300 python tools/rr2_check.py --time > "$OUT/rr2_check.log" 2>&1
+timeout -k 10 300 python tools/gram_modes_time.py > "$OUT/gram_modes.log" 2>&1
+timeout -k 10 200 python tools/cfg5_two_halves.py > "$OUT/cfg5_two_halves.log" 2>&1
 timeout -k 10 600 python tools/nominal_fuzz.py --cases 96 --no-svd --large-only > "$OUT/nominal_fuzz.log" 2>&1
 timeout -k 10 400 python tools/config5_check.py --check 512 > "$OUT/cfg5_parity.log" 2>&1
 timeout -k 10 600 python tools/config5_check.py --robust --check 512 > "$OUT/cfg5size_robust_parity.log" 2>&1

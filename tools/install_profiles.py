@@ -37,7 +37,7 @@ for name in ("cfg5_time.log", "cfg5_phase_stamps.log", "cfg5_parity.log", "cfg5s
         shutil.copy(os.path.join(src, name), os.path.join(dst, tag.replace("_final", "") + "_" + name))
 if glob.glob(os.path.join(src, "cfg5_stats/*/*_kernel_stats.csv")):
     shutil.copy(one("cfg5_stats/*/*_kernel_stats.csv"), os.path.join(dst, tag.replace("_final", "") + "_cfg5_kernel_stats.csv"))
-    for name in ("cfg5_pmc_totals.txt", "nominal_fuzz.log"):
+    for name in ("cfg5_pmc_totals.txt", "nominal_fuzz.log", "cfg5_law_pmc.txt", "rr2_check.log", "gram_modes.log", "cfg5_two_halves.log"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, tag.replace("_final", "") + "_" + name))
     for row in csv.DictReader(open(one("cfg5_stats/*/*_kernel_stats.csv"))):

@@ -34,4 +34,12 @@ for name in sys.argv[2:]:
     for k in sorted(acc):
         n = len(cnt[k])
         print(name, "%-32s dispatches %3d  totals: " % (k, n) + "  ".join("%s=%.4g" % (c, v) for c, v in sorted(acc[k].items())))
+    if name in ("fetch", "write"):      # per solve (three solves in the run), in MB; FETCH_SIZE doubled (gfx950: 128-byte requests tallied at 64 B)
+        key, mul = ("FETCH_SIZE", 2.0) if name == "fetch" else ("WRITE_SIZE", 1.0)
+        tot = 0.0
+        for k in sorted(acc):
+            mb = mul * acc[k][key] / 3.0 / 1e3
+            tot += mb
+            print("%s-MB-per-solve %-32s %9.1f" % (name, k, mb))
+        print("%s-MB-per-solve %-32s %9.1f" % (name, "TOTAL", tot))
 PY
