@@ -70,9 +70,11 @@ extern "C" {
 #define DDMPC_MEM_HOST   0
 #define DDMPC_MEM_DEVICE 1
 
-#define DDMPC_GRAM_AUTO       0
+#define DDMPC_GRAM_AUTO       0     /* = STRUCTURED                                      */
 #define DDMPC_GRAM_DENSE      1     /* H H' by fp64 MFMA over the implicit Hankel operand */
-#define DDMPC_GRAM_STRUCTURED 2     /* Hankel sliding-window recurrence                 */
+#define DDMPC_GRAM_STRUCTURED 2     /* Hankel sliding-window recurrence (hankel_matrix.py:5-53 is generic in the channel count
+                                       and so is this: inside the cold-solve kernel for m + p == 4, by a launch ahead of it
+                                       for any other count)                              */
 
 /* ddmpc_get_solution selectors: the `.value` of the reference's cp.Variables
  * (controller.py:434-445) */
@@ -149,8 +151,10 @@ int ddmpc_device_count(void);
  * kinds).  Beyond that, controllers run on single-workgroup kernels that keep their
  * matrices in a global workspace (a Gram-route solve plus refinement with exact Hankel products; throughput: see
  * profiles/README.md): ROBUST ones on ddmpc_large_solve_kernel (same outputs, status, iterations, ddmpc_get_solution),
- * NOMINAL ones on the rank-revealing kernel (ddmpc_get_solution: ubar / ybar from its z, alpha = H'x from the vector it
- * exports).  No affine law is formed at that size (ddmpc_get_gain is DDMPC_ERR_UNSUPPORTED); the warm path there is
+ * NOMINAL ones on the rank-revealing route -- phase kernels over the whole batch by default, the one-workgroup kernels on
+ * request (DDMPC_OPT_LARGE_PIPELINE) -- with ddmpc_get_solution: ubar / ybar from its z, alpha = H'x from the vector it
+ * exports.  By default no affine law is formed at that size (ddmpc_get_gain is DDMPC_ERR_UNSUPPORTED unless a NOMINAL
+ * controller asked for it with DDMPC_OPT_LARGE_AFFINE_LAW); the warm path there is
  * factor reuse -- ddmpc_prepare forms what depends on the data and the weights alone (NOMINAL: Gram, its rank-revealing
  * factor, the reduced normal matrix and its factor; ROBUST: Gram + lam D, the factor of the columns outside the slack
  * box, the Schur complement of the boxed block), ddmpc_step and the per-step closed loop solve on what it kept, with

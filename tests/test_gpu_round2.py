@@ -163,6 +163,10 @@ def test_bench_self_launches_two_ranks_and_gathers_bit_exactly(gpu, tmp_path):
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 192 and rec["config"]["non_optimal_instances"] == 0
+    # what the process group itself saw (round 4): two ranks, gloo in this rehearsal, the device each one bound
+    dinfo = rec["distributed"]
+    assert dinfo["world_size"] == 2 and dinfo["backend"] == "gloo" and [r["rank"] for r in dinfo["ranks"]] == [0, 1]
+    assert all(r["device"] == 0 and r["name"] for r in dinfo["ranks"])
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch-per-gpu", "192",
                           "--dump-gathered", str(g1)] + common, capture_output=True, text=True, timeout=900, env=env)
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
@@ -190,6 +194,7 @@ def test_bench_rccl_branch_at_world_size_one(gpu, tmp_path):
     rec = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["config"]["global_batch"] == 160 and rec["config"]["non_optimal_instances"] == 0
     assert "RCCL branch forced" in rec["config"]["parallelism"]
+    assert rec["distributed"]["world_size"] == 1 and rec["distributed"]["backend"] == "nccl" and rec["distributed"]["ranks"][0]["device"] == 0
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dump-gathered", str(gp)] + common,
                          capture_output=True, text=True, timeout=900, env=env)
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
