@@ -1659,6 +1659,7 @@ int ddmpc_closed_loop(ddmpc_handle* h, const ddmpc_plant* plant, int32_t n_steps
   if (!h || !plant || !x || !u_past || !y_past || !w || !u_sys || !y_sys || !status)
     return fail(DDMPC_ERR_INVALID, "null argument");
   if (!h->have_data) return fail(DDMPC_ERR_NOT_READY, "ddmpc_set_data must be called before ddmpc_closed_loop");
+  if (!h->prepared) h->gpre_valid = false;      // (borrowed device data may have changed since the last solve; a kept law pins it)
   if (n_steps <= 0 || n_mpc_step <= 0) return fail(DDMPC_ERR_INVALID, "n_steps and n_mpc_step must be positive");
   const ddmpc_params& p = h->prm;
   if (n_mpc_step > p.L) return fail(DDMPC_ERR_INVALID, "n_mpc_step must not exceed the prediction horizon L");

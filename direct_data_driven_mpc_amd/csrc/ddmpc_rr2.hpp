@@ -421,12 +421,16 @@ __device__ __forceinline__ void rr2_diag_update(const double* A, double (*Dt)[RR
 // rank-1 update of the whole tile is a single MFMA whose operands are row c of the tile itself -- it sits in register c / 4 of
 // the lanes with l4 = c % 4, exactly the lanes that feed contraction slot c % 4 -- scaled by 1 / sqrt(pivot).  No LDS round
 // trip on the chain (psd_tile_factor: two per column, ~550 cycles; here ~200).  Pivots <= tol are skipped (column zeroed).
-// Leaves L in the lower triangle of Dg (zeros above), Ms[k][m] = Mt[m][k] with Mt = S L~^-1, Dinv, the pivot flags.
+// The inverse rides along in a second accumulator R that starts as the identity: row c of Mt = S L~^-1 is row c of R over
+// the pivot's square root, and the rows below lose u (x) that row -- one more MFMA per column, independent of the first.
+// (Until round 4's end Mt came from a forward substitution by 16 lanes afterwards: 120 dependent LDS reads + FMAs per tile,
+// about as long as the factorisation itself.)
+// Leaves L in the lower triangle of Dg (zeros above), Ms[k][m] = Mt[m][k] (rows of skipped pivots zero), Dinv, the pivot flags.
 __device__ __forceinline__ void rr2_tile_factor(double* Dg, double* Ms, double* Dinv, double tol, int* skipout) {
   const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
-  d4 acc;
+  d4 acc, rr;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) acc[q] = Dg[(l4 + 4 * q) * RR2_TLD + l15];
+  for (int q = 0; q < 4; ++q) { acc[q] = Dg[(l4 + 4 * q) * RR2_TLD + l15]; rr[q] = (l4 + 4 * q == l15) ? 1.0 : 0.0; }
   static_for<16>([&](auto cc) __attribute__((always_inline)) {
     constexpr int c = cc();
     constexpr int q = c >> 2, slot = c & 3;
@@ -440,25 +444,13 @@ __device__ __forceinline__ void rr2_tile_factor(double* Dg, double* Ms, double* 
     const double inv = sk ? 0.0 : fma(0.5 * y1, ye1, y1);
     const bool mine = l4 == slot;
     const double u = (mine && l15 >= c) ? acc[q] * inv : 0.0;                // u_i = D[c][i] / sqrt(pivot), i = l15 >= c
-    if (mine) Dg[l15 * RR2_TLD + c] = u;                                          // L(i, c); zeros above the diagonal
+    const double y = mine ? rr[q] * inv : 0.0;                               // Mt[c][j] = R[c][j] / sqrt(pivot), j = l15
+    if (mine) { Dg[l15 * RR2_TLD + c] = u; Ms[l15 * RR2_TLD + c] = y; }     // L(i, c), zeros above the diagonal; Ms[k = j][m = c]
     acc = rr2_mfma(-u, u, acc);
+    rr = rr2_mfma(-u, y, rr);
     if (lane == 0) { skipout[c] = sk ? 1 : 0; Dinv[c] = inv; }
   });
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                     // in-wave hand-off through LDS
-  __builtin_amdgcn_wave_barrier();
-  if (lane < 16) {                                     // column `lane` of L~^-1 by forward substitution, rows of skipped pivots zero
-    double y[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      double sacc = (c == lane) ? 1.0 : 0.0;
-#pragma unroll
-      for (int c1 = 0; c1 < c; ++c1) sacc -= Dg[c * RR2_TLD + c1] * y[c1];
-      y[c] = sacc * Dinv[c];
-    }
-#pragma unroll
-    for (int c = 0; c < 16; ++c) Ms[lane * RR2_TLD + c] = y[c];          // Ms[k = lane][m = c] = Mt[c][lane]
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -486,6 +478,13 @@ __device__ __forceinline__ void rr2_panel_body(const Rr2Chol& F, long long b, in
     for (int e = tid; e < RR2_NB * RR2_NB; e += nthr) m64[e] = 0.0;
     return;
   }
+#ifdef RR2_PANEL_PROBE
+  long long tp_[12]; int np_ = 0;
+#define RR2_STAMP() do { if (tid == 0 && np_ < 12) tp_[np_++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RR2_STAMP() do {} while (0)
+#endif
+  RR2_STAMP();
   // ---- the diagonal block, updated, into LDS (strict upper triangle of the diagonal tiles zero, absent tiles zero)
   for (int e = tid; e < 10 * RR2_TSZ; e += nthr) Dt[e / RR2_TSZ][e % RR2_TSZ] = 0.0;
   __syncthreads();
@@ -505,9 +504,11 @@ __device__ __forceinline__ void rr2_panel_body(const Rr2Chol& F, long long b, in
     }
     __syncthreads();
   }
+  RR2_STAMP();     // 1: block in LDS
   for (int t = 0; t < n4; ++t) {
     if (wave == 0) rr2_tile_factor(Dt[t * (t + 1) / 2 + t], Ms[t], Dinv + 16 * t, tol, skipl + 16 * t);
     __syncthreads();
+    if (t == 0) RR2_STAMP();   // 2: first tile factored
     // tiles below the diagonal tile: X(s,t) = P(s,t) Mt'   (X'[m][i] = sum_k Mt[m][k] P'[k][i])
     if (wave >= 1 && t + wave < n4) {
       double* Pst = Dt[(t + wave) * (t + wave + 1) / 2 + t];
@@ -544,6 +545,7 @@ __device__ __forceinline__ void rr2_panel_body(const Rr2Chol& F, long long b, in
   // With it the rows below the block are ONE multiplication X = P Minv' of independent MFMA chains (part 2) instead of a
   // forward substitution through four dependent tile solves, and a substitution with the finished factor advances 64 rows
   // per step (ddmpc_rr2_solve.hpp).  The Dt tiles of the diagonal (their factor is no longer needed in LDS form) are reused.
+  RR2_STAMP();     // 3: block factored
   for (int e = tid; e < 4 * 256; e += nthr) {
     const int t = e >> 8, a = (e >> 4) & 15, bb = e & 15;
     Mi[t * (t + 1) / 2 + t][a * RR2_TLD + bb] = Ms[t][bb * RR2_TLD + a];
@@ -568,6 +570,7 @@ __device__ __forceinline__ void rr2_panel_body(const Rr2Chol& F, long long b, in
     }
     __syncthreads();
   }
+  RR2_STAMP();     // 4: Minv formed
   // ---- the block's own factor, Minv, pivot flags, live-chunk bits
   for (int e = tid; e < 10 * 256; e += nthr) {
     const int ti = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
@@ -594,6 +597,11 @@ __device__ __forceinline__ void rr2_panel_body(const Rr2Chol& F, long long b, in
     }
     F.live[b * F.l_stride] |= bits;
   }
+#ifdef RR2_PANEL_PROBE
+  RR2_STAMP();     // 5: stores issued
+  if (tid == 0 && b == 300) printf("panel c0=%d: to LDS %lld, tile0 %lld, rest of block %lld, Minv %lld, stores %lld (x10 ns)\n", c0,
+                                   tp_[1] - tp_[0], tp_[2] - tp_[1], tp_[3] - tp_[2], tp_[4] - tp_[3], tp_[5] - tp_[4]);
+#endif
 }
 
 __global__ __launch_bounds__(256) void rr2_chol_panel_kernel(Rr2Chol F, int c0) {
