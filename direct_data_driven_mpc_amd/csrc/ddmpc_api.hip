@@ -208,13 +208,16 @@ int ddmpc_device_count(void) {
 //   w, terminal window: ybar = y_s (:615,621), sigma = w - y_s boxed (:659,674)          -> D = 1/lamb_sigma | 0
 //   w, free prediction steps: q (ybar - y_s)^2 + lamb_sigma sigma^2 (:710,716), boxed   -> D = 1/q + 1/lamb_sigma | 1/q
 //   nominal scheme: no sigma (:536-538); ybar rows behave like ubar rows with weight q.
-// Inverse of a symmetric positive definite n x n matrix (row-major) by Cholesky; false if not SPD.
+// Inverse of a symmetric positive definite n x n matrix (row-major) by Cholesky; false if not SPD -- numerically: a pivot
+// below 1e-13 of the largest diagonal entry is a singular (or indefinite) matrix whose "inverse" would be rounding noise.
 static bool spd_inverse(std::vector<double>& a, int n) {
   std::vector<double> l((size_t)n * n, 0.0);
+  double dmax = 0.0;
+  for (int j = 0; j < n; ++j) dmax = std::max(dmax, a[(size_t)j * n + j]);
   for (int j = 0; j < n; ++j) {
     double d = a[(size_t)j * n + j];
     for (int k = 0; k < j; ++k) d -= l[(size_t)j * n + k] * l[(size_t)j * n + k];
-    if (!(d > 0.0)) return false;
+    if (!(d > 1e-13 * dmax)) return false;
     const double dj = std::sqrt(d);
     l[(size_t)j * n + j] = dj;
     for (int i = j + 1; i < n; ++i) {
@@ -343,16 +346,30 @@ static int upload_params(ddmpc_handle* h) {
       std::vector<double> a((size_t)nn * nn);
       for (int i = 0; i < nn; ++i)
         for (int j = 0; j < nn; ++j) a[(size_t)i * nn + j] = 0.5 * (W[(size_t)i * ld + j] + W[(size_t)j * ld + i]);
-      if (!spd_inverse(a, nn))
-        return fail(DDMPC_ERR_UNSUPPORTED, "%s must be positive definite on the free prediction steps (HIP path)",
-                    pass == 0 ? "R" : "Q");
-      for (int i = 0; i < nn; ++i)
-        for (int j = 0; j < nn; ++j) {
-          const int ri = (p.n + i / nc) * k.nch + (pass == 0 ? 0 : p.m) + i % nc;
-          const int rj = (p.n + j / nc) * k.nch + (pass == 0 ? 0 : p.m) + j % nc;
-          dm[(size_t)ri * RP + rj] = a[(size_t)i * nn + j];     // (robust y rows: + 1/lamb_sigma on the diagonal via tabd,
-                                                                  //  switched off for a sigma at its bound)
-        }
+      // Components whose row (= column) of the weighting matrix is entirely zero are unweighted, exactly like a zero on the
+      // diagonal of a DIAG matrix (inv_weight): they leave the block that is inverted and get 1/w = DDMPC_UNWEIGHTED on the
+      // diagonal.  This is the singular case that can be served with the Gram matrix in its own coordinates; a null space
+      // that is NOT spanned by coordinate axes would need the Gram tiles rotated per instance (a penalty on a skew direction
+      // cancels catastrophically in the Cholesky) and stays unsupported.
+      std::vector<int> keep;
+      for (int i = 0; i < nn; ++i) {
+        bool any = false;
+        for (int j = 0; j < nn && !any; ++j) any = a[(size_t)i * nn + j] != 0.0;
+        if (any) keep.push_back(i);
+      }
+      const int nk = (int)keep.size();
+      std::vector<double> ak((size_t)nk * nk);
+      for (int i = 0; i < nk; ++i)
+        for (int j = 0; j < nk; ++j) ak[(size_t)i * nk + j] = a[(size_t)keep[i] * nn + keep[j]];
+      if (nk > 0 && !spd_inverse(ak, nk))
+        return fail(DDMPC_ERR_UNSUPPORTED, "%s must be positive definite on the free prediction steps once its all-zero rows and "
+                    "columns (unweighted components) are set aside (HIP path)", pass == 0 ? "R" : "Q");
+      auto row_of = [&](int i) { return (p.n + i / nc) * k.nch + (pass == 0 ? 0 : p.m) + i % nc; };
+      for (int i = 0; i < nn; ++i) { const int ri = row_of(i); dm[(size_t)ri * RP + ri] = DDMPC_UNWEIGHTED; }
+      for (int i = 0; i < nk; ++i)
+        for (int j = 0; j < nk; ++j)
+          dm[(size_t)row_of(keep[i]) * RP + row_of(keep[j])] = ak[(size_t)i * nk + j];     // (robust y rows: + 1/lamb_sigma on the
+                                                                  //  diagonal via tabd, switched off for a sigma at its bound)
     }
     if ((rc = h->d_dmat.ensure(dm.size() * sizeof(double)))) return rc;
     HIP_TRY(hipMemcpy(h->d_dmat.p, dm.data(), dm.size() * sizeof(double), hipMemcpyHostToDevice));

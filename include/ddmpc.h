@@ -64,8 +64,10 @@ extern "C" {
                                        utilities/controller/controller_creation.py:125-127) */
 #define DDMPC_WEIGHT_DIAG   1       /* Q = diag(q[0..p*L)), R = diag(r[0..m*L)); entries >= 0 (a zero weight leaves the
                                        component free) */
-#define DDMPC_WEIGHT_DENSE  2       /* Q [p*L, p*L], R [m*L, m*L] row-major, symmetric, positive definite on the free
-                                       prediction steps (controller.py:121-124,708-710); every slack mode */
+#define DDMPC_WEIGHT_DENSE  2       /* Q [p*L, p*L], R [m*L, m*L] row-major, symmetric; on the free prediction steps positive
+                                       definite once all-zero rows / columns (components without a weight, as zeros on the
+                                       diagonal of a DIAG matrix) are set aside (controller.py:121-124,708-710); every slack
+                                       mode.  A null space that is not spanned by coordinate axes: DDMPC_ERR_UNSUPPORTED */
 
 #define DDMPC_MEM_HOST   0
 #define DDMPC_MEM_DEVICE 1
