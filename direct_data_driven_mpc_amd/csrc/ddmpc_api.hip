@@ -487,7 +487,8 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   }
   // Structured Gram (AUTO / STRUCTURED): inside the cold-solve kernel for four channels, from ddmpc_gram_tiles_kernel ahead of
   // it for any other count (gram_pre below; the kernel's own fallback for those stays the dense product)
-  k.gram_dense = (p.gram_mode == DDMPC_GRAM_DENSE || k.nch != 4) ? 1 : 0;
+  // (two channels ride on the four-channel scheme inside the kernel: a SISO trajectory is two interleaved four-channel ones)
+  k.gram_dense = (p.gram_mode == DDMPC_GRAM_DENSE || (k.nch != 4 && k.nch != 2)) ? 1 : 0;
   k.gpre = nullptr;
   k.gpre_stride = 0;
 
@@ -555,7 +556,7 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
     delete h;
     return fail(DDMPC_ERR_UNSUPPORTED, "trajectory too long for LDS staging: needs %zu bytes of LDS", h->lds_bytes);
   }
-  h->gram_pre = p.gram_mode != DDMPC_GRAM_DENSE && k.nch != 4 &&
+  h->gram_pre = p.gram_mode != DDMPC_GRAM_DENSE && k.nch != 4 && k.nch != 2 &&
                 gram_tiles_lds_doubles(k.xs_len, k.r, k.nch, h->kc.NT) * sizeof(double) <= 150 * 1024;
   if (p.n * k.nch > h->kc.max_past) {       // (implied by L >= n and the instance table; kept as a guard of the LDS aliasing)
     delete h;

@@ -490,7 +490,15 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
     } else {
       // ---- structured Gram (nch == 4): lag blocks by v_mfma_f64_4x4x4, then 2 MFMAs per tile down every tile diagonal
       //      (the Hankel sliding-window recurrence in matrix form, see ddmpc_kernels.hpp) -- k-major tiles.
-      const int c = P.c, Ln = P.Ln;
+      // Two channels (SISO plants) ride on the same code: row rho = 2 t + ch of H is row rho of a FOUR-channel Hankel matrix
+      // over the same flat trajectory (pseudo time t / 2, pseudo channel 2 (t % 2) + ch), whose columns step by 4 entries where
+      // H's step by 2: H = [the pseudo matrix over x, columns 0, 2, 4, .. | the pseudo matrix over x + 2, columns 1, 3, ..], so
+      // G is the sum of two four-channel Gram matrices -- every phase below runs over nsub trajectories `x + 2 sub` with
+      // csub(sub) columns each and adds up (lag blocks: one more trip of the k-loop; base tiles: the window terms of both;
+      // walks: 2 MFMAs per tile and trajectory).
+      const int nsub = (nch == 2) ? 2 : 1;
+      const int Ln = (nch == 2) ? (P.Ln + 1) >> 1 : P.Ln;
+      auto csub = [&](int sub) __attribute__((always_inline)) { return (nch == 2) ? ((P.c + 1 - sub) >> 1) : P.c; };
       {
         // Every wave takes ALL lag groups (a half of them with 8 waves) over a quarter of the time range: the A operand
         // of a k-step is shared by the groups (x[t + 4 g + blk], g + u = const), so a trip of 4 k-steps needs
@@ -509,13 +517,17 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         if (iter == 1) {
           double cacc[MAXG];
           static_for<MAXG>([&](auto gi) __attribute__((always_inline)) { cacc[gi()] = 0.0; });
+#pragma nounroll
+          for (int sub = 0; sub < nsub; ++sub) {
+          const int c = csub(sub);
+          const double* xb = xs + 2 * sub;
           const int cfull = c & ~3;
           const int nks = cfull >> 2;                       // full k-steps (4 time steps each)
           const int kw = (nks + TS - 1) / TS;
           const int ks0 = tsl * kw;
           const int ks1 = (ks0 + kw) < nks ? (ks0 + kw) : nks;
-          const double* pB = xs + 4 * (kq + 4 * ks0) + ij;                               // B[k][j] = x_j[t0 + k]
-          const double* pA = xs + 4 * (kq + blk + 4 * ks0) + ij + 16 * (gsl * MAXG);     // A[i][k] = x_i[t0 + k + 4g + blk]
+          const double* pB = xb + 4 * (kq + 4 * ks0) + ij;                               // B[k][j] = x_j[t0 + k]
+          const double* pA = xb + 4 * (kq + blk + 4 * ks0) + ij + 16 * (gsl * MAXG);     // A[i][k] = x_i[t0 + k + 4g + blk]
           // 4 k-steps per trip: 4 + (MAXG + 3) loads, then 4 MAXG MFMAs (a second operand set in flight under the MFMAs
           // costs 60 spilled VGPRs in the Cholesky that follows: slower overall)
           auto ld = [&](double (&bv)[4], double (&av)[MAXG + 3]) __attribute__((always_inline)) {
@@ -553,6 +565,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
               cacc[gi()] = __builtin_amdgcn_mfma_f64_4x4x4f64(kok ? a1 : 0.0, bv, cacc[gi()], 0, 0, 0);
             });
           }
+          }   // sub
           static_for<MAXG>([&](auto gi) __attribute__((always_inline)) {
             PP[((tsl * GS + gsl) * MAXG + gi()) * 64 + lane] = cacc[gi()];
           });
@@ -591,17 +604,21 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
             del = del >= Ln ? Ln - 1 : del;                // padded rows: cleared in the fix-up
             const int pa = neg ? l4 : l3, pb = neg ? l3 : l4;
             const int nl = neg ? lo : j;                   // window terms: the earlier of the two time indices
-            const double* qa0 = xs + 4 * del + pa;         // x_pa[del + .]
-            const double* qa1 = qa0 + 4 * c;
-            const double* qb0 = xs + pb;
-            const double* qb1 = qb0 + 4 * c;
             double t = ctab[del * 16 + pa * 4 + pb];
-            const double e0 = qa1[0] * qb1[0] - qa0[0] * qb0[0];
-            const double e1 = qa1[4] * qb1[4] - qa0[4] * qb0[4];
-            const double e2 = qa1[8] * qb1[8] - qa0[8] * qb0[8];
-            t += (0 < nl) ? e0 : 0.0;
-            t += (1 < nl) ? e1 : 0.0;
-            t += (2 < nl) ? e2 : 0.0;
+#pragma nounroll
+            for (int sub = 0; sub < nsub; ++sub) {
+              const int c = csub(sub);
+              const double* qa0 = xs + 2 * sub + 4 * del + pa;         // x_pa[del + .]
+              const double* qa1 = qa0 + 4 * c;
+              const double* qb0 = xs + 2 * sub + pb;
+              const double* qb1 = qb0 + 4 * c;
+              const double e0 = qa1[0] * qb1[0] - qa0[0] * qb0[0];
+              const double e1 = qa1[4] * qb1[4] - qa0[4] * qb0[4];
+              const double e2 = qa1[8] * qb1[8] - qa0[8] * qb0[8];
+              t += (0 < nl) ? e0 : 0.0;
+              t += (1 < nl) ? e1 : 0.0;
+              t += (2 < nl) ? e2 : 0.0;
+            }
             return t;
           };
           const d4 v = d4{base(0), base(1), base(2), base(3)};
@@ -616,12 +633,19 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         if constexpr (TM::tab.wave[d] == WAVE && d + 1 < NT) {
           const double* pb = xs + 4 * l4 + l15;          // rows of tile column J = t: the A operand (k side)
           const double* pa = pb + 16 * d;                // rows of tile row I = d + t: the B operand (i side)
+          const int c = csub(0);
 #pragma nounroll
           for (int t = 0; t + 1 < NT - d; ++t) {
             const double a1 = pa[0], b1 = pb[0], a2 = pa[4 * c], b2 = pb[4 * c];
+            double a3 = 0.0, b3 = 0.0, a4 = 0.0, b4 = 0.0;
+            if (nsub == 2) { const int c1 = csub(1); a3 = pa[2]; b3 = pb[2]; a4 = pa[2 + 4 * c1]; b4 = pb[2 + 4 * c1]; }   // (kernel-uniform)
             static_for<NT - d - 1>([&](auto T) __attribute__((always_inline)) {
               if (t == T) {
-                const d4 v = __builtin_amdgcn_mfma_f64_16x16x4f64(-b1, a1, acc[TM::slot(d + T, T)], 0, 0, 0);
+                d4 v = __builtin_amdgcn_mfma_f64_16x16x4f64(-b1, a1, acc[TM::slot(d + T, T)], 0, 0, 0);
+                if (nsub == 2) {
+                  v = __builtin_amdgcn_mfma_f64_16x16x4f64(-b3, a3, v, 0, 0, 0);
+                  v = __builtin_amdgcn_mfma_f64_16x16x4f64(b4, a4, v, 0, 0, 0);
+                }
                 acc[TM::slot(d + T + 1, T + 1)] = __builtin_amdgcn_mfma_f64_16x16x4f64(b2, a2, v, 0, 0, 0);
               }
             });

@@ -75,8 +75,8 @@ extern "C" {
 #define DDMPC_GRAM_AUTO       0     /* = STRUCTURED                                      */
 #define DDMPC_GRAM_DENSE      1     /* H H' by fp64 MFMA over the implicit Hankel operand */
 #define DDMPC_GRAM_STRUCTURED 2     /* Hankel sliding-window recurrence (hankel_matrix.py:5-53 is generic in the channel count
-                                       and so is this: inside the cold-solve kernel for m + p == 4, by a launch ahead of it
-                                       for any other count)                              */
+                                       and so is this: inside the cold-solve kernel for m + p == 2 or 4, by a launch ahead of
+                                       it for any other count)                              */
 
 /* ddmpc_get_solution selectors: the `.value` of the reference's cp.Variables
  * (controller.py:434-445) */
