@@ -377,3 +377,81 @@ def test_dense_weights_with_unweighted_components(slack):
         BatchedDDMPC(n=spec.n, m=spec.m, p=spec.p, L_=spec.L, N=400, Q=Qs, R=R, u_s=spec.u_s, y_s=spec.y_s, batch=1,
                      controller_type=L.ROBUST, slack_type=L.SLACK_NONE, eps_max=spec.eps_max, lamb_alpha=spec.lamb_alpha,
                      lamb_sigma=spec.lamb_sigma, c=spec.c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [24, 44, 76, 108, 140, 204, 260])
+def test_siso_structured_gram_on_every_kernel_instance(rows):
+    """Two channels ride on the four-channel structured Gram inside the cold-solve kernel (a SISO Hankel matrix = two interleaved
+    four-channel ones over the same flat trajectory).  Every instance of the kernel (<2,1> ... <17,8>), odd and even
+    L + n (an odd one leaves half a pseudo time step of padding rows), odd and even column counts (the two interleaved
+    trajectories then differ in length): structured against the dense product and both against the full-space oracle."""
+    from direct_data_driven_mpc_amd.harness import generate_batch
+    rng = np.random.default_rng(rows)
+    m = p = 1; n = 3
+    Ln = rows // 2                                            # 12, 22, 38, 54, 70, 102, 130 (even) ...
+    if rows % 8 == 4: Ln += 1                                 # ... and a few odd ones: 23, 55, 71, 131
+    Lh = Ln - n
+    N = 2 * (Lh + 2 * n) + 160 + (rows // 4) % 2              # odd and even numbers of Hankel columns
+    A = rng.normal(size=(n, n)); A *= 0.8 / max(abs(np.linalg.eigvals(A)))
+    plant = dict(A=A, B=rng.normal(size=(n, m)), C=rng.normal(size=(p, n)), D=np.zeros((p, m)), eps_max=0.002)
+    spec = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=2.0 * np.eye(p * Lh), R=0.05 * np.eye(m * Lh), u_s=np.array([0.3]), y_s=np.array([-0.2]),
+                      robust=True, eps_max=0.002, lamb_alpha=20.0, lamb_sigma=500.0, c=1.0, slack="convex" if rows % 16 == 12 else "none", tec=True)
+    B = 3
+    d = generate_batch(range(B), N=N, plant=plant)
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    res = {}
+    for mode in (L.GRAM_DENSE, L.GRAM_STRUCTURED):
+        with BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=2.0, R=0.05, u_s=spec.u_s, y_s=spec.y_s, batch=B, controller_type=L.ROBUST,
+                          slack_type=L.SLACK_CONVEX if spec.slack == "convex" else L.SLACK_NONE, eps_max=0.002, lamb_alpha=20.0,
+                          lamb_sigma=500.0, c=1.0, gram_mode=mode) as eng:
+            eng.set_refinement("always")
+            eng.set_data(d["u_d"], d["y_d"])
+            res[mode] = tuple(x.copy() for x in eng.solve(up, yp)) + (eng.kernel_name(), eng.cost_model()[0])
+    dn, st = res[L.GRAM_DENSE], res[L.GRAM_STRUCTURED]
+    assert dn[4] == st[4] and "cold" in st[4]
+    assert st[5] < dn[5]                                      # the structured mode is charged the structured flop count
+    for b in range(B):
+        sol = orc.solve_fullspace(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
+        for r_ in (dn, st):
+            assert L.STATUS_STRINGS[int(r_[2][b])] == sol.status == "optimal"
+            assert np.max(np.abs(r_[0][b] - sol.optimal_u)) / max(np.max(np.abs(sol.optimal_u)), 1e-3) < 1e-8, (rows, b)
+            assert abs(r_[1][b] - sol.cost) <= 1e-8 * max(abs(sol.cost), 1e-6), (rows, b)
+    assert np.max(np.abs(dn[0] - st[0])) <= 1e-9 * np.max(np.abs(dn[0])) and np.array_equal(dn[3], st[3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [19, 21, 23, 35, 41, 47, 69, 83])
+def test_large_nominal_seeded_plants_on_the_phase_kernels(case):
+    """Eight plants of tools/nominal_fuzz.py beyond 271 rows (SISO with L up to 313, 1x3, 2x3; trajectories short enough that the
+    matrix-pipe H(H'x) runs with fewer column groups than it has partial-sum slots -- case 35 is the one that exposed the
+    unwritten slots; dependent row tiles retire early on all of them) on the phase kernels, against the model-based solution."""
+    from direct_data_driven_mpc_amd.harness import generate_batch
+    from oracle.nominal_exact import solve_nominal_model_based
+    rng = np.random.default_rng(9000 + case)
+    m, p = [(2, 2), (1, 3), (3, 1), (2, 3), (4, 2), (1, 1)][case % 6]
+    ns = n = int(rng.integers(2, 5))
+    rows = int(rng.integers(60, 260)) if case % 2 == 0 else int(rng.integers(280, 640))
+    Lh = max(2 * n, rows // (m + p) - n)
+    N = (m + 1) * (Lh + 2 * n) + int(rng.integers(100, 300))
+    assert (m + p) * (Lh + n) > 271
+    A = rng.normal(size=(ns, ns)); A *= rng.uniform(0.5, 0.9) / max(abs(np.linalg.eigvals(A)))
+    plant = dict(A=A, B=rng.normal(size=(ns, m)), C=rng.normal(size=(p, ns)), D=np.zeros((p, m)), eps_max=0.0)
+    u_s = rng.uniform(-0.5, 0.5, m)
+    y_s = (plant["C"] @ np.linalg.inv(np.eye(ns) - A) @ plant["B"]) @ u_s
+    q, rw = float(rng.uniform(1.0, 4.0)), float(rng.uniform(0.01, 0.2))
+    spec = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=q * np.eye(p * Lh), R=rw * np.eye(m * Lh), u_s=u_s, y_s=y_s, robust=False,
+                      eps_max=0.0, lamb_alpha=0.0, lamb_sigma=0.0, c=0.0, slack="none", tec=True)
+    B = 2
+    d = generate_batch(range(case * 10, case * 10 + B), N=N, plant=plant)
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    with BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=q, R=rw, u_s=u_s, y_s=y_s, batch=B, controller_type=L.NOMINAL) as eng:
+        eng.set_large_pipeline("phases")
+        eng.set_data(d["u_d"], d["y_d"])
+        u, cost, status, _ = eng.solve(up, yp)
+        uw = eng.step(up, yp)
+    assert np.all(status == 0) and np.array_equal(uw[0], u) and np.array_equal(uw[1], cost)      # warm on the kept factors: bit-equal
+    for b in range(B):
+        mod = solve_nominal_model_based(spec, plant, up[b], yp[b])
+        assert np.max(np.abs(u[b] - mod["optimal_u"])) / max(np.max(np.abs(mod["optimal_u"])), 1e-3) < 1e-8, (case, b)
+        assert abs(cost[b] - mod["cost"]) <= 1e-9 * max(abs(mod["cost"]), 1e-9), (case, b)
