@@ -450,7 +450,13 @@ def test_large_nominal_seeded_plants_on_the_phase_kernels(case):
         eng.set_data(d["u_d"], d["y_d"])
         u, cost, status, _ = eng.solve(up, yp)
         uw = eng.step(up, yp)
+        eng.set_large_affine_law(True)                        # ... and as an affine law of the past window (one launch per step)
+        eng.prepare()
+        ul = eng.step(up, yp)
+        g = eng.gain()
     assert np.all(status == 0) and np.array_equal(uw[0], u) and np.array_equal(uw[1], cost)      # warm on the kept factors: bit-equal
+    assert np.all(ul[2] == 0) and np.max(np.abs(ul[0] - u)) <= 1e-8 * np.max(np.abs(u)) and np.max(np.abs(ul[1] - cost)) <= 1e-9 * np.max(np.abs(cost)) + 1e-18
+    assert g.shape == (B, n * (m + p) + 1, (m + p) * (Lh + n)) and np.all(np.isfinite(g))
     for b in range(B):
         mod = solve_nominal_model_based(spec, plant, up[b], yp[b])
         assert np.max(np.abs(u[b] - mod["optimal_u"])) / max(np.max(np.abs(mod["optimal_u"])), 1e-3) < 1e-8, (case, b)
