@@ -461,3 +461,35 @@ def test_large_nominal_seeded_plants_on_the_phase_kernels(case):
         mod = solve_nominal_model_based(spec, plant, up[b], yp[b])
         assert np.max(np.abs(u[b] - mod["optimal_u"])) / max(np.max(np.abs(mod["optimal_u"])), 1e-3) < 1e-8, (case, b)
         assert abs(cost[b] - mod["cost"]) <= 1e-9 * max(abs(mod["cost"]), 1e-9), (case, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 7])
+def test_large_nominal_small_batches_and_switching_pipelines(B):
+    """Batches of one and seven instances (grids of the lock-step launches with a single instance row; no multiple of anything),
+    and DDMPC_OPT_LARGE_PIPELINE switched back and forth on a live handle between solves and around ddmpc_prepare: every solve
+    agrees with the other pipeline's to rounding, a warm step is bit-equal to the cold solve of the pipeline that prepared."""
+    from test_gpu_round3 import _config5
+    spec, plant, N, d, up, yp = _config5(B)
+    n = spec.n
+    up2 = d["u_d"][:, 200:200 + n, :].reshape(B, -1).copy(); yp2 = d["y_d"][:, 200:200 + n, :].reshape(B, -1).copy()
+    with _spec_engine(spec, N, B) as eng:
+        eng.set_data(d["u_d"], d["y_d"])
+        a = tuple(x.copy() for x in eng.solve(up, yp))                     # phases (default)
+        eng.set_large_pipeline("one_workgroup")
+        b = tuple(x.copy() for x in eng.solve(up, yp))
+        eng.set_large_pipeline("phases")
+        c = tuple(x.copy() for x in eng.solve(up, yp))
+        eng.prepare()
+        w = tuple(x.copy() for x in eng.step(up2, yp2))
+        cold2 = tuple(x.copy() for x in eng.solve(up2, yp2))
+        eng.set_large_pipeline("one_workgroup")                             # forgets what the other pipeline kept
+        w1 = tuple(x.copy() for x in eng.step(up2, yp2))
+        cold1 = tuple(x.copy() for x in eng.solve(up2, yp2))
+    assert np.all(a[2] == 0) and np.all(b[2] == 0) and np.all(w[2] == 0) and np.all(w1[2] == 0)
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])                       # the same pipeline: bit-equal
+    sc = np.max(np.abs(a[0]), axis=1, keepdims=True)
+    assert np.max(np.abs(a[0] - b[0]) / sc) < 1e-8 and np.max(np.abs(a[1] - b[1]) / np.abs(a[1])) < 1e-9
+    assert np.array_equal(w[0], cold2[0]) and np.array_equal(w[1], cold2[1])
+    assert np.array_equal(w1[0], cold1[0]) and np.array_equal(w1[1], cold1[1])
+    assert np.max(np.abs(cold1[0] - cold2[0]) / np.max(np.abs(cold2[0]), axis=1, keepdims=True)) < 1e-8
