@@ -493,3 +493,47 @@ def test_large_nominal_small_batches_and_switching_pipelines(B):
     assert np.array_equal(w[0], cold2[0]) and np.array_equal(w[1], cold2[1])
     assert np.array_equal(w1[0], cold1[0]) and np.array_equal(w1[1], cold1[1])
     assert np.max(np.abs(cold1[0] - cold2[0]) / np.max(np.abs(cold2[0]), axis=1, keepdims=True)) < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,p,rows", [(2, 1, 30), (2, 1, 75), (1, 2, 111), (2, 1, 204), (1, 2, 261), (3, 2, 45), (3, 2, 105), (2, 3, 200), (3, 2, 265),
+                                      (3, 3, 66), (3, 3, 258), (4, 3, 70), (4, 3, 266)])
+def test_structured_gram_launch_on_every_kernel_instance(m, p, rows):
+    """ddmpc_gram_tiles_kernel (the structured Gram of channel counts other than 2 and 4, formed ahead of the cold-solve kernel)
+    on every instance of that kernel, <2,1> ... <17,8>: 3, 5, 6 and 7 channels, row counts off the tile size, structured against
+    the dense product and both against the full-space oracle; warm step after ddmpc_prepare (the tiles are formed once there)."""
+    from direct_data_driven_mpc_amd.harness import generate_batch
+    rng = np.random.default_rng(100 * rows + m)
+    n = 2
+    nch = m + p
+    Ln = rows // nch
+    Lh = Ln - n
+    assert Lh >= 2 * n
+    N = (m + 1) * (Lh + 2 * n) + 120 + rows % 3
+    A = rng.normal(size=(n, n)); A *= 0.8 / max(abs(np.linalg.eigvals(A)))
+    plant = dict(A=A, B=rng.normal(size=(n, m)), C=rng.normal(size=(p, n)), D=np.zeros((p, m)), eps_max=0.002)
+    slack = "convex" if rows % 2 else "none"
+    spec = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=2.0 * np.eye(p * Lh), R=0.05 * np.eye(m * Lh), u_s=rng.uniform(-0.3, 0.3, m),
+                      y_s=rng.uniform(-0.3, 0.3, p), robust=True, eps_max=0.002, lamb_alpha=20.0, lamb_sigma=500.0, c=1.0, slack=slack, tec=True)
+    B = 3
+    d = generate_batch(range(B), N=N, plant=plant)
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    res = {}
+    for mode in (L.GRAM_DENSE, L.GRAM_STRUCTURED):
+        with BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=2.0, R=0.05, u_s=spec.u_s, y_s=spec.y_s, batch=B, controller_type=L.ROBUST,
+                          slack_type=L.SLACK_CONVEX if slack == "convex" else L.SLACK_NONE, eps_max=0.002, lamb_alpha=20.0,
+                          lamb_sigma=500.0, c=1.0, gram_mode=mode) as eng:
+            assert "cold" in eng.kernel_name()
+            eng.set_refinement("always")
+            eng.set_data(d["u_d"], d["y_d"])
+            res[mode] = tuple(x.copy() for x in eng.solve(up, yp))
+            uw = eng.step(up, yp)
+            assert np.max(np.abs(uw[0] - res[mode][0])) <= 1e-8 * np.max(np.abs(res[mode][0])) and np.array_equal(uw[2], res[mode][2])
+    dn, st = res[L.GRAM_DENSE], res[L.GRAM_STRUCTURED]
+    for b in range(B):
+        sol = orc.solve_fullspace(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
+        for r_ in (dn, st):
+            assert L.STATUS_STRINGS[int(r_[2][b])] == sol.status == "optimal"
+            assert np.max(np.abs(r_[0][b] - sol.optimal_u)) / max(np.max(np.abs(sol.optimal_u)), 1e-3) < 1e-8, (rows, b)
+            assert abs(r_[1][b] - sol.cost) <= 1e-8 * max(abs(sol.cost), 1e-6), (rows, b)
+    assert np.max(np.abs(dn[0] - st[0])) <= 1e-9 * np.max(np.abs(dn[0])) and np.array_equal(dn[3], st[3])
