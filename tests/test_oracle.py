@@ -183,3 +183,36 @@ def test_nominal_oracles_against_the_extended_precision_golden_solutions():
         assert np.max(np.abs(mod["optimal_u"] - z["optimal_u"][k])) < 1e-8 * sc and abs(mod["cost"] - z["cost"][k]) < 1e-9 * z["cost"][k]
         svd = solve_nominal_exact(spec, d["u_d"][0], d["y_d"][0], up, yp)
         assert svd["status"] == "optimal" and np.max(np.abs(svd["optimal_u"] - z["optimal_u"][k])) < 2e-8 * sc
+
+
+@pytest.mark.parametrize("slack", ["none", "convex"])
+def test_fp64_checkers_against_the_extended_precision_golden_solutions_of_the_headline_config(slack):
+    # tests/golden/cfg2_extended.npz: BASELINE configs[1] (four-tank robust, L = 30, N = 400), the QP as the reference states it
+    # (full-space KKT of build_fullspace_qp), solved in 80-bit arithmetic with the active set verified there
+    # (make_golden_cfg2_extended.py).  The fp64 checkers the GPU tests use -- the numpy full-space oracle, its reduced form and
+    # the compiled C restatement -- sit within 1e-12 of it; the active-set iteration counts agree.
+    import os
+    from direct_data_driven_mpc_amd.harness import generate_batch
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg2_extended.npz"))
+    seeds = [int(s) for s in z["seeds"]]
+    spec = orc.spec_from_params(**({"slack_var_constraint_type": 1} if slack == "convex" else {}))
+    n = spec.n
+    d = generate_batch(seeds, N=400)
+    up = d["u_d"][:, -n:, :].reshape(len(seeds), -1).copy(); yp = d["y_d"][:, -n:, :].reshape(len(seeds), -1).copy()
+    ug, cg = z["optimal_u_" + slack], z["cost_" + slack]
+    for k in range(len(seeds)):
+        sol = orc.solve_fullspace(spec, d["u_d"][k], d["y_d"][k], up[k], yp[k])
+        assert sol.status == "optimal" and np.max(np.abs(sol.optimal_u - ug[k])) < 1e-12 * np.max(np.abs(ug[k])) and abs(sol.cost - cg[k]) < 1e-12 * cg[k]
+        assert np.max(np.abs(sol.alpha - z["alpha_" + slack][k])) < 1e-10 * np.max(np.abs(z["alpha_" + slack][k]))
+        if slack == "convex":
+            assert sol.iters == int(z["iters_convex"][k]) and int(np.count_nonzero(sol.active)) == int(z["n_active_convex"][k])
+        red = solve_reduced(spec, d["u_d"][k], d["y_d"][k], up[k], yp[k])
+        assert np.max(np.abs(red["optimal_u"] - ug[k])) < 5e-11 * np.max(np.abs(ug[k])) and abs(red["cost"] - cg[k]) < 5e-11 * cg[k]
+    try:
+        from oracle import oracle_c
+        oracle_c.load()
+    except Exception:
+        pytest.skip("the compiled C restatement is not built")
+    u_c, c_c, st_c, it_c = oracle_c.solve_batch(spec, 400, d["u_d"], d["y_d"], up, yp)[:4]
+    assert np.all(st_c == 0)
+    assert np.max(np.abs(u_c - ug) / np.max(np.abs(ug), axis=1, keepdims=True)) < 5e-11 and np.max(np.abs(c_c - cg) / cg) < 5e-11
