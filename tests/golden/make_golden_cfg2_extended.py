@@ -1,4 +1,5 @@
-"""Golden solutions of BASELINE configs[1] (four-tank robust DD-MPC, L = 30, N = 400; slack NONE and CONVEX) in EXTENDED precision:
+"""Golden solutions of BASELINE configs[1] (four-tank robust DD-MPC, L = 30, N = 400) and configs[3] (L = 60, N = 1000), slack NONE
+and CONVEX, in EXTENDED precision:
 the QP exactly as the reference hands it to CVXPY -- variables [alpha; ubar; ybar; sigma], the cost of
 direct_data_driven_mpc_controller.py:679-722, the equalities of :506-629, the slack box of :631-677 -- assembled by
 oracle/ddmpc_oracle.build_fullspace_qp (every entry of P, q, A, b is a data value or a weight: exact in 80-bit) and solved through
@@ -6,7 +7,7 @@ its dense KKT system by Gaussian elimination with partial pivoting and iterative
 Slack CONVEX: the active set of the fp64 primal-dual iteration is taken as the candidate and its optimality conditions (bounds on
 the inactive sigma, multiplier signs on the active ones) are verified IN extended precision before the result is stored.
 
-    python tests/golden/make_golden_cfg2_extended.py          # ~1 minute; writes tests/golden/cfg2_extended.npz
+    python tests/golden/make_golden_cfg2_extended.py          # ~5 minutes; writes tests/golden/cfg2_extended.npz, cfg4_extended.npz
 
 TEST INFRASTRUCTURE ONLY.  What it pins: the accuracy of the fp64 checkers (numpy full-space oracle, compiled C restatement) and of
 the GPU on the headline configuration against a solution three orders of magnitude beyond fp64 -- not the reference's own solver
@@ -82,22 +83,26 @@ def solve_extended(spec, u_d, y_d, u_past, y_past):
                 fp64_u=ref.optimal_u, fp64_cost=ref.cost)
 
 
-if __name__ == "__main__":
-    seeds = [0, 1, 2, 3, 1000, 4095]
-    d = generate_batch(seeds, N=400)
-    out = dict(seeds=np.array(seeds))
+def make(fname, seeds, L_, N):
+    d = generate_batch(seeds, N=N)
+    out = dict(seeds=np.array(seeds), L=np.array(L_), N=np.array(N))
     for tag, kw in (("none", dict()), ("convex", dict(slack_var_constraint_type=1))):
-        spec = orc.spec_from_params(**kw)
+        spec = orc.spec_from_params(L=L_, N=N, **kw)
         n = spec.n
         U, C, AL, IT, NA = [], [], [], [], []
         for k, s in enumerate(seeds):
             up = d["u_d"][k, -n:, :].reshape(-1); yp = d["y_d"][k, -n:, :].reshape(-1)
             r = solve_extended(spec, d["u_d"][k], d["y_d"][k], up, yp)
             eu = np.max(np.abs(r["fp64_u"] - r["optimal_u"])) / np.max(np.abs(r["optimal_u"]))
-            print("slack %-6s seed %4d: KKT residual %.1e, active bounds %2d (fp64 iterations %d); fp64 full-space oracle vs extended: u %.1e cost %.1e" % (
-                tag, s, r["kkt_residual"], r["n_active"], r["iters"], eu, abs(r["fp64_cost"] - r["cost"]) / abs(r["cost"])), flush=True)
+            print("%s slack %-6s seed %4d: KKT residual %.1e, active bounds %2d (fp64 iterations %d); fp64 full-space oracle vs extended: u %.1e cost %.1e" % (
+                fname, tag, s, r["kkt_residual"], r["n_active"], r["iters"], eu, abs(r["fp64_cost"] - r["cost"]) / abs(r["cost"])), flush=True)
             U.append(r["optimal_u"]); C.append(r["cost"]); AL.append(r["alpha"]); IT.append(r["iters"]); NA.append(r["n_active"])
         out["optimal_u_" + tag] = np.array(U); out["cost_" + tag] = np.array(C); out["alpha_" + tag] = np.array(AL)
         out["iters_" + tag] = np.array(IT); out["n_active_" + tag] = np.array(NA)
-    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "cfg2_extended.npz"), **out)
-    print("wrote cfg2_extended.npz")
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), fname), **out)
+    print("wrote", fname)
+
+
+if __name__ == "__main__":
+    make("cfg2_extended.npz", [0, 1, 2, 3, 1000, 4095], 30, 400)          # BASELINE configs[1]
+    make("cfg4_extended.npz", [0, 1023], 60, 1000)                          # BASELINE configs[3]: 1,321 variables + 392 equalities

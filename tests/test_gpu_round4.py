@@ -540,24 +540,27 @@ def test_structured_gram_launch_on_every_kernel_instance(m, p, rows):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg4"])
 @pytest.mark.parametrize("slack", ["none", "convex"])
-def test_headline_config_against_the_extended_precision_golden_solutions(slack):
+def test_headline_config_against_the_extended_precision_golden_solutions(slack, cfg):
     """BASELINE configs[1] (four-tank robust DD-MPC, L = 30, N = 400) against the QP as the reference states it, solved in 80-bit
     arithmetic (tests/golden/cfg2_extended.npz, make_golden_cfg2_extended.py; the fp64 checkers are pinned to it on the CPU in
     test_oracle.py): cold solve in every refinement mode and the warm step, six instances, slack NONE and CONVEX, at 1e-10 -- two
     orders inside the suite's bars; CONVEX: the same active-set iteration counts."""
     from direct_data_driven_mpc_amd.harness import generate_batch
-    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg2_extended.npz"))
+    # (cfg4: BASELINE configs[3], L = 60, N = 1000 on the <17,8> instance, two instances, tests/golden/cfg4_extended.npz)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", cfg + "_extended.npz"))
     seeds = [int(s) for s in z["seeds"]]
     B = len(seeds)
-    spec = orc.spec_from_params(**({"slack_var_constraint_type": 1} if slack == "convex" else {}))
+    Lh, N = int(z["L"]), int(z["N"])
+    spec = orc.spec_from_params(L=Lh, N=N, **({"slack_var_constraint_type": 1} if slack == "convex" else {}))
     n = spec.n
-    d = generate_batch(seeds, N=400)
+    d = generate_batch(seeds, N=N)
     up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
     ug, cg = z["optimal_u_" + slack], z["cost_" + slack]
     sc = np.max(np.abs(ug), axis=1, keepdims=True)
     for refine in ("auto", "off", "always"):
-        with _spec_engine(spec, 400, B) as eng:
+        with _spec_engine(spec, N, B) as eng:
             eng.set_refinement(refine)
             eng.set_data(d["u_d"], d["y_d"])
             u, cost, status, iters = eng.solve(up, yp)
