@@ -35,7 +35,7 @@ EXPORTS = (
     "ddmpc_set_stream", "ddmpc_synchronize", "ddmpc_set_data", "ddmpc_solve", "ddmpc_set_setpoints",
     "ddmpc_get_solution", "ddmpc_hankel", "ddmpc_cost_model", "ddmpc_kernel_name", "ddmpc_debug_stamps",
     "ddmpc_closed_loop", "ddmpc_prepare", "ddmpc_step", "ddmpc_get_gain", "ddmpc_set_option",
-    "ddmpc_pe_guard", "ddmpc_solve_from_host", "ddmpc_debug_workspace",
+    "ddmpc_pe_guard", "ddmpc_solve_from_host", "ddmpc_debug_workspace", "ddmpc_debug_poison_allocations",
 )
 
 c_double_p = C.POINTER(C.c_double)

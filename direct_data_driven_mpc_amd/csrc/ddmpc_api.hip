@@ -51,6 +51,8 @@ int fail(int code, const char* fmt, ...) {
                   __FILE__, __LINE__);                                                  \
   } while (0)
 
+static int g_poison_byte = 0;      // ddmpc_debug_poison_allocations
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
@@ -61,17 +63,9 @@ struct DevBuf {
     bytes = 0;
     HIP_TRY(hipMalloc(&p, need));
     bytes = need;
-    // debugging aid: DDMPC_POISON=1 fills every fresh device buffer with NaN bit patterns, so that a read of something no
-    // kernel has written shows up in the results of a single run instead of depending on what the allocator handed back
-    // (DDMPC_POISON=<byte>: that byte instead -- 63 gives small finite doubles, which flow through where a NaN is dropped by a comparison)
-    static const int poison = getenv("DDMPC_POISON") ? atoi(getenv("DDMPC_POISON")) : 0;
-    static const int only = getenv("DDMPC_POISON_ONLY") ? atoi(getenv("DDMPC_POISON_ONLY")) : -1;   // (just the n-th allocation of the process)
-    static int serial = 0;
-    const int id = serial++;
-    if (poison && (only < 0 || only == id)) {
-      HIP_TRY(hipMemset(p, poison == 1 ? 0xFF : poison, need));
-      if (only >= 0) fprintf(stderr, "[ddmpc] poisoned allocation #%d (%zu bytes)\n", id, need);
-    }
+    // debugging aid (ddmpc_debug_poison_allocations): every fresh device buffer pre-filled with a byte pattern, so that a read
+    // of something no kernel has written shows up in the results of one run instead of depending on what the allocator handed back
+    if (g_poison_byte) HIP_TRY(hipMemset(p, g_poison_byte, need));
     return DDMPC_OK;
   }
   void release() {
@@ -1852,6 +1846,12 @@ int ddmpc_debug_stamps(ddmpc_handle* h, int enable, uint64_t* out) {
   }
   h->stamps_on = enable != 0;
   return DDMPC_OK;
+}
+
+int ddmpc_debug_poison_allocations(int byte) {
+  const int prev = g_poison_byte;
+  g_poison_byte = byte & 0xff;
+  return prev;
 }
 
 int ddmpc_debug_workspace(ddmpc_handle* h, int64_t b, double* ws_out, int64_t ws_count, int32_t* meta_out, int64_t meta_count,

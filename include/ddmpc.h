@@ -311,6 +311,12 @@ int ddmpc_debug_stamps(ddmpc_handle* h, int enable, uint64_t* out);
 int ddmpc_debug_workspace(ddmpc_handle* h, int64_t b, double* ws_out, int64_t ws_count, int32_t* meta_out, int64_t meta_count,
                           int64_t* ws_avail, int64_t* meta_avail);
 
+/* Diagnostics only, process-wide: from now on every device buffer the library allocates is pre-filled with `byte` (0: off, the
+ * default; 255 gives NaN bit patterns, 63 small finite doubles).  A result that changes with the fill has read memory no kernel
+ * wrote -- fresh device memory is zero on this stack, which hides such reads in a standalone run.  Returns the previous setting.
+ * (tests/test_gpu_round4.py) */
+int ddmpc_debug_poison_allocations(int byte);
+
 #ifdef __cplusplus
 }
 #endif
