@@ -513,6 +513,30 @@ def main():
             big.close()
             del big, upb, ypb, uob, cob, sob, iob
 
+    # ---- N > 1: the same GPU's rate at the SAME per-GPU batch, with the other ranks idle (they wait in the collective below).
+    # The --gpus 1 line times configs[1]'s 4096 instances, the --gpus N > 1 lines 32,768 per GPU, and one GPU is ~9 % faster per
+    # instance at the larger batch: a curve through the lines would read above 100 %.  This makes the N > 1 line self-sufficient:
+    # `per_gpu_reference` = rank 0's shard alone, same K steps, same two alternating data sets, no gather;
+    # `scaling_efficiency_vs_same_batch` = value / (N x that).  Outside the timed region.
+    per_gpu_ref = None
+    if use_dist:
+        u_keep, c_keep, s_keep = u_opt.clone(), cost.clone(), status.clone()
+        barrier()
+        if rank == 0:
+            torch.cuda.synchronize()
+            r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            tr = time.perf_counter()
+            r0.record()
+            for k in range(a.steps):
+                step(k)
+            r1.record()
+            torch.cuda.synchronize()
+            dtr = time.perf_counter() - tr
+            per_gpu_ref = {"value": B * a.steps / dtr, "unit": "QP solves/s", "batch": B, "steps": a.steps,
+                           "ms_per_step": dtr / a.steps * 1e3, "kernel_ms": float(r0.elapsed_time(r1)) / a.steps,
+                           "note": "rank 0 alone on its GPU after the timed region: same shard, same steps, no gather"}
+            assert torch.equal(u_opt, u_keep) and torch.equal(cost, c_keep) and torch.equal(status, s_keep), "re-run differs"
+        barrier()
     others = None
     if rank == 0 and other_jobs is not None:
         others = other_configs_device(other_jobs, dev)
@@ -556,6 +580,9 @@ def main():
             out["other_configs"] = others
         if dist_info is not None:
             out["distributed"] = dist_info
+        if per_gpu_ref is not None:
+            out["per_gpu_reference"] = per_gpu_ref
+            out["scaling_efficiency_vs_same_batch"] = out["value"] / (world * per_gpu_ref["value"])
         if cpu is not None:
             base, (u_c, c_c, st_c), (u_f, c_f) = cpu
             ns = u_c.shape[0]

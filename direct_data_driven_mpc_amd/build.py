@@ -91,15 +91,16 @@ def build(force: bool = False, jobs: int = 0, verbose: bool = True) -> str:
     cmd = [hipcc] + COMMON_FLAGS + api_flags + ["-c", os.path.join(CSRC, "ddmpc_api.hip"), "-o", api_obj]
     tasks.append((cmd, api_obj, _fingerprint(cmd, API_DEPS, [header])))
     for nt, w in instances():
-        # 2: the cold-solve kernel, "2r": the same with the iterative-refinement loop compiled in
-        for gen in ("2", "2r"):
+        # 2: the cold-solve kernel, "2r": the same with the iterative-refinement loop compiled in, "2c": the plain kernel with
+        # the rank-k treatment of the slack box (controllers with the CONVEX box)
+        for gen in ("2", "2r", "2c"):
             obj = os.path.join(OBJ_DIR, "ddmpc_inst%s_%d_%d.o" % (gen, nt, w))
-            extra = {"2": [], "2r": ["-DDDMPC_INST_REF=true"]}[gen]
+            extra = {"2": [], "2r": ["-DDDMPC_INST_REF=true"], "2c": ["-DDDMPC_INST_CVX=true"]}[gen]
             cmd = [hipcc] + COMMON_FLAGS + ["-DDDMPC_INST_NT=%d" % nt, "-DDDMPC_INST_W=%d" % w] + extra + \
                   ["-c", os.path.join(CSRC, "ddmpc_inst.hip"), "-o", obj]
             tasks.append((cmd, obj, _fingerprint(cmd, INST_DEPS)))
     todo = [t for t in tasks if force or not _is_current(t[1], t[2])]
-    todo.sort(key=lambda t: -int(re.search(r"ddmpc_inst2?r?_(\d+)_", t[1]).group(1)) if "ddmpc_inst" in t[1] else 0)  # longest first
+    todo.sort(key=lambda t: -int(re.search(r"ddmpc_inst2?[rc]?_(\d+)_", t[1]).group(1)) if "ddmpc_inst" in t[1] else 0)  # longest first
     if todo:
         jobs = jobs or min(len(todo), max(1, (os.cpu_count() or 2) - 1), 8)
         if verbose:

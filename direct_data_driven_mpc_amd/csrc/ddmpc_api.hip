@@ -24,6 +24,9 @@ namespace ddmpc {
       int*, double*, signed char*, unsigned long long*, double*, double*, int*, const int*, long long, int*);   \
   extern template __global__ void ddmpc_cold_solve_kernel2<NT, W, true>(                                   \
       KParams, const double*, const double*, const double*, const double*, double*, double*, int*,        \
+      int*, double*, signed char*, unsigned long long*, double*, double*, int*, const int*, long long, int*);   \
+  extern template __global__ void ddmpc_cold_solve_kernel2<NT, W, false, true>(                            \
+      KParams, const double*, const double*, const double*, const double*, double*, double*, int*,        \
       int*, double*, signed char*, unsigned long long*, double*, double*, int*, const int*, long long, int*);
 #include "ddmpc_instances.inc"
 #undef DDMPC_INSTANCE
@@ -102,6 +105,7 @@ struct KernelChoice {
   cold_kernel2_t fn2;        // cold-solve kernel (ddmpc_cold2.hpp)
   const char* name2;
   cold_kernel2_t fn2r;       // the same with the iterative-refinement loop compiled in
+  cold_kernel2_t fn2c;       // the plain kernel with the rank-k treatment of the slack box (CONVEX controllers)
   int lds_fixed;             // Lds2<NT, W>::xs: doubles in front of the trajectory region
   int max_past;              // Lds2Limits: entries of [u_past; y_past] the prologue staging holds
   int scratch;               // Lds2Limits: doubles free for the residual check of AUTO refinement
@@ -112,7 +116,7 @@ struct KernelChoice {
 const KernelChoice kKernels[] = {
 #define DDMPC_INSTANCE(NT, W) \
   {NT, W, &ddmpc_cold_solve_kernel2<NT, W, false>, "ddmpc_cold_solve_kernel2<" #NT "," #W ">", &ddmpc_cold_solve_kernel2<NT, W, true>, \
-   Lds2<NT, W>::xs, Lds2Limits<NT, W>::max_past, Lds2Limits<NT, W>::scratch},
+   &ddmpc_cold_solve_kernel2<NT, W, false, true>, Lds2<NT, W>::xs, Lds2Limits<NT, W>::max_past, Lds2Limits<NT, W>::scratch},
 #include "ddmpc_instances.inc"
 #undef DDMPC_INSTANCE
 };
@@ -164,6 +168,7 @@ struct ddmpc_handle {
                                            // [max diag of G | max diag of T | live chunks of G | live chunks of T]
   int nF = 0;                              // fixed components (hard constraints), nominal scheme
   int large_pipeline = DDMPC_PIPELINE_PHASES;   // DDMPC_OPT_LARGE_PIPELINE
+  int convex_update = 1;                        // DDMPC_OPT_CONVEX_UPDATE: active-set iterations keep the first factor (rank-k update)
   bool rescue_ran = false;
   int epoch = 0;                           // cold launches so far (KParams::epoch)
   int prep_epoch = 0;                      // stamp of the flags recorded by ddmpc_prepare's factor-export launch (AUTO)
@@ -490,8 +495,8 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   const KernelChoice* kc = nullptr;
   for (const KernelChoice& cand : kKernels)
     if (16 * cand.NT >= rows_needed) { kc = &cand; break; }
-  static const KernelChoice kLargeNominal = {0, 4, nullptr, "ddmpc_nominal_rr_kernel", nullptr, 0, 0, 0};
-  static const KernelChoice kLargeSolve = {0, 4, nullptr, "ddmpc_large_solve_kernel", nullptr, 0, 0, 0};
+  static const KernelChoice kLargeNominal = {0, 4, nullptr, "ddmpc_nominal_rr_kernel", nullptr, nullptr, 0, 0, 0};
+  static const KernelChoice kLargeSolve = {0, 4, nullptr, "ddmpc_large_solve_kernel", nullptr, nullptr, 0, 0, 0};
   if (!kc) {
     // No register-resident kernel holds this many rows.  With scalar/diagonal weights the problem is served by the
     // global-workspace kernels (plain VALU code): ROBUST controllers by
@@ -550,8 +555,16 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
     delete h;
     return fail(DDMPC_ERR_UNSUPPORTED, "trajectory too long for LDS staging: needs %zu bytes of LDS", h->lds_bytes);
   }
+  // (trajectories whose staging does not fit the LDS of ddmpc_gram_tiles_kernel keep the dense product)
   h->gram_pre = p.gram_mode != DDMPC_GRAM_DENSE && k.nch != 4 && k.nch != 2 &&
                 gram_tiles_lds_doubles(k.xs_len, k.r, k.nch, h->kc.NT) * sizeof(double) <= 150 * 1024;
+  if (p.gram_mode == DDMPC_GRAM_STRUCTURED && k.nch != 4 && k.nch != 2 && !h->gram_pre) {
+    // AUTO falls back to the dense product silently; a caller who asked for STRUCTURED by name is told
+    const int nch_ = k.nch;
+    delete h;
+    return fail(DDMPC_ERR_UNSUPPORTED, "DDMPC_GRAM_STRUCTURED cannot be served for this shape (m+p = %d channels: the trajectory "
+                "staging of the Gram launch must fit 150 KB of LDS); use DDMPC_GRAM_AUTO or DDMPC_GRAM_DENSE", nch_);
+  }
   if (p.n * k.nch > h->kc.max_past) {       // (implied by L >= n and the instance table; kept as a guard of the LDS aliasing)
     delete h;
     return fail(DDMPC_ERR_UNSUPPORTED, "past window of n (m+p) = %d entries exceeds the %d the kernel stages", p.n * k.nch, h->kc.max_past);
@@ -573,6 +586,8 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(h->kc.fn2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(h->kc.fn2r), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(h->kc.fn2c), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
     if (e != hipSuccess) { ddmpc_destroy(h); return fail(DDMPC_ERR_HIP, "hipFuncSetAttribute(LDS=%zu) failed: %s", h->lds_bytes, hipGetErrorString(e)); }
   }
   int rc = upload_params(h);
@@ -747,6 +762,9 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
   KParams kq = kp_override ? *kp_override : h->kp;
   if ((rc = gram_pre_launch(h, kq, h->ud, h->yd, (size_t)h->batch, 0, true))) return rc;
   const int mode = (lfac != nullptr || kq.lam == 0.0) ? DDMPC_REFINE_OFF : kq.refine;
+  // controllers with the slack box: the plain variant that keeps the first factor across active-set iterations (rank-k update);
+  // DDMPC_OPT_CONVEX_UPDATE = 0 selects the variant that factors again in every iteration (the refining variant always does)
+  const cold_kernel2_t plain = (kq.convex && h->convex_update) ? h->kc.fn2c : h->kc.fn2;
   if (mode == DDMPC_REFINE_ALWAYS) {
     hipLaunchKernelGGL(h->kc.fn2r, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                        (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, only, 0LL, (int*)nullptr);
@@ -758,7 +776,7 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
     int* rcount = (int*)h->d_rflag.p + h->batch;
     if (only) HIP_TRY(hipMemsetAsync(h->d_rflag.p, 0, (size_t)h->batch * sizeof(int), h->stream));   // filtered-out instances: no flag
     kq.epoch = next_refine_epoch(h);
-    hipLaunchKernelGGL(h->kc.fn2, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
+    hipLaunchKernelGGL(plain, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                        (int*)iters, bws, aws, stp, lfac, lfacT, (int*)h->d_rflag.p, only, 0LL, rcount);
     HIP_TRY(hipGetLastError());
     kq.refine = DDMPC_REFINE_ALWAYS;
@@ -778,7 +796,7 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
       kq.epoch = h->prep_epoch = next_refine_epoch(h);
       h->flag_epoch = kq.epoch;
     }
-    hipLaunchKernelGGL(h->kc.fn2, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
+    hipLaunchKernelGGL(plain, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                        (int*)iters, bws, aws, stp, lfac, lfacT, rf, only, 0LL, rcount);
   }
   HIP_TRY(hipGetLastError());
@@ -1049,6 +1067,16 @@ static int launch_rr2_gain_build(ddmpc_handle* h, double* scratch, long long ndb
   if ((rc = h->d_gz.ensure(B * (size_t)nrhs * k.r * sizeof(double))) || (rc = h->d_gres.ensure(B * (size_t)nrhs * nFp * sizeof(double))) ||
       (rc = h->d_zvirt.ensure(Bv * (size_t)k.rE * sizeof(double))))
     return rc;
+  if (h->rr2_x_pending) {
+    // the virtual-batch solves below reuse (and re-size) the vectors the last solve kept for the on-demand x = L^-T w of
+    // ddmpc_get_solution(ALPHA): form x now (ddmpc_solve -> ddmpc_prepare -> ddmpc_get_solution)
+    Rr2Solve S0;
+    if ((rc = rr2_solve_desc(h, scratch, ndbl, &S0))) return rc;
+    if ((rc = h->d_xws.ensure(B * (size_t)k.rE * sizeof(double)))) return rc;
+    hipLaunchKernelGGL(rr2_xws_kernel, dim3((unsigned)B), dim3(RR2_TS), 0, h->stream, S0, k, (double*)h->d_xws.p);
+    HIP_TRY(hipGetLastError());
+    h->rr2_x_pending = false;
+  }
   Rr2Solve S;
   if ((rc = rr2_solve_desc(h, scratch, ndbl, &S, Bv))) return rc;
   S.fdiv = RR2_GAIN_CHUNK; S.unit = 1;
@@ -1229,7 +1257,8 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
     }
     KParams kck = kchunk;
     if ((rcl = gram_pre_launch(h, kck, (const double*)(dud + b0 * su), (const double*)(dyd + b0 * sy), nb, b0, false))) break;
-    hipLaunchKernelGGL(always ? h->kc.fn2r : h->kc.fn2, dim3((unsigned)nb), dim3(64 * h->kc.W), h->lds_bytes, h->stream, kck,
+    hipLaunchKernelGGL(always ? h->kc.fn2r : ((h->kp.convex && h->convex_update) ? h->kc.fn2c : h->kc.fn2), dim3((unsigned)nb), dim3(64 * h->kc.W),
+                       h->lds_bytes, h->stream, kck,
                        (const double*)(dud + b0 * su), (const double*)(dyd + b0 * sy), (const double*)(dup + b0 * sup),
                        (const double*)(dyp + b0 * syp), duo + b0 * suo, dco + b0, (int*)(dst + b0), (int*)(dit + b0),
                        (double*)nullptr, (signed char*)nullptr, (unsigned long long*)nullptr, (double*)nullptr,
@@ -1472,6 +1501,9 @@ int ddmpc_set_option(ddmpc_handle* h, int option, int value) {
       h->large_affine = value != 0;
       h->prepared = false;
       h->large_gain_ready = false;
+      return DDMPC_OK;
+    case DDMPC_OPT_CONVEX_UPDATE:
+      h->convex_update = value != 0;
       return DDMPC_OK;
     case DDMPC_OPT_LARGE_PIPELINE:
       if (value != DDMPC_PIPELINE_ONE_WORKGROUP && value != DDMPC_PIPELINE_PHASES)
@@ -1843,6 +1875,12 @@ int ddmpc_debug_stamps(ddmpc_handle* h, int enable, uint64_t* out) {
     int rc = h->d_stamps.ensure(bytes);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(h->d_stamps.p, 0, bytes, h->stream));
+  }
+  if (h->large_nominal && h->stamps_on != (enable != 0)) {
+    // the stamps switch selects the pipeline of NOMINAL controllers beyond 271 rows (phase kernels / one workgroup), and the two
+    // keep different things next to the factors (Minv blocks, live masks): what ddmpc_prepare left is not the other's input
+    h->prepared = false;
+    h->large_gain_ready = false;
   }
   h->stamps_on = enable != 0;
   return DDMPC_OK;

@@ -370,38 +370,43 @@ __global__ __launch_bounds__(256) void ddmpc_gram_tiles_kernel(KParams P, int NT
     // instruction for (row group sg, tile t): D[i][j] = K[4 sg + i][16 t + 4 blk + j]; lane = 16 k + 4 blk + i holds
     // A[i][k] = H[4 sg + i][i0 + k], lane = 16 k + 4 blk + j holds B[k][j] = H[16 t + 4 blk + j][i0 + k] (the same A in all four
     // blocks); D[i][j] comes back in lane 16 i + 4 blk + j (layout probed in tools/mfma_f64_4x4_probe.hip).
-    constexpr int TW = 5, SG = 4;                                           // tiles per wave (NT <= 17 on four waves), row groups (nch <= 16)
+    constexpr int TW = 5, SG = 4;                                           // tiles per wave (NT <= 17 on four waves), row groups per pass
     const int nsg = (nch + 3) >> 2;
-    double acc[SG][TW];
-#pragma unroll
-    for (int g = 0; g < SG; ++g)
-#pragma unroll
-      for (int t = 0; t < TW; ++t) acc[g][t] = 0.0;
     const int kq = lane >> 4, ij = lane & 3;
     const int cfull = c & ~3;
-    const double* pa = xs + kq * nch + ij;                                  // + 4 sg: A of row group sg
-    const double* pb = xs + kq * nch + 16 * wave + (lane & 15);             // + 64 t: B of tile wave + 4 t
-    auto kstep = [&](bool kok) __attribute__((always_inline)) {
-      double av[SG], bv[TW];
-#pragma unroll
-      for (int g = 0; g < SG; ++g) av[g] = (g < nsg && kok) ? pa[4 * g] : 0.0;
-#pragma unroll
-      for (int t = 0; t < TW; ++t) bv[t] = (wave + 4 * t < NT && kok) ? pb[64 * t] : 0.0;
+    // (more than 16 channels: further passes of four row groups over the trajectory -- until round 5 only the first 16
+    //  channels' lag sums were formed and wider plants read unwritten LDS)
+#pragma unroll 1
+    for (int sg0 = 0; sg0 < nsg; sg0 += SG) {
+      double acc[SG][TW];
 #pragma unroll
       for (int g = 0; g < SG; ++g)
 #pragma unroll
-        for (int t = 0; t < TW; ++t)
-          if (g < nsg && wave + 4 * t < NT) acc[g][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[g], bv[t], acc[g][t], 0, 0, 0);   // (wave-uniform)
-    };
-    for (int i0 = 0; i0 < cfull; i0 += 4, pa += 4 * nch, pb += 4 * nch) kstep(true);
-    if (cfull < c) kstep(cfull + kq < c);
+        for (int t = 0; t < TW; ++t) acc[g][t] = 0.0;
+      const double* pa = xs + kq * nch + ij + 4 * sg0;                      // + 4 g: A of row group sg0 + g
+      const double* pb = xs + kq * nch + 16 * wave + (lane & 15);           // + 64 t: B of tile wave + 4 t
+      auto kstep = [&](bool kok) __attribute__((always_inline)) {
+        double av[SG], bv[TW];
 #pragma unroll
-    for (int g = 0; g < SG; ++g)
+        for (int g = 0; g < SG; ++g) av[g] = (sg0 + g < nsg && kok) ? pa[4 * g] : 0.0;
 #pragma unroll
-      for (int t = 0; t < TW; ++t) {
-        const int sig = 4 * g + (lane >> 4), rho = 16 * (wave + 4 * t) + (lane & 15);
-        if (g < nsg && wave + 4 * t < NT && sig < nch && rho < r) ctab[rho * nch + sig] = acc[g][t];
-      }
+        for (int t = 0; t < TW; ++t) bv[t] = (wave + 4 * t < NT && kok) ? pb[64 * t] : 0.0;
+#pragma unroll
+        for (int g = 0; g < SG; ++g)
+#pragma unroll
+          for (int t = 0; t < TW; ++t)
+            if (sg0 + g < nsg && wave + 4 * t < NT) acc[g][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[g], bv[t], acc[g][t], 0, 0, 0);   // (wave-uniform)
+      };
+      for (int i0 = 0; i0 < cfull; i0 += 4, pa += 4 * nch, pb += 4 * nch) kstep(true);
+      if (cfull < c) kstep(cfull + kq < c);
+#pragma unroll
+      for (int g = 0; g < SG; ++g)
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+          const int sig = 4 * (sg0 + g) + (lane >> 4), rho = 16 * (wave + 4 * t) + (lane & 15);
+          if (sg0 + g < nsg && wave + 4 * t < NT && sig < nch && rho < r) ctab[rho * nch + sig] = acc[g][t];
+        }
+    }
   }
   // The chains: chain (rho0, b), rho0 = d nch + a, runs through the entries (sig, rho) = (b + k nch, rho0 + k nch), rho < r.
   // The lanes of a wave take consecutive rho0 of one b: at a given step they read broadcast values x[sig], x[sig + c nch] and

@@ -204,7 +204,11 @@ struct Lds2Limits {
 // records whether it exceeds the threshold; the API re-solves exactly those instances with the REF variant
 // (DDMPC_REFINE_AUTO).  Keeping the loop out of the plain variant keeps its register allocation free of spills on the
 // factorisation's critical path.
-template <int NT, int W, int WAVE, bool REF>
+// CVX: compile the rank-k treatment of the slack box in (see `rank_update` below): active-set iterations after the first keep
+// the factor of the EMPTY active set and treat the k <= KC switched components as a diagonal modification of rank k instead
+// of forming and factoring the whole system again.  A separate instantiation (plain variant only), so that the kernel of
+// controllers without the box -- the headline -- keeps its code and register allocation bit for bit.
+template <int NT, int W, int WAVE, bool REF, bool CVX>
 __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict__ sm,
                                            const double* __restrict__ up, const double* __restrict__ yp,
                                            double* __restrict__ u_opt, double* __restrict__ cost_out,
@@ -289,6 +293,8 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
   // (measured: raising the panel wave's priority with s_setprio costs 3 %: it starves the MFMA waves of the co-resident workgroups)
   int iter = 0;
   int status = 0;
+  int nupd = 0;                      // CVX: solves done by rank-k update so far (iter == 1 + nupd <=> the factor is the first one)
+  bool ctab_ok = false;              // CVX: the lag-block table is in LDS (the rank-k update keeps W = L^-1 E in its place)
   int tid = tid0;
   double kmax = 0.0;                 // panel wave: largest diagonal entry of G = H H' (scale of the residual bound of AUTO refinement)
   long long tphF = 0, tphB = 0, tphT = 0, tphA = 0, tphU = 0;
@@ -514,7 +520,8 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         const int kq = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
         double* PP = sm + LD::pt2;                          // partial lag blocks [time slice][group][lane] (PT2 / LT / PB are idle)
         constexpr int tsl = WAVE % TS, gsl = WAVE / TS;
-        if (iter == 1) {
+        const bool need_lag = CVX ? !ctab_ok : (iter == 1);     // (workgroup-uniform)
+        if (need_lag) {
           double cacc[MAXG];
           static_for<MAXG>([&](auto gi) __attribute__((always_inline)) { cacc[gi()] = 0.0; });
 #pragma nounroll
@@ -571,7 +578,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
           });
         }
         __syncthreads();
-        if (iter == 1) {
+        if (need_lag) {
           for (int e = tid; e < GS * MAXG * 64; e += NTHR) {
             const int g = e >> 6, ln = e & 63;              // (group slice, group in slice) = (g / MAXG, g % MAXG): g is the group
             double sacc = 0.0;
@@ -582,6 +589,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         }
       }
       __syncthreads();
+      ctab_ok = true;
       stamp();   // 2
       static_for<TM::MAXS>([&](auto S) __attribute__((always_inline)) { acc[S] = d4{0.0, 0.0, 0.0, 0.0}; });
       // (2) first tile of every owned tile diagonal from the lag blocks.  Register j of lane (l4, l15 = 4 lo + l3) of
@@ -841,7 +849,11 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         tphT += t1 - t0; tphA += (t2 - t1) + (t4 - t3); tphF += (t3 - t2) + (t5 - t4); tphB += t6 - t5;   // F includes U (wave 0)
       }
     });
-    if (timing && threadIdx.x == 0) { stamps[7] = tphF; stamps[8] = tphB; stamps[9] = tphT; stamps[10] = tphA; stamps[11] = tphU; }
+    if (timing && threadIdx.x == 0) {
+      stamps[7] = tphF; stamps[8] = tphB;
+      if constexpr (CVX) { stamps[9] = 0; stamps[10] = 0; stamps[11] = 0; }         // (the rank-k update's three phases go there)
+      else { stamps[9] = tphT; stamps[10] = tphA; stamps[11] = tphU; }
+    }
     stamp();   // 4
 
     // ---- optional export of the factor (ddmpc_prepare): lower tiles L(I,J), row-major 16x16 each, at
@@ -876,7 +888,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
     //   (2) EVERY wave, redundantly: x_J = M_J' (y_J - sum of the parts), kept in registers for its own products of the
     //       later rounds (lane l15 holds x_J[l15]); the panel wave also writes it to `out`
     //      -- one workgroup barrier per round instead of two.
-    auto back_substitute = [&](double* __restrict__ out) __attribute__((always_inline)) {
+    auto back_substitute = [&](double* __restrict__ out, const double* __restrict__ yin, const int rE) __attribute__((always_inline)) {
       double* Mb = PB;                                               // Mb[J][k][i] = M_J[k][i]
       if constexpr (WAVE == 0) {
         static_for<NT>([&](auto J) __attribute__((always_inline)) {
@@ -910,7 +922,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
           double pi = 0.0;
           static_for<4>([&](auto j) __attribute__((always_inline)) {
             const int k = l4 + 4 * j();
-            double v = tvec[16 * J + k];
+            double v = yin[16 * J + k];
             static_for<W>([&](auto w) __attribute__((always_inline)) {
               if constexpr (TM::has_col(w, J)) v -= pr[w * 16 + k];
             });
@@ -963,7 +975,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         }
       });
     };
-    back_substitute(beta);
+    back_substitute(beta, tvec, rE);
 
     // ---- iterative refinement: residual with EXACT products with the implicit Hankel matrix,
     //        rho = t - ( H (H' beta) + lam D beta ),
@@ -1020,7 +1032,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         });
         __syncthreads();
         forward_substitute();
-        back_substitute(dvec);                                        // delta (dvec is free: D lives in registers)
+        back_substitute(dvec, tvec, rE);                                // delta (dvec is free: D lives in registers)
         double dmx = 0.0, bmx = 0.0;
         static_for<NE>([&](auto e) __attribute__((always_inline)) {
           const int rho = tid + e * NTHR;
@@ -1050,8 +1062,8 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
     stamp();   // 6
 
     // ---- slack box: primal-dual active-set update --------------------------------
-    bool again = false;
-    if (P.convex) {
+    // (writes the new active set; true when it changed and another solve is due)
+    auto active_set_test = [&]() __attribute__((always_inline)) -> bool {
       static_for<NE>([&](auto e) __attribute__((always_inline)) {
         const int rho = tid + e * NTHR;
         if (rho < r && (cK[rho] == K_WPRED || cK[rho] == K_WTERM)) {   // sigma[n*p:], controller.py:659
@@ -1061,8 +1073,241 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         }
       });
       __syncthreads();
-      again = (flags[1] != 0) && (flags[0] == 0);
-      if (again && iter >= P.max_iter) { again = false; status = 4; }
+      bool ag = (flags[1] != 0) && (flags[0] == 0);
+      if (ag && iter >= P.max_iter) { ag = false; status = 4; }
+      return ag;
+    };
+    // ---- the same solve WITHOUT a new factorisation (CVX).  An active-set iteration switches D_ii (and the target) of the
+    // few components S whose slack reached its bound -- 1 or 2 of 136 on the benchmark data, never more than 2 in 640
+    // instances of configs[1] / configs[3] (tools/convex_update_study.py) -- while until round 4 every iteration formed and
+    // factored the whole matrix again.  With K0 = L L' the factor of the EMPTY active set, E = [e_s], s in S, k = |S| <= KC:
+    //     K(act) = K0 - E diag(d) E',  d_s = lam (D0_s - D1_s) > 0        t(act) = t0 + bound E sgn
+    //     beta = K(act)^-1 t(act) = L^-T ( y' + W (diag(1/d) - W'W)^-1 W'y' ),   W = L^-1 E,   y' = y + bound W sgn
+    // (Woodbury; diag(1/d) - W'W is positive definite because K(act) is, and well conditioned: 1/d = lamb_sigma / lam = 1e4
+    // against |W'W| <= 1 / (lam D0) ~ 30).  W: ONE forward substitution of a 16-column block on the matrix pipe, tile row by
+    // tile row -- the accumulator tiles U(K,J) and the tile of right-hand sides are both contracted over their first index,
+    // which is exactly what an accumulator register offers as an MFMA operand (A = acc[j], B = W_K[j]); then M_J from LDS.
+    // Rows above the first switched component are zero and skipped.  W (r x KC, compact) lives in the lag-block table's LDS,
+    // the per-wave partial products in PT2 / LT; the M tiles of the last back substitution are still in the panel buffer.
+    // Then the k x k system by every thread redundantly, and ONE back substitution.  Anything unusual (k > KC, a component
+    // whose D does not change, a non-positive pivot) returns false and the caller factors the system of the new active set
+    // as before.  Results: the same active sets and iteration counts as re-factoring (the CPU study: 0 mismatches, solutions
+    // 5e-13 apart); tests/test_gpu_round5.py.
+    auto rank_update = [&]() __attribute__((always_inline)) -> bool {
+      constexpr int KS = 4;                                          // size of the k x k system (padded with the identity)
+      // columns of W kept: four where two sets of per-wave partial products fit PT2 + LT (up to four waves), else two
+      constexpr int KC = (2 * W * 16 * 4 <= LD::PT2_LEN + LD::LT_LEN) ? 4 : 2;
+      int rE_u = P.rE;                                               // opaque per call (see the top of the iteration loop): the
+      asm volatile("" : "+s"(rE_u));                                 // wave-uniform tests below stay where they are written
+      const int rE = rE_u;
+      double* Wc = ctab;                                             // Wc[row * KC + j]
+      double* wpart = PT2;                                           // [row parity][wave][16][KC]
+      double* sS = part;                                             // [KS][KS] W'W, [16 + x] W'y
+      static_assert(2 * W * 16 * KC <= LD::PT2_LEN + LD::LT_LEN, "two sets of per-wave partial products fit PT2 + LT");
+      static_assert(RP * KC <= LD::CTAB_LEN, "W fits the lag-block table");
+      const long long tu0 = now();
+      // the switched components in ascending order (deterministic: column order decides the summation order)
+      if constexpr (WAVE == 0) {
+        int base = 0;
+        for (int r0 = 0; r0 < RP; r0 += 64) {
+          const int rho = r0 + lane;
+          const int a = (rho < RP) ? act[rho] : 0;
+          const unsigned long long mk = __ballot(a != 0);
+          const int slot = base + __popcll(mk & ((1ull << lane) - 1ull));
+          if (a != 0 && slot < KC) flags[4 + slot] = rho;
+          base += __popcll(mk);
+        }
+        if (lane == 0) flags[2] = base;
+      }
+      __syncthreads();
+      const int k = flags[2];
+      if (k > KC || k < 1) return false;                             // (workgroup-uniform)
+      if (tid == 0) flags[1] = 0;                                    // (everybody has read it: barrier above)
+      ctab_ok = false;
+      const int s0 = flags[4];
+      const int sj = (l15 == 0) ? s0 : (l15 == 1) ? flags[5] : (l15 == 2) ? flags[6] : flags[7];
+      int J0 = s0 >> 4;                                              // first tile row with a nonzero row of W
+      J0 = __builtin_amdgcn_readfirstlane(J0);
+      // One workgroup barrier per tile row.  W_J = M_J (E_J - sum_{K<J} U(K,J)' W_K): only the term K = J - 1 needs the tile row
+      // just finished, and the whole first sub-diagonal of tiles belongs to ONE wave (TileMap2 deals whole diagonals) -- the
+      // chain wave CW.  It keeps W_{J-1} in registers, adds the other terms -- formed one row AHEAD by every wave from the rows
+      // already in LDS, beside the chain -- and applies M_J itself; the panel wave (idle here: it owns the diagonal tiles only)
+      // accumulates W'W and W'y one row behind.  (First version: partial products of row J by every wave -> barrier -> the
+      // panel wave -> barrier: 28 K cycles per update on the benchmark against 15 K for the back substitution.)
+      constexpr int CW = TM::wave(1, 0);
+      auto noncrit = [](int w, int J) constexpr { for (int K = 0; K + 2 <= J; ++K) if (TM::wave(J, K) == w) return true; return false; };
+      d4 sacc = d4{0.0, 0.0, 0.0, 0.0}, gacc = d4{0.0, 0.0, 0.0, 0.0}, Wprev = d4{0.0, 0.0, 0.0, 0.0};
+      const double* Mb = PB;
+      static_for<NT + 1>([&](auto JJ) __attribute__((always_inline)) {
+        constexpr int J = JJ;
+        asm volatile("" : "+s"(J0));                                 // (opaque per tile row: no hoisted lane masks)
+        const bool do_chain = J < NT && J >= J0 && 16 * J < rE;      // workgroup-uniform
+        const bool do_gram = J >= 1 && J - 1 >= J0 && 16 * (J - 1) < rE;
+        if constexpr (J < NT) {
+          if (do_chain) {
+            if constexpr (WAVE == CW) {
+              d4 Pc = d4{0.0, 0.0, 0.0, 0.0};
+              if constexpr (J >= 1) {
+                if (J > J0) {                                        // the term that waits for the row before
+                  constexpr int S = TM::slot(J, J - 1);
+                  static_for<4>([&](auto j) __attribute__((always_inline)) {
+                    Pc = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[S][j()], Wprev[j()], Pc, 0, 0, 0);
+                  });
+                }
+              }
+              d4 V;
+              static_for<4>([&](auto q) __attribute__((always_inline)) {
+                const int row = 16 * J + l4 + 4 * q();
+                double v = (l15 < k && sj == row) ? 1.0 : 0.0;
+                if constexpr (J >= 2) {
+                  if (J > J0 + 1) {                                  // the terms K <= J - 2, formed during the step before
+                    static_for<W>([&](auto w) __attribute__((always_inline)) {
+                      if constexpr (noncrit(w(), J)) v -= wpart[(((J & 1) * W + w()) * 16 + l4 + 4 * q()) * KC + (l15 & (KC - 1))];
+                    });
+                  }
+                }
+                V[q()] = (l15 < KC && row < rE) ? v - Pc[q()] : 0.0;
+              });
+              d4 Wt = d4{0.0, 0.0, 0.0, 0.0};
+              static_for<4>([&](auto ks) __attribute__((always_inline)) {
+                Wt = __builtin_amdgcn_mfma_f64_16x16x4f64(Mb[J * 256 + l15 * 16 + 4 * ks() + l4], V[ks()], Wt, 0, 0, 0);
+              });
+              if (l15 < KC) {
+                static_for<4>([&](auto q) __attribute__((always_inline)) { Wc[(16 * J + l4 + 4 * q()) * KC + l15] = Wt[q()]; });
+              }
+              Wprev = Wt;
+            }
+          }
+        }
+        // one row ahead: the terms K <= J - 1 of tile row J + 1 (W_K is in LDS since the barrier of step K)
+        if constexpr (J + 1 < NT && J >= 1) {
+          if (J >= J0 + 1 && 16 * (J + 1) < rE) {
+            if constexpr (noncrit(WAVE, J + 1)) {
+              d4 pacc = d4{0.0, 0.0, 0.0, 0.0};
+              static_for<J>([&](auto K) __attribute__((always_inline)) {
+                if constexpr (TM::wave(J + 1, K) == WAVE) {
+                  if (K >= J0) {
+                    constexpr int S = TM::slot(J + 1, K);
+                    static_for<4>([&](auto j) __attribute__((always_inline)) {
+                      const double wv = Wc[(16 * K + 4 * j() + l4) * KC + (l15 & (KC - 1))];
+                      pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[S][j()], (l15 < KC) ? wv : 0.0, pacc, 0, 0, 0);
+                    });
+                  }
+                }
+              });
+              if (l15 < KC) {
+                static_for<4>([&](auto q) __attribute__((always_inline)) {
+                  wpart[((((J + 1) & 1) * W + WAVE) * 16 + l4 + 4 * q()) * KC + l15] = pacc[q()];
+                });
+              }
+            }
+          }
+        }
+        // one row behind: W'W and W'y of tile row J - 1
+        if constexpr (WAVE == 0 && J >= 1) {
+          if (do_gram) {
+            static_for<4>([&](auto q) __attribute__((always_inline)) {
+              const double wv = Wc[(16 * (J - 1) + 4 * q() + l4) * KC + (l15 & (KC - 1))];
+              const double wq = (l15 < KC) ? wv : 0.0;
+              const double yv = tvec[16 * (J - 1) + 4 * q() + l4];
+              sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(wq, wq, sacc, 0, 0, 0);
+              gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(wq, (l15 == 0) ? yv : 0.0, gacc, 0, 0, 0);
+            });
+          }
+        }
+        if (do_chain) __syncthreads();                               // W_J (and the terms of row J + 1) are in LDS
+      });
+      const long long tu1 = now();
+      // ---- the k x k system, by the panel wave (every lane redundantly; the other waves hold up to 13 accumulator tiles and
+      //      have no registers to spare for it):  (diag(1/d) - W'W) cv = W'y',  y' = y + bound W sgn;  coefficients
+      //      ev = bound sgn + cv of  y' + W cv = y + W ev  go to sS[24 ..], flags[3] = 1 when a pivot failed
+      if constexpr (WAVE == 0) {
+        if (l15 < KS) sS[l4 * KS + l15] = sacc[0];                   // (W'W)[x = l4][y = l15]
+        if (l15 == 0) sS[16 + l4] = gacc[0];                         // (W'y)[x = l4]
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // in-wave hand-off through LDS (see factor_begin)
+        // lane 4 x + y (< 16) holds entry (x, y) of Sm = diag(1/d) - W'W (identity on the padding) in ONE register; the
+        // Cholesky runs across the lanes (three shuffles per column) -- a register-resident 4 x 4 factorisation in every lane
+        // took 56 VGPRs next to the nine accumulator tiles and pushed three of those into scratch for the whole kernel
+        const int sx = (lane >> 2) & 3, sy = lane & 3;
+        const bool on_x = sx < k, on_y = sy < k;
+        const int srx = on_x ? flags[4 + sx] : 0, sry = on_y ? flags[4 + sy] : 0;
+        const double ddx = P.lam * (cD0[srx] - cD1[srx]);
+        bool ok = !on_x || ddx > 1e-300;
+        const double sgy = on_y ? (double)act[sry] * P.bound : 0.0;   // bound sgn of component y
+        const double gxy = (on_x && on_y) ? sS[sx * KS + sy] : 0.0;   // (W'W)[x][y]
+        double av = -gxy;
+        if (sx == sy) av = on_x ? 1.0 / ddx - gxy : 1.0;
+        double hp = gxy * sgy;                                         // h_x = (W'y)_x + sum_y (W'W)[x][y] bound sgn_y
+        hp += __shfl_xor(hp, 1, 64); hp += __shfl_xor(hp, 2, 64);
+        const double hx = hp + (on_x ? sS[16 + sx] : 0.0);
+        static_for<KS>([&](auto jj) __attribute__((always_inline)) {
+          constexpr int j = jj;
+          const double pj = __shfl(av, 5 * j, 64);
+          ok = ok && (pj > 0.0);
+          const double il = 1.0 / sqrt(pj);
+          const double axj = __shfl(av, 4 * sx + j, 64) * il, ayj = __shfl(av, 4 * sy + j, 64) * il;
+          if (sx > j && sy > j) av = fma(-axj, ayj, av);
+          else if (sy == j && sx > j) av = axj;
+          else if (sx == j && sy == j) av = il;                       // (the reciprocal pivot is kept)
+        });
+        ok = __ballot(!ok && lane < 16) == 0ull;
+        if (lane < 16) sS[lane] = av;                                 // L (lower), reciprocal pivots on the diagonal
+        if (lane < 16 && sy == 0) sS[20 + sx] = hx;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < KS) {                                              // forward and backward substitution, then ev = bound sgn + cv
+          double c0 = sS[20] * sS[0];
+          double c1 = (sS[21] - sS[4] * c0) * sS[5];
+          double c2 = (sS[22] - sS[8] * c0 - sS[9] * c1) * sS[10];
+          double c3 = (sS[23] - sS[12] * c0 - sS[13] * c1 - sS[14] * c2) * sS[15];
+          c3 = c3 * sS[15];
+          c2 = (c2 - sS[14] * c3) * sS[10];
+          c1 = (c1 - sS[9] * c2 - sS[13] * c3) * sS[5];
+          c0 = (c0 - sS[4] * c1 - sS[8] * c2 - sS[12] * c3) * sS[0];
+          const double cv = (lane == 0) ? c0 : (lane == 1) ? c1 : (lane == 2) ? c2 : c3;
+          const int srl = (lane < k) ? flags[4 + lane] : 0;
+          sS[24 + lane] = cv + ((lane < k) ? (double)act[srl] * P.bound : 0.0);
+        }
+        if (lane == 0) flags[3] = ok ? 0 : 1;
+      }
+      __syncthreads();
+      const long long tu2 = now();
+      if (flags[3] != 0) return false;                               // (workgroup-uniform)
+      const double e0 = sS[24], e1 = sS[25], e2 = sS[26], e3 = sS[27];
+      static_assert(KS == 4 && 28 <= LD::PART_LEN, "four coefficients behind the k x k system in part[]");
+      static_for<NE>([&](auto e) __attribute__((always_inline)) {
+        const int rho = tid + e * NTHR;
+        if (rho < RP) {
+          double v = 0.0;
+          if (rho < rE) {
+            v = tvec[rho];
+            if (rho >= 16 * J0) {
+              const d2 w01 = *reinterpret_cast<const d2*>(Wc + rho * KC);
+              v = fma(w01[0], e0, v); v = fma(w01[1], e1, v);
+              if constexpr (KC == 4) {
+                const d2 w23 = *reinterpret_cast<const d2*>(Wc + rho * KC + 2);
+                v = fma(w23[0], e2, v); v = fma(w23[1], e3, v);
+              }
+            }
+          }
+          dvec[rho] = v;
+        }
+      });
+      __syncthreads();
+      back_substitute(beta, dvec, rE);
+      if (timing && threadIdx.x == 0) {                              // diagnostics: forward block substitution | k x k system | back substitution
+        stamps[9] += (unsigned long long)(tu1 - tu0); stamps[10] += (unsigned long long)(tu2 - tu1); stamps[11] += (unsigned long long)(now() - tu2);
+      }
+      return true;
+    };
+    bool again = false;
+    if (P.convex) {
+      for (;;) {
+        again = active_set_test();
+        if constexpr (!CVX) break;
+        if (!again || iter != 1 + nupd) break;                        // (the factor at hand is not the empty active set's)
+        if (!rank_update()) break;
+        ++iter; ++nupd;
+      }
     }
     if (!again) break;
   }
@@ -1332,7 +1577,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
 // short persistent grid (nbatch > 0: workgroup g takes instances g, g + gridDim.x, ... and skips the ones `only` filters
 // out): the AUTO refinement pass usually finds few or no flagged instances, and 768 workgroups scanning flags cost less
 // than a batch-sized grid of workgroups that exit at once.
-template <int NT, int W, bool REF>
+template <int NT, int W, bool REF, bool CVX = false>
 __global__ __launch_bounds__(64 * W, DDMPC_MIN_WAVES(NT, W)) void ddmpc_cold_solve_kernel2(
     KParams P, const double* __restrict__ u_d, const double* __restrict__ y_d,
     const double* __restrict__ u_past, const double* __restrict__ y_past, double* __restrict__ u_opt,
@@ -1426,7 +1671,7 @@ __global__ __launch_bounds__(64 * W, DDMPC_MIN_WAVES(NT, W)) void ddmpc_cold_sol
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   static_for<W>([&](auto WV) {
     if (wave == WV)
-      wave_body2<NT, W, WV, REF>(P, sm, up, yp, uo, cost + b, status + b, it, bw, aw, st, lf, lft,
+      wave_body2<NT, W, WV, REF, CVX && !REF>(P, sm, up, yp, uo, cost + b, status + b, it, bw, aw, st, lf, lft,
                                  refine_flag ? refine_flag + b : nullptr, REF ? nullptr : refine_count,
                                  P.gpre ? P.gpre + b * P.gpre_stride : nullptr);
   });

@@ -502,10 +502,13 @@ __global__ __launch_bounds__(512) void rr2_hankel_mfma_kernel(Rr2Solve S, KParam
     const int per = (nS + kparts - 1) / kparts;
     d4 acc = d4{0.0, 0.0, 0.0, 0.0};
     if (kp < kparts) {
-      const int a = (16 * ta + l15) < (G.NBK - 4) ? (16 * ta + l15) : (G.NBK - 4);   // (a >= na: later columns -- not stored; kept inside the staged rows)
+      const int a = 16 * ta + l15;                       // (a >= na: later columns -- computed from staged rows, never stored)
       const int s1 = (kp + 1) * per < nS ? (kp + 1) * per : nS;
       for (int sI = kp * per; sI < s1; ++sI) {
-        const double* pa = xT + ((sI & 15) * G.NBK + (a + (sI >> 4))) * G.RS + l4;
+        // the ROW is clamped to the staged block of this residue, whatever L + n is (lanes with a < na never reach the clamp:
+        // na - 1 + (Ln + 14) / 16 < NBK): a lane past the columns reads finite staged data, not the neighbouring region
+        const int row = (a + (sI >> 4)) < G.NBK ? (a + (sI >> 4)) : G.NBK - 1;
+        const double* pa = xT + ((sI & 15) * G.NBK + row) * G.RS + l4;
         const double* pb = xp + (sI - l15 + 15) * G.RS + l4;
         for (int c4 = 0; c4 < c4n; ++c4) acc = rr2_mfma(pa[4 * c4], pb[4 * c4], acc);
       }

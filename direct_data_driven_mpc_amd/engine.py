@@ -251,6 +251,11 @@ class BatchedDDMPC:
         L.check(self._lib.ddmpc_set_option(self._h, L.OPT_LARGE_PIPELINE,
                                            {"one_workgroup": L.PIPELINE_ONE_WORKGROUP, "phases": L.PIPELINE_PHASES}[mode]))
 
+    def set_convex_update(self, on: bool) -> None:
+        """Slack CONVEX on the register-resident kernels: True (default) = active-set iterations after the first keep the first
+        factor (rank-k update), False = every iteration factors the system again (DDMPC_OPT_CONVEX_UPDATE)."""
+        L.check(self._lib.ddmpc_set_option(self._h, L.OPT_CONVEX_UPDATE, 1 if on else 0))
+
     def set_large_affine_law(self, on: bool) -> None:
         """NOMINAL controllers beyond the register-resident kernels: `prepare` also forms the affine law z(past) and `step`
         evaluates it (DDMPC_OPT_LARGE_AFFINE_LAW; default off: `step` repeats the solve on the kept factors)."""

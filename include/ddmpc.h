@@ -120,6 +120,13 @@ extern "C" {
                                          returns it as [batch][n(m+p)+1][(m+p)(L+n)], z = [ubar; ybar] per component = gain[0] +
                                          gain[1:]' [u_past; y_past].  0 (default): ddmpc_step repeats the solve on the kept factors,
                                          bit-equal to ddmpc_solve (controller.py:389-407) */
+#define DDMPC_OPT_CONVEX_UPDATE 8      /* ROBUST controllers with the CONVEX slack box on the register-resident kernels
+                                         (controller.py:631-677): 1 (default) = active-set iterations after the first keep the factor
+                                         of the empty active set and treat the <= 4 switched slack components as a diagonal modification
+                                         of rank k (Woodbury: one block forward substitution on the matrix pipe, a k x k system, one
+                                         back substitution); more components, or anything unusual, falls back to 0 = the whole system is
+                                         formed and factored again in every iteration (rounds 1-4).  Same active sets, iteration
+                                         counts and -- to rounding -- solutions */
 #define DDMPC_REFINE_RES_DEFAULT 107  /* 2e-11: benchmark data stays below ~2e-12, the parity bars are missed from ~1.3e-10 on */
 
 typedef struct ddmpc_handle ddmpc_handle;

@@ -167,6 +167,11 @@ def test_bench_self_launches_two_ranks_and_gathers_bit_exactly(gpu, tmp_path):
     dinfo = rec["distributed"]
     assert dinfo["world_size"] == 2 and dinfo["backend"] == "gloo" and [r["rank"] for r in dinfo["ranks"]] == [0, 1]
     assert all(r["device"] == 0 and r["name"] for r in dinfo["ranks"])
+    # round 5: the N > 1 line carries the single-GPU rate at the SAME per-GPU batch and the efficiency against it
+    ref = rec["per_gpu_reference"]
+    assert ref["batch"] == 96 and ref["steps"] == 2 and ref["value"] > 0 and ref["ms_per_step"] > 0
+    assert abs(rec["scaling_efficiency_vs_same_batch"] - rec["value"] / (2 * ref["value"])) < 1e-12
+    assert "configs[2]" in rec["config"]["workload"] or "custom batch" in rec["config"]["workload"]
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch-per-gpu", "192",
                           "--dump-gathered", str(g1)] + common, capture_output=True, text=True, timeout=900, env=env)
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
