@@ -2,7 +2,7 @@
 // Host-side responsibilities: parameter validation with the reference's error
 // conditions (direct_data_driven_mpc_controller.py:165-168,211-222,298-343,664-670),
 // device buffer ownership, kernel-instance selection, launch.
-#include "ddmpc_rr2_solve.hpp"
+#include "ddmpc_rr3.hpp"
 #include "../../include/ddmpc.h"
 
 #include <cmath>
@@ -162,6 +162,9 @@ struct ddmpc_handle {
   bool gain_step_last = false;             // ... the last solve was a step on the law (no w to form alpha from)
   bool rr2_x_pending = false;              // ... x = L^-T w of the last solve has not been formed yet (ddmpc_get_solution does it on demand)
   DevBuf d_rr2mt;                          // ... Minv of every 64 x 64 diagonal block of the two factors (ddmpc_rr2.hpp)
+  DevBuf d_rr3w, d_rr3k, d_rr_fb, d_rrmeta_fb;   // ROBUST beyond 271 rows on the phase kernels (ddmpc_rr3.hpp): W + the k x k factor, the per-instance
+                                          // ints; workspace / record of the fall-back (ddmpc_large_solve_kernel on instances marked 5)
+  int nA3 = 0;                            // ... first position of the slack-box components in the "boxed last" order
   DevBuf d_gpre;                          // Gram tiles of ddmpc_gram_tiles_kernel (structured Gram, m + p != 4), see gram_pre_launch
   bool gram_pre = false, gpre_valid = false;
   DevBuf d_perm, d_rr2d, d_rr2res;                   // phase kernels (ddmpc_rr2.hpp): fixed-first component order [perm | iperm]; per instance
@@ -326,6 +329,23 @@ static int upload_params(ddmpc_handle* h) {
     for (int i = 0; i + h->nF < k.r; ++i) { wz[i] = td[3 * (size_t)RP + pm[h->nF + i]]; wz[rv + i] = td[2 * (size_t)RP + pm[h->nF + i]]; }
     if ((rc = h->d_wz.ensure(wz.size() * sizeof(double)))) return rc;
     HIP_TRY(hipMemcpy(h->d_wz.p, wz.data(), wz.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (h->large && !h->large_nominal) {
+    // ROBUST beyond the register-resident kernels on the phase kernels (ddmpc_rr3.hpp): the components the slack box acts on
+    // go LAST (time order inside both classes), so that every active-set iteration works on the trailing block of the factor
+    const size_t rv = ((size_t)k.r + 1) & ~(size_t)1;
+    std::vector<int> pm(2 * rv, 0);
+    int pos = 0;
+    for (int cls = 0; cls < 2; ++cls) {
+      for (int rho = 0; rho < k.r; ++rho) {
+        const int kd = ti[0 * RP + rho];
+        const bool boxed = k.convex && (kd == K_WPRED || kd == K_WTERM);
+        if ((boxed ? 1 : 0) == cls) { pm[pos] = rho; pm[rv + rho] = pos; ++pos; }
+      }
+      if (cls == 0) h->nA3 = pos;
+    }
+    if ((rc = h->d_perm.ensure(pm.size() * sizeof(int)))) return rc;
+    HIP_TRY(hipMemcpy(h->d_perm.p, pm.data(), pm.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   h->kp.dense_w = 0;
   h->kp.dmat = nullptr;
@@ -603,7 +623,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_gpre, &h->d_perm, &h->d_rr2d, &h->d_rr2res, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz, &h->d_gz, &h->d_gres, &h->d_zvirt};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_gpre, &h->d_perm, &h->d_rr2d, &h->d_rr2res, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz, &h->d_gz, &h->d_gres, &h->d_zvirt, &h->d_rr3w, &h->d_rr3k, &h->d_rr_fb, &h->d_rrmeta_fb};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -710,6 +730,117 @@ static int gram_pre_launch(ddmpc_handle* h, KParams& kq, const double* ud, const
   return DDMPC_OK;
 }
 
+// ---- ROBUST controllers beyond the register-resident kernels on the phase kernels (ddmpc_rr3.hpp) ----------------------------
+static long long rr3_ndbl(const ddmpc_handle* h) { return (long long)pk_size(((size_t)h->kp.r + 15) & ~(size_t)15); }
+// What depends on the data and the weights alone: G (boxed components last) + lam D0, its Cholesky factor with the Minv blocks.
+static int launch_rr3_factors(ddmpc_handle* h) {
+  const KParams& k = h->kp;
+  const int r = k.r, n16 = (r + 15) & ~15, rv = (r + 1) & ~1;
+  const long long ndbl = rr3_ndbl(h), mstride = 2 * (long long)rv + 2;
+  const size_t B = (size_t)h->batch;
+  const long long m64G = (long long)((n16 + RR2_NB - 1) / RR2_NB) * RR2_NB * RR2_NB;
+  int rc;
+  if ((rc = h->d_rr.ensure(B * (size_t)ndbl * sizeof(double))) || (rc = h->d_rrmeta.ensure(B * (size_t)mstride * sizeof(int))) ||
+      (rc = h->d_rr2d.ensure(B * 4 * sizeof(unsigned long long))) || (rc = h->d_rr2mt.ensure(B * (size_t)m64G * sizeof(double))))
+    return rc;
+  HIP_TRY(hipMemsetAsync(h->d_rr2d.p, 0, B * 4 * sizeof(unsigned long long), h->stream));
+  unsigned long long* dd = (unsigned long long*)h->d_rr2d.p;
+  const int* perm = (const int*)h->d_perm.p;
+  double* scratch = (double*)h->d_rr.p;
+  hipLaunchKernelGGL(rr2_gram_kernel, dim3((unsigned)((k.Ln + 4 * RR2_SL - 1) / (4 * RR2_SL)), (unsigned)B), dim3(256), 0, h->stream,
+                     k, h->ud, h->yd, perm + rv, scratch, ndbl, n16, dd);
+  hipLaunchKernelGGL(rr3_shift_kernel, dim3((unsigned)B), dim3(256), 0, h->stream, k, 16 * h->kc.NT, perm, scratch, ndbl);
+  Rr2Chol FG{};
+  FG.ws = scratch; FG.stride = ndbl; FG.off = 0; FG.n16 = n16; FG.n_inst = nullptr; FG.n_stride = 0;
+  FG.dmax = dd + 0; FG.d_stride = 4; FG.tol_rel = 0.0; FG.skip = (int*)h->d_rrmeta.p; FG.s_stride = mstride; FG.nflag = r;
+  FG.live = dd + 2; FG.l_stride = 4; FG.m64 = (double*)h->d_rr2mt.p; FG.m64_stride = m64G;
+  FG.res = nullptr; FG.res_stride = 0; FG.dead = nullptr; FG.dead_stride = 0;
+  const int nt = n16 >> 4;
+  for (int c0 = 0; c0 < n16; c0 += RR2_NB) {
+    hipLaunchKernelGGL(rr2_chol_panel_kernel, dim3(1, (unsigned)B), dim3(256), 0, h->stream, FG, c0);
+    const int nbelow = nt - (c0 >> 4) - 4;
+    if (nbelow > 0)
+      hipLaunchKernelGGL(rr2_chol_update_kernel<RR2_UT>, dim3((unsigned)((nbelow + 4 * RR2_UT - 1) / (4 * RR2_UT)), (unsigned)B),
+                         dim3(256), 0, h->stream, FG, c0);
+  }
+  HIP_TRY(hipGetLastError());
+  return DDMPC_OK;
+}
+
+// The solve on those factors (what a control step repeats, controller.py:389-407).
+static int launch_rr3_solve(ddmpc_handle* h, const KParams& kq, const double* up, const double* yp, double* uo, double* cost,
+                            int32_t* status, int32_t* iters) {
+  const int r = kq.r, n16 = (r + 15) & ~15, rv = (r + 1) & ~1, VL = (r + 63) & ~63;
+  const size_t B = (size_t)h->batch;
+  const long long m64G = (long long)((n16 + RR2_NB - 1) / RR2_NB) * RR2_NB * RR2_NB;
+  const int nA = kq.convex ? h->nA3 : r, n0 = nA & ~63;
+  const int ldw = ((r - n0) + 63) & ~63;
+  const Rr3Lds LD = Rr3Lds::make(r);
+  const size_t lds = (size_t)LD.total * sizeof(double);
+  const long long wstride = (long long)RR3_KMAX * ldw + (long long)RR3_KMAX * (RR3_KMAX + 1), kstride = 4 + RR3_KMAX + rv + 4;
+  int rc;
+  if ((rc = h->d_rr2v.ensure(B * (size_t)R3_NV * VL * sizeof(double))) || (rc = h->d_rr2zp.ensure(B * (size_t)RR2_NG * VL * sizeof(double))) ||
+      (rc = h->d_rr3w.ensure(B * (size_t)wstride * sizeof(double))) || (rc = h->d_rr3k.ensure(B * (size_t)kstride * sizeof(int))) ||
+      (rc = h->d_beta.ensure(B * (size_t)kq.rE * sizeof(double))) || (rc = h->d_act.ensure(B * (size_t)kq.rE)))
+    return rc;
+  Rr3 S{};
+  S.ws = (const double*)h->d_rr.p; S.stride = rr3_ndbl(h);
+  S.m64 = (const double*)h->d_rr2mt.p; S.m64_stride = m64G;
+  S.skip = (const int*)h->d_rrmeta.p; S.s_stride = 2 * (long long)rv + 2;
+  S.dd = (const unsigned long long*)h->d_rr2d.p;
+  S.perm = (const int*)h->d_perm.p;
+  S.rv = rv; S.r = r; S.nA = nA; S.n0 = n0;
+  S.V = (double*)h->d_rr2v.p; S.vstride = (long long)R3_NV * VL; S.VL = VL;
+  S.ZP = (double*)h->d_rr2zp.p;
+  S.Wg = (double*)h->d_rr3w.p; S.wstride = wstride; S.ldw = ldw;
+  S.kq = (int*)h->d_rr3k.p; S.kstride = kstride;
+  const int RPs = 16 * h->kc.NT;
+  const bool refine = kq.refine != DDMPC_REFINE_OFF && kq.lam != 0.0;
+  if (lds > 64 * 1024) {
+    HIP_TRY(hipFuncSetAttribute((const void*)rr3_solve_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)rr3_solve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  hipLaunchKernelGGL(rr3_solve_kernel<false>, dim3((unsigned)B), dim3(RR2_TS), lds, h->stream, S, kq, RPs, up, yp, uo, cost, (int*)status,
+                     (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, refine ? 1 : 0);
+  if (refine) {
+    // H (H' beta) with exact products (the Hankel kernels of the NOMINAL pipeline: they read slot R3_X of the vectors)
+    Rr2Solve H{};
+    H.V = S.V; H.vstride = S.vstride; H.VL = VL; H.ZP = S.ZP; H.fdiv = 1; H.r = r;
+    int hk_ng = 0;
+    size_t hk_lds = 0;
+    if (kq.nch <= 16) {
+      for (int ng = RR2_NG; ng >= 1 && hk_ng == 0; --ng) {
+        const Rr2HankelGeom G = rr2_hankel_geom(kq.c, kq.Ln, kq.nch, ng);
+        const size_t bytes = rr2_hankel_mfma_lds(G, kq.Ln) * sizeof(double);
+        if ((G.cg >= 64 || ng == 1) && bytes <= 80 * 1024 && G.ntA <= 8 && G.ntZ <= 8) { hk_ng = ng; hk_lds = bytes; }
+      }
+      if (hk_ng && hk_lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)rr2_hankel_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hk_lds));
+    }
+    if (hk_ng) hipLaunchKernelGGL(rr2_hankel_mfma_kernel, dim3((unsigned)RR2_NG, (unsigned)B), dim3(512), hk_lds, h->stream, H, kq, h->ud, h->yd, (int)R3_X, 0, hk_ng);
+    else hipLaunchKernelGGL(rr2_hankel_kernel, dim3(RR2_NG, (unsigned)B), dim3(512), 0, h->stream, H, kq, h->ud, h->yd, (int)R3_X, 0);
+    hipLaunchKernelGGL(rr3_solve_kernel<true>, dim3((unsigned)B), dim3(RR2_TS), lds, h->stream, S, kq, RPs, up, yp, uo, cost, (int*)status,
+                       (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, 0);
+  }
+  HIP_TRY(hipGetLastError());
+  {
+    // instances the phase solve marked 5 (more switched components than W holds, a failed pivot of the k x k system): the
+    // one-workgroup kernel of rounds 1-4 solves them from scratch in a workspace of its own; every other workgroup leaves at once
+    const size_t rr = (size_t)r, npk = pk_size(rr), rvv = (rr + 1) & ~(size_t)1;
+    const size_t nB = kq.convex ? (size_t)h->prm.p * h->prm.L : 0;
+    const size_t nlag = (size_t)kq.Ln * kq.nch * kq.nch, sb = 2 * pk_size(nB);
+    const size_t stride = (npk + (nlag > sb ? nlag : sb) + 15) & ~(size_t)15;
+    if ((rc = h->d_rr_fb.ensure(B * stride * sizeof(double))) || (rc = h->d_rrmeta_fb.ensure(B * sizeof(int)))) return rc;
+    const size_t flds = 6 * rvv * sizeof(double) + 4 * rvv * sizeof(int) + (size_t)PSD_PAN * sizeof(double);
+    if (flds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_large_solve_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+    hipLaunchKernelGGL(ddmpc_large_solve_kernel<0>, dim3((unsigned)(B < 8 ? B : 8)), dim3(large_threads(rr)), flds, h->stream, kq, RPs, h->ud, h->yd, up, yp, uo,
+                       cost, (int*)status, (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, (double*)h->d_rr_fb.p, (long long)stride,
+                       (int*)h->d_rrmeta_fb.p, 5, (long long)B);
+    HIP_TRY(hipGetLastError());
+  }
+  return DDMPC_OK;
+}
+
 static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
                        int32_t* status, int32_t* iters, double* lfac = nullptr, const int* only = nullptr,
                        const KParams* kp_override = nullptr, bool want_ws = true, double* lfacT = nullptr, int large_mode = 0) {
@@ -719,6 +850,13 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
   h->ws_stale = !want_ws && !h->large;
   if (h->large_nominal) {          // no cold kernel at this size: every instance goes to the rank-revealing kernel
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)status, 4, (size_t)h->batch, h->stream));
+    return DDMPC_OK;
+  }
+  if (h->large && h->prm.weight_kind != DDMPC_WEIGHT_DENSE && h->large_pipeline == DDMPC_PIPELINE_PHASES && h->batch <= 65535 && !h->stamps_on) {
+    // ... on the phase kernels (ddmpc_rr3.hpp): lock-step factorisation of the whole batch, then one workgroup per instance
+    // that streams the factor twice and runs the active-set iterations on its trailing block
+    if (large_mode != 2 && (rc = launch_rr3_factors(h))) return rc;
+    if (large_mode != 1 && (rc = launch_rr3_solve(h, kp_override ? *kp_override : h->kp, up, yp, uo, cost, status, iters))) return rc;
     return DDMPC_OK;
   }
   if (h->large) {                  // robust scheme beyond the register-resident kernels: matrices in a global workspace
@@ -737,7 +875,7 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
       hipLaunchKernelGGL(fn, dim3((unsigned)h->batch), dim3(large_threads(r)), lds, h->stream,
                          kp_override ? *kp_override : h->kp, 16 * h->kc.NT, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                          (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, (double*)h->d_rr.p, (long long)stride,
-                         (int*)h->d_rrmeta.p);
+                         (int*)h->d_rrmeta.p, 0, (long long)h->batch);
       return DDMPC_OK;
     };
     if ((rc = large_mode == 1 ? launch(ddmpc_large_solve_kernel<1>) : large_mode == 2 ? launch(ddmpc_large_solve_kernel<2>)
@@ -1895,6 +2033,20 @@ int ddmpc_debug_poison_allocations(int byte) {
 int ddmpc_debug_workspace(ddmpc_handle* h, int64_t b, double* ws_out, int64_t ws_count, int32_t* meta_out, int64_t meta_count,
                           int64_t* ws_avail, int64_t* meta_avail) {
   if (!h) return fail(DDMPC_ERR_INVALID, "null handle");
+  if (h->large && !h->large_nominal && h->d_rr3k.p) {
+    // ROBUST on the phase kernels (ddmpc_rr3.hpp): the per-instance record of the last solve --
+    // [k, state, iterations, k, switched positions (RR3_KMAX), active set (rv), start tick, ticks] -- into meta_out
+    const int rv = (h->kp.r + 1) & ~1;
+    const long long kstride = 4 + RR3_KMAX + rv + 4;
+    if (meta_avail) *meta_avail = kstride;
+    if (ws_avail) *ws_avail = 0;
+    if (b < 0 || b >= h->batch) return fail(DDMPC_ERR_INVALID, "instance out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (meta_out && meta_count > 0)
+      HIP_TRY(hipMemcpy(meta_out, (const int*)h->d_rr3k.p + b * kstride, (size_t)(meta_count < kstride ? meta_count : kstride) * sizeof(int), hipMemcpyDeviceToHost));
+    return DDMPC_OK;
+  }
   if (!h->large_nominal || !h->d_rr.p || !h->d_rrmeta.p) return fail(DDMPC_ERR_NOT_READY, "no global workspace to read");
   if (b < 0 || b >= h->batch) return fail(DDMPC_ERR_INVALID, "instance out of range");
   HIP_TRY(hipSetDevice(h->device));

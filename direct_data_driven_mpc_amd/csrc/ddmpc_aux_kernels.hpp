@@ -2133,17 +2133,16 @@ __global__ __launch_bounds__(512, DDMPC_RR_WAVES) void ddmpc_nominal_rr_kernel(K
 // factorisation in meta_ws[b] (ddmpc_prepare).  MODE 2: a solve on what a MODE-1 launch left there (ddmpc_step: only the past
 // window has changed, controller.py:389-407); same arithmetic, so the results are bit-equal to MODE 0's.
 template <int MODE>
-__global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, int RPs, const double* __restrict__ u_d,
-                                                                const double* __restrict__ y_d,
-                                                                const double* __restrict__ u_past,
-                                                                const double* __restrict__ y_past,
-                                                                double* __restrict__ u_opt, double* __restrict__ cost,
-                                                                int* __restrict__ status, int* __restrict__ iters,
-                                                                double* __restrict__ beta_ws,
-                                                                signed char* __restrict__ act_ws, double* scratch,
-                                                                long long scratch_stride, int* __restrict__ meta_ws) {
+__device__ __forceinline__ void ddmpc_large_solve_body(const KParams& P, int RPs, const double* __restrict__ u_d,
+                                                       const double* __restrict__ y_d,
+                                                       const double* __restrict__ u_past,
+                                                       const double* __restrict__ y_past,
+                                                       double* __restrict__ u_opt, double* __restrict__ cost,
+                                                       int* __restrict__ status, int* __restrict__ iters,
+                                                       double* __restrict__ beta_ws,
+                                                       signed char* __restrict__ act_ws, double* scratch,
+                                                       long long scratch_stride, int* __restrict__ meta_ws, const long long b) {
   extern __shared__ __attribute__((aligned(16))) double lsm_lds[];
-  const long long b = blockIdx.x;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int r = P.r, m = P.m, p = P.p;
   const int n = P.npu / m;
@@ -2373,6 +2372,34 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
     cost[b] = tot;
     status[b] = st;
     if (iters) iters[b] = iter > 0 ? iter : 1;
+  }
+}
+
+// grid = batch (only_status == 0): one workgroup per instance.  only_status != 0: the fall-back launch behind the phase kernels
+// of ddmpc_rr3.hpp -- a SMALL persistent grid whose workgroups walk the batch and solve the instances marked with that status
+// (usually none).  Small on purpose: this kernel spills (668 B of scratch per lane), and a batch-sized grid of it makes the
+// runtime set up ~175 MB of scratch for the dispatch -- measured 3.9 ms per launch even when every workgroup left at once.
+template <int MODE>
+__global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, int RPs, const double* __restrict__ u_d,
+                                                                const double* __restrict__ y_d,
+                                                                const double* __restrict__ u_past,
+                                                                const double* __restrict__ y_past,
+                                                                double* __restrict__ u_opt, double* __restrict__ cost,
+                                                                int* __restrict__ status, int* __restrict__ iters,
+                                                                double* __restrict__ beta_ws,
+                                                                signed char* __restrict__ act_ws, double* scratch,
+                                                                long long scratch_stride, int* __restrict__ meta_ws, int only_status,
+                                                                long long nbatch) {
+  if (only_status == 0) {
+    ddmpc_large_solve_body<MODE>(P, RPs, u_d, y_d, u_past, y_past, u_opt, cost, status, iters, beta_ws, act_ws, scratch, scratch_stride,
+                                 meta_ws, (long long)blockIdx.x);
+    return;
+  }
+  for (long long b = blockIdx.x; b < nbatch; b += gridDim.x) {
+    if (status[b] == only_status)                                  // (workgroup-uniform)
+      ddmpc_large_solve_body<MODE>(P, RPs, u_d, y_d, u_past, y_past, u_opt, cost, status, iters, beta_ws, act_ws, scratch, scratch_stride,
+                                   meta_ws, b);
+    __syncthreads();                                               // LDS is reused by the next instance
   }
 }
 

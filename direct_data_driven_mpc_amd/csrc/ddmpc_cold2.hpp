@@ -881,15 +881,23 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         }
       }
     });
-    // ---- back substitution U x = y (y in tvec), one tile column per round, right to left.  The panel wave first puts
-    //      its M tiles into the (now free) panel buffer; then per round
-    //   (1) every wave: s[k] = sum over its tiles (I > J) of U(J,I)[k][.] x_I  (4 multiply-adds per tile, then one
-    //       16-lane reduction per register) -> part[round parity][wave][k]                      -- one barrier
-    //   (2) EVERY wave, redundantly: x_J = M_J' (y_J - sum of the parts), kept in registers for its own products of the
-    //       later rounds (lane l15 holds x_J[l15]); the panel wave also writes it to `out`
-    //      -- one workgroup barrier per round instead of two.
+    // ---- back substitution U x = y, one tile column per round, right to left, ONE workgroup barrier per round.  The panel wave
+    //      first puts its M tiles into the (now free) panel buffer.
+    //          x_J = M_J' (y_J - sum_{I >= J+2} U(J,I) x_I)  -  (M_J' U(J,J+1)) x_{J+1}
+    //      Only the last term needs the column just finished, and the whole first sub-diagonal of tiles belongs to one wave (the
+    //      chain wave CW; TileMap2 deals whole diagonals).  That wave forms  Ct_J = U(J,J+1)' M_J  on the matrix pipe one round
+    //      ahead -- both operands in their natural layouts: the accumulator tile as A, M_J from LDS as B -- and the product comes
+    //      out with x_J's index on the lanes: the critical term is 4 multiply-adds and ONE reduction over the four lane rows
+    //      (with the tile itself it is a 16-lane reduction per register: 48 instructions), x_{J+1} read back from LDS in the
+    //      register-per-row form.  Per round J:
+    //        chain wave: v = y_J - the far terms (formed during the round before), x_J = M_J' v - Ct_J x_{J+1} -> `out`; Ct_{J-1}
+    //        every wave, beside it: the far terms I >= J + 1 of column J - 1 -> part[parity of the column][wave][k]
+    //      (Until round 5 every wave summed ALL its terms of column J after the barrier of column J + 1, 16-lane reductions
+    //      included, and every wave formed x_J redundantly: 1.6 K cycles per round, 15 K of the benchmark's 126 K.)
     auto back_substitute = [&](double* __restrict__ out, const double* __restrict__ yin, const int rE) __attribute__((always_inline)) {
       double* Mb = PB;                                               // Mb[J][k][i] = M_J[k][i]
+      constexpr int CW = TM::wave(1, 0);
+      auto far_col = [](int w, int J) constexpr { for (int I = J + 2; I < NT; ++I) if (TM::wave(I, J) == w) return true; return false; };
       if constexpr (WAVE == 0) {
         static_for<NT>([&](auto J) __attribute__((always_inline)) {
           if (16 * J < rE) {
@@ -901,39 +909,63 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
       __syncthreads();                                               // M tiles and y are in LDS
       double xl[NT];                                                 // x_I[l15] of the rounds done so far
       static_for<NT>([&](auto I) __attribute__((always_inline)) { xl[I] = 0.0; });
+      d4 Ct = d4{0.0, 0.0, 0.0, 0.0};                                // chain wave: Ct_J, register q of lane (l4, l15) = (M_J' U(J,J+1))[l15][l4 + 4q]
+      d4 xk = d4{0.0, 0.0, 0.0, 0.0};                                //             x_{J+1}[l4 + 4q]
       static_for<NT>([&](auto JREV) __attribute__((always_inline)) {
         constexpr int J = NT - 1 - JREV;
         if (16 * J < rE) {                                            // workgroup-uniform
-          double* pr = part + (J & 1) * (16 * W);
-          if constexpr (TM::has_col(WAVE, J)) {
-            d4 s = d4{0.0, 0.0, 0.0, 0.0};
-            static_for<NT>([&](auto I) __attribute__((always_inline)) {
-              if constexpr (I > J && TM::wave(I, J) == WAVE) {
-                constexpr int S = TM::slot(I, J);
-                static_for<4>([&](auto j) __attribute__((always_inline)) { s[j()] = fma(acc[S][j()], xl[I], s[j()]); });
+          if constexpr (WAVE == CW) {
+            const double* pr = part + (J & 1) * (16 * W);
+            double pi = 0.0;
+            static_for<4>([&](auto j) __attribute__((always_inline)) {
+              const int k = l4 + 4 * j();
+              double v = yin[16 * J + k];
+              if constexpr (J + 2 < NT) {
+                if (16 * (J + 2) < rE) {
+                  static_for<W>([&](auto w) __attribute__((always_inline)) {
+                    if constexpr (far_col(w(), J)) v -= pr[w * 16 + k];
+                  });
+                }
               }
+              pi = fma(Mb[J * 256 + k * 16 + l15], v, pi);
             });
-            static_for<4>([&](auto j) __attribute__((always_inline)) { s[j()] = row16_total(s[j()]); });
-            if (l15 == 0) {
-              static_for<4>([&](auto j) __attribute__((always_inline)) { pr[WAVE * 16 + l4 + 4 * j] = s[j()]; });
+            static_for<4>([&](auto q) __attribute__((always_inline)) { pi = fma(-Ct[q()], xk[q()], pi); });   // (zero for the first column)
+            pi = rows4_total(pi);
+            xl[J] = (16 * J + l15 < rE) ? pi : 0.0;
+            if (l4 == 0) out[16 * J + l15] = xl[J];
+            if constexpr (J >= 1) {
+              constexpr int S = TM::slot(J, J - 1);                   // Ct_{J-1} = U(J-1,J)' M_{J-1}, and x_J in the register-per-row form
+              Ct = d4{0.0, 0.0, 0.0, 0.0};
+              static_for<4>([&](auto j) __attribute__((always_inline)) {
+                Ct = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[S][j()], Mb[(J - 1) * 256 + (4 * j() + l4) * 16 + l15], Ct, 0, 0, 0);
+              });
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // `out` was written by other lanes of this wave
+              static_for<4>([&](auto q) __attribute__((always_inline)) { xk[q()] = out[16 * J + l4 + 4 * q()]; });
             }
           }
-          __syncthreads();
-          double pi = 0.0;
-          static_for<4>([&](auto j) __attribute__((always_inline)) {
-            const int k = l4 + 4 * j();
-            double v = yin[16 * J + k];
-            static_for<W>([&](auto w) __attribute__((always_inline)) {
-              if constexpr (TM::has_col(w, J)) v -= pr[w * 16 + k];
-            });
-            pi = fma(Mb[J * 256 + k * 16 + l15], v, pi);
-          });
-          pi = rows4_total(pi);
-          xl[J] = (16 * J + l15 < rE) ? pi : 0.0;
-          if constexpr (WAVE == 0) { if (l4 == 0) out[16 * J + l15] = xl[J]; }
+          // one column ahead: the far terms I >= J + 1 of column J - 1
+          if constexpr (J >= 1) {
+            if constexpr (far_col(WAVE, J - 1)) {
+              if (16 * (J + 1) < rE) {
+                d4 sv = d4{0.0, 0.0, 0.0, 0.0};
+                static_for<NT>([&](auto I) __attribute__((always_inline)) {
+                  if constexpr (I >= J + 1 && TM::wave(I, J - 1) == WAVE) {
+                    constexpr int S = TM::slot(I, J - 1);
+                    static_for<4>([&](auto j) __attribute__((always_inline)) { sv[j()] = fma(acc[S][j()], xl[I], sv[j()]); });
+                  }
+                });
+                static_for<4>([&](auto j) __attribute__((always_inline)) { sv[j()] = row16_total(sv[j()]); });
+                if (l15 == 0) {
+                  double* pw = part + ((J - 1) & 1) * (16 * W);
+                  static_for<4>([&](auto j) __attribute__((always_inline)) { pw[WAVE * 16 + l4 + 4 * j] = sv[j()]; });
+                }
+              }
+            }
+          }
+          __syncthreads();                                            // x_J (and the far terms of column J - 1) are in LDS
+          if constexpr (WAVE != CW) xl[J] = out[16 * J + l15];
         }
       });
-      __syncthreads();                                               // `out` complete
     };
     // ---- forward substitution U' y = rho in place in tvec (refinement only; the first right-hand side rides along
     //      with the factorisation), left to right:
