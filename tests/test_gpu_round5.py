@@ -224,3 +224,64 @@ def test_convex_rank_update_in_warm_steps_and_closed_loop(gpu):
     assert flagged.any() and (~flagged).any()
     assert np.array_equal(cold[0][flagged], warm[0][flagged]) and np.array_equal(cold[1][flagged], warm[1][flagged])
     assert np.max(np.abs(cold[0] - warm[0])) <= 1e-9 * np.max(np.abs(cold[0]))
+
+
+# ------------------------------------------------------------------ ROBUST beyond 271 rows on the phase kernels (ddmpc_rr3.hpp)
+def _four_tank_long(B, L_, N, slack, c_box=1.0):
+    spec = orc.spec_from_params(slack_var_constraint_type=1 if slack == "convex" else 0, L=L_)
+    spec.c = c_box
+    d = harness.generate_batch(range(B), N=N)
+    n = spec.n
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    return spec, d, up, yp
+
+
+@pytest.mark.parametrize("slack", ["none", "convex"])
+def test_large_robust_phase_kernels_agree_with_the_one_workgroup_kernel(gpu, slack):
+    """controller.py:541-545, 631-677 at 296 rows (four-tank, L = 70: beyond the register-resident kernels).  Round 5 moved the
+    ROBUST scheme at these sizes onto the lock-step pipeline (ddmpc_rr3.hpp: factor of the empty active set, slack-box iterations
+    as Woodbury updates on the trailing block).  Against the one-workgroup kernel of rounds 1-4 (DDMPC_OPT_LARGE_PIPELINE, which
+    re-factors the Schur block of the boxed components per iteration): equal statuses and iteration counts, solutions 1e-9 apart;
+    against the full-space oracle at the standard bars; ddmpc_step on the kept factors bit-equal to ddmpc_solve."""
+    B, L_, N = 6, 70, 700
+    spec, d, up, yp = _four_tank_long(B, L_, N, slack)
+    res = {}
+    for pipe in ("phases", "one_workgroup"):
+        with _spec_engine(spec, N, B) as eng:
+            assert eng.kernel_name() == "ddmpc_large_solve_kernel"
+            eng.set_large_pipeline(pipe)
+            eng.set_data(d["u_d"], d["y_d"])
+            res[pipe] = tuple(x.copy() for x in eng.solve(up, yp))
+            sg = eng.get_solution("sigma")
+            w = tuple(x.copy() for x in eng.step(up, yp))
+            assert all(np.array_equal(a, b_) for a, b_ in zip(w, res[pipe]))
+            if slack == "convex":
+                assert np.max(np.abs(sg[:, spec.n * spec.p:])) <= spec.c * spec.eps_max * (1 + 1e-12)
+    a, b_ = res["phases"], res["one_workgroup"]
+    assert np.all(a[2] == 0) and np.array_equal(a[2], b_[2]) and np.array_equal(a[3], b_[3])
+    assert np.max(np.abs(a[0] - b_[0])) <= 1e-9 * np.max(np.abs(b_[0])) and np.max(np.abs(a[1] - b_[1]) / np.abs(b_[1])) < 1e-9
+    for b in range(B):
+        sol = orc.solve_fullspace(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
+        assert sol.status == "optimal" and int(a[3][b]) == max(sol.iters, 1)
+        assert np.max(np.abs(a[0][b] - sol.optimal_u)) / np.max(np.abs(sol.optimal_u)) < TOL_U
+        assert abs(a[1][b] - sol.cost) / abs(sol.cost) < TOL_COST
+
+
+def test_large_robust_phase_kernels_hand_crowded_active_sets_to_the_fall_back(gpu):
+    """A box tight enough that more than 64 slack components reach their bound (c = 0.01 at 296 rows): the phase solve keeps at most
+    64 columns of W, marks such instances and ddmpc_large_solve_kernel finishes them on a small persistent grid.  Every instance
+    against the full-space oracle (status, iteration count, optimal_u, cost), whichever path served it."""
+    B, L_, N = 6, 70, 700
+    spec, d, up, yp = _four_tank_long(B, L_, N, "convex", c_box=0.01)
+    with _spec_engine(spec, N, B) as eng:
+        eng.set_data(d["u_d"], d["y_d"])
+        u, cost, status, iters = (x.copy() for x in eng.solve(up, yp))
+        sg = eng.get_solution("sigma")
+    nact = np.sum(np.abs(sg[:, spec.n * spec.p:]) >= spec.c * spec.eps_max * (1 - 1e-12), axis=1)
+    assert nact.max() > 64, nact                                      # the fall-back did serve at least one instance
+    for b in range(B):
+        sol = orc.solve_fullspace(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
+        assert L.STATUS_STRINGS[int(status[b])] == sol.status == "optimal"
+        assert int(iters[b]) == sol.iters, (b, int(iters[b]), sol.iters, int(nact[b]))
+        assert np.max(np.abs(u[b] - sol.optimal_u)) / np.max(np.abs(sol.optimal_u)) < TOL_U
+        assert abs(cost[b] - sol.cost) / abs(sol.cost) < TOL_COST
