@@ -167,6 +167,8 @@ struct ddmpc_handle {
   int nA3 = 0;                            // ... first position of the slack-box components in the "boxed last" order
   DevBuf d_gpre;                          // Gram tiles of ddmpc_gram_tiles_kernel (structured Gram, m + p != 4), see gram_pre_launch
   bool gram_pre = false, gpre_valid = false;
+  DevBuf d_rr2tol, d_rr2rank;              // ... per-instance pivot tolerance and [flag, accepted pivots] of the rank decision (+ one counter word)
+  DevBuf d_rr2cand;                        // ... the pivot candidates of G's factorisation as they were met (Rr2Chol::cand)
   DevBuf d_perm, d_rr2d, d_rr2res;                   // phase kernels (ddmpc_rr2.hpp): fixed-first component order [perm | iperm]; per instance
                                            // [max diag of G | max diag of T | live chunks of G | live chunks of T]
   int nF = 0;                              // fixed components (hard constraints), nominal scheme
@@ -623,7 +625,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_gpre, &h->d_perm, &h->d_rr2d, &h->d_rr2res, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz, &h->d_gz, &h->d_gres, &h->d_zvirt, &h->d_rr3w, &h->d_rr3k, &h->d_rr_fb, &h->d_rrmeta_fb};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_gpre, &h->d_perm, &h->d_rr2d, &h->d_rr2res, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz, &h->d_gz, &h->d_gres, &h->d_zvirt, &h->d_rr3w, &h->d_rr3k, &h->d_rr_fb, &h->d_rrmeta_fb, &h->d_rr2cand, &h->d_rr2tol, &h->d_rr2rank};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -1061,8 +1063,11 @@ static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, 
   int* meta = (int*)h->d_rrmeta.p;
   const int* perm = (const int*)h->d_perm.p;
   const int* iperm = perm + rv;
-  hipLaunchKernelGGL(rr2_gram_kernel, dim3((unsigned)((k.Ln + 4 * RR2_SL - 1) / (4 * RR2_SL)), (unsigned)B), dim3(256), 0, h->stream,
-                     k, h->ud, h->yd, iperm, scratch, ndbl, n16, dd);
+  auto gram = [&]() {
+    hipLaunchKernelGGL(rr2_gram_kernel, dim3((unsigned)((k.Ln + 4 * RR2_SL - 1) / (4 * RR2_SL)), (unsigned)B), dim3(256), 0, h->stream,
+                       k, h->ud, h->yd, iperm, scratch, ndbl, n16, dd);
+  };
+  gram();
   auto cholesky = [&](const Rr2Chol& F, int nmax16) {
     const int nt = nmax16 >> 4;
     for (int c0 = 0; c0 < nmax16; c0 += RR2_NB) {
@@ -1079,7 +1084,35 @@ static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, 
   FG.dmax = dd + 0; FG.d_stride = 4; FG.tol_rel = rank_tol; FG.skip = meta; FG.s_stride = mstride; FG.nflag = r;
   FG.live = dd + 2; FG.l_stride = 4; FG.m64 = (double*)h->d_rr2mt.p; FG.m64_stride = m64G + m64T;
   FG.res = (double*)h->d_rr2res.p + 2; FG.res_stride = rstride; FG.dead = (unsigned long long*)h->d_rr2res.p; FG.dead_stride = rstride;
+  if ((rc = h->d_rr2cand.ensure(B * (size_t)n16 * sizeof(double)))) return rc;
+  FG.cand = (double*)h->d_rr2cand.p; FG.cand_stride = n16;
   cholesky(FG, n16);
+  {
+    // The rank decision, judged from the pivot candidates (rr2_rank_margin_kernel): an instance that accepted more pivots than
+    // rank H can be gets a tolerance inside the gap behind the largest m (L + n) + n candidates and the batch is factored once
+    // more with per-instance tolerances (every other instance keeps its tolerance: bit-identical factors); a decision without a
+    // clear margin is flagged and the solve reports "optimal_inaccurate".  One 4-byte read-back per data set decides on the
+    // second pass -- none on the benchmark configurations.
+    if ((rc = h->d_rr2tol.ensure(B * sizeof(double))) || (rc = h->d_rr2rank.ensure((2 * B + 1) * sizeof(int)))) return rc;
+    const int bound = k.m * k.Ln + h->prm.n;
+    const double safe = 20.0;
+    int* rec = (int*)h->d_rr2rank.p;
+    HIP_TRY(hipMemsetAsync(rec + 2 * B, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(rr2_rank_margin_kernel, dim3((unsigned)B), dim3(256), 0, h->stream, (const double*)h->d_rr2cand.p, (long long)n16, r, bound,
+                       rank_tol, (const double*)nullptr, safe, 1, (double*)h->d_rr2tol.p, rec, rec + 2 * B);
+    int nredo = 0;
+    HIP_TRY(hipMemcpyAsync(&nredo, rec + 2 * B, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (nredo > 0) {
+      HIP_TRY(hipMemsetAsync(h->d_rr2d.p, 0, B * 4 * sizeof(unsigned long long), h->stream));
+      HIP_TRY(hipMemset2DAsync(h->d_rr2res.p, (size_t)rstride * sizeof(double), 0, 2 * sizeof(unsigned long long), B, h->stream));
+      gram();
+      FG.tol_inst = (const double*)h->d_rr2tol.p;
+      cholesky(FG, n16);
+      hipLaunchKernelGGL(rr2_rank_margin_kernel, dim3((unsigned)B), dim3(256), 0, h->stream, (const double*)h->d_rr2cand.p, (long long)n16, r, bound,
+                         rank_tol, (const double*)h->d_rr2tol.p, safe, 0, (double*)h->d_rr2tol.p, rec, rec + 2 * B);
+    }
+  }
   hipLaunchKernelGGL(rr2_meta_kernel, dim3((unsigned)B), dim3(256), 0, h->stream, meta, mstride, rv, r, nF, nR);
   if (nR > 0) {
     const int ldw = ((nR16 + 31) / 32) * 32 + 16;                         // LDS row of the C'WC kernel: 16 mod 32 doubles
@@ -1121,6 +1154,7 @@ static int rr2_solve_desc(ddmpc_handle* h, double* scratch, long long ndbl, Rr2S
   S.dd = (const unsigned long long*)h->d_rr2d.p;
   S.perm = (const int*)h->d_perm.p;
   S.wz = (const double*)h->d_wz.p;
+  S.rankrec = (const int*)h->d_rr2rank.p;
   S.V = (double*)h->d_rr2v.p; S.vstride = (long long)V_NV * VL; S.VL = VL;
   S.ZP = (double*)h->d_rr2zp.p;
   S.sc = (double*)h->d_rr2sc.p;
@@ -2045,6 +2079,16 @@ int ddmpc_debug_workspace(ddmpc_handle* h, int64_t b, double* ws_out, int64_t ws
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (meta_out && meta_count > 0)
       HIP_TRY(hipMemcpy(meta_out, (const int*)h->d_rr3k.p + b * kstride, (size_t)(meta_count < kstride ? meta_count : kstride) * sizeof(int), hipMemcpyDeviceToHost));
+    return DDMPC_OK;
+  }
+  if (h->large_nominal && ws_count < 0 && h->d_rr2cand.p) {
+    // diagnostics: the pivot candidates of G's factorisation (phase kernels), n16 doubles, relative to nothing (dmax is meta's business)
+    const int n16 = (h->kp.r + 15) & ~15;
+    if (ws_avail) *ws_avail = n16;
+    if (b < 0 || b >= h->batch) return fail(DDMPC_ERR_INVALID, "instance out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (ws_out) HIP_TRY(hipMemcpy(ws_out, (const double*)h->d_rr2cand.p + b * n16, (size_t)n16 * sizeof(double), hipMemcpyDeviceToHost));
     return DDMPC_OK;
   }
   if (!h->large_nominal || !h->d_rr.p || !h->d_rrmeta.p) return fail(DDMPC_ERR_NOT_READY, "no global workspace to read");

@@ -73,6 +73,13 @@ struct Rr2Chol {
   long long res_stride;
   unsigned long long* dead;
   long long dead_stride;
+  // The pivot candidates as they were met (nullptr: not recorded): cand[i] = the diagonal entry column i was decided on -- the
+  // pivot where it was accepted, the residue where it was skipped (0 for padding and retired rows).  The rank decision of an
+  // exact-data problem is judged from this sequence afterwards (rr2_rank_margin_kernel).
+  double* cand;
+  long long cand_stride;
+  const double* tol_inst;           // per-instance pivot tolerance (relative), nullptr: tol_rel for everybody (second pass of the
+                                    // rank decision, rr2_rank_margin_kernel)
 };
 
 __device__ __forceinline__ double rr2_bits_to_double(unsigned long long v) { return __longlong_as_double((long long)v); }
@@ -426,7 +433,7 @@ __device__ __forceinline__ void rr2_diag_update(const double* A, double (*Dt)[RR
 // (Until round 4's end Mt came from a forward substitution by 16 lanes afterwards: 120 dependent LDS reads + FMAs per tile,
 // about as long as the factorisation itself.)
 // Leaves L in the lower triangle of Dg (zeros above), Ms[k][m] = Mt[m][k] (rows of skipped pivots zero), Dinv, the pivot flags.
-__device__ __forceinline__ void rr2_tile_factor(double* Dg, double* Ms, double* Dinv, double tol, int* skipout) {
+__device__ __forceinline__ void rr2_tile_factor(double* Dg, double* Ms, double* Dinv, double tol, int* skipout, double* candout) {
   const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
   d4 acc, rr;
 #pragma unroll
@@ -448,7 +455,7 @@ __device__ __forceinline__ void rr2_tile_factor(double* Dg, double* Ms, double* 
     if (mine) { Dg[l15 * RR2_TLD + c] = u; Ms[l15 * RR2_TLD + c] = y; }     // L(i, c), zeros above the diagonal; Ms[k = j][m = c]
     acc = rr2_mfma(-u, u, acc);
     rr = rr2_mfma(-u, y, rr);
-    if (lane == 0) { skipout[c] = sk ? 1 : 0; Dinv[c] = inv; }
+    if (lane == 0) { skipout[c] = sk ? 1 : 0; Dinv[c] = inv; candout[c] = dk; }
   });
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                     // in-wave hand-off through LDS
 }
@@ -461,7 +468,7 @@ __device__ __forceinline__ void rr2_tile_factor(double* Dg, double* Ms, double* 
 // and for the substitutions of the solve), the pivot flags and the live-chunk bits.  grid = (1, batch), 256 threads: ONE workgroup per instance (the block is factored in place).
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void rr2_panel_body(const Rr2Chol& F, long long b, int c0, int n16, double (*Dt)[RR2_TSZ],
-                                               double (*Ms)[RR2_TSZ], double (*Mi)[RR2_TSZ], double* Dinv, int* skipl) {
+                                               double (*Ms)[RR2_TSZ], double (*Mi)[RR2_TSZ], double* Dinv, int* skipl, double* candl) {
   if (c0 >= n16) return;
   double* A = F.ws + b * F.stride + F.off;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -469,11 +476,12 @@ __device__ __forceinline__ void rr2_panel_body(const Rr2Chol& F, long long b, in
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6;
   const int tp = c0 >> 4, nt = n16 >> 4;
   const int n4 = (nt - tp) < 4 ? (nt - tp) : 4;                             // tiles across the panel
-  const double tol = F.tol_rel * rr2_bits_to_double(F.dmax[b * F.d_stride]);
+  const double tol = (F.tol_inst ? F.tol_inst[b] : F.tol_rel) * rr2_bits_to_double(F.dmax[b * F.d_stride]);
   // retired row tiles of the block (Rr2Chol::res): their rows hold zeros from the column they were retired at and count as zero
   const unsigned dmask = F.res ? (unsigned)((F.dead[b * F.dead_stride + ((c0 / RR2_NB) & 1)] >> tp) & ((1ull << n4) - 1ull)) : 0u;
   if (dmask == (1u << n4) - 1u) {                                           // (workgroup-uniform) nothing left to factor
     if (tid < 16 * n4 && c0 + tid < F.nflag) F.skip[b * F.s_stride + c0 + tid] = 1;
+    if (F.cand && tid < 16 * n4 && c0 + tid < F.nflag) F.cand[b * F.cand_stride + c0 + tid] = 0.0;
     double* m64 = F.m64 + b * F.m64_stride + (size_t)(c0 / RR2_NB) * (RR2_NB * RR2_NB);
     for (int e = tid; e < RR2_NB * RR2_NB; e += nthr) m64[e] = 0.0;
     return;
@@ -506,7 +514,7 @@ __device__ __forceinline__ void rr2_panel_body(const Rr2Chol& F, long long b, in
   }
   RR2_STAMP();     // 1: block in LDS
   for (int t = 0; t < n4; ++t) {
-    if (wave == 0) rr2_tile_factor(Dt[t * (t + 1) / 2 + t], Ms[t], Dinv + 16 * t, tol, skipl + 16 * t);
+    if (wave == 0) rr2_tile_factor(Dt[t * (t + 1) / 2 + t], Ms[t], Dinv + 16 * t, tol, skipl + 16 * t, candl + 16 * t);
     __syncthreads();
     if (t == 0) RR2_STAMP();   // 2: first tile factored
     // tiles below the diagonal tile: X(s,t) = P(s,t) Mt'   (X'[m][i] = sum_k Mt[m][k] P'[k][i])
@@ -588,6 +596,7 @@ __device__ __forceinline__ void rr2_panel_body(const Rr2Chol& F, long long b, in
     m64[e] = (t <= s && s < n4) ? Mi[s * (s + 1) / 2 + t][(i & 15) * RR2_TLD + (j & 15)] : 0.0;
   }
   if (tid < 16 * n4 && c0 + tid < F.nflag) F.skip[b * F.s_stride + c0 + tid] = skipl[tid];
+  if (F.cand && tid < 16 * n4 && c0 + tid < F.nflag) F.cand[b * F.cand_stride + c0 + tid] = ((dmask >> (tid >> 4)) & 1u) ? 0.0 : candl[tid];
   if (tid == 0) {
     unsigned long long bits = 0ull;
     for (int t = 0; t < n4; ++t) {
@@ -609,10 +618,11 @@ __global__ __launch_bounds__(256) void rr2_chol_panel_kernel(Rr2Chol F, int c0) 
   __shared__ __attribute__((aligned(16))) double Ms[4][RR2_TSZ];            // Mt of the diagonal tiles, k-major
   __shared__ __attribute__((aligned(16))) double Mi[10][RR2_TSZ];           // Minv of the block, tile (s, t) row-major
   __shared__ double Dinv[64];
+  __shared__ double candl[64];
   __shared__ int skipl[64];
   const long long b = blockIdx.y;
   const int n16 = F.n_inst ? ((F.n_inst[b * F.n_stride] + 15) & ~15) : F.n16;
-  rr2_panel_body(F, b, c0, n16, Dt, Ms, Mi, Dinv, skipl);
+  rr2_panel_body(F, b, c0, n16, Dt, Ms, Mi, Dinv, skipl, candl);
 }
 
 // The whole factorisation of a SMALL matrix (the reduced normal matrix T: a few panels) in one launch: one workgroup per
@@ -625,12 +635,13 @@ __global__ __launch_bounds__(256, 2) void rr2_chol_small_kernel(Rr2Chol F) {
   __shared__ __attribute__((aligned(16))) double DtMs[14][RR2_TSZ];         // panel step: Dt (10 tiles) | Ms (4 tiles); update: the staging ring
   __shared__ __attribute__((aligned(16))) double Mi[10][RR2_TSZ];
   __shared__ double Dinv[64];
+  __shared__ double candl[64];
   __shared__ int skipl[64];
   static_assert(sizeof(double) * 14 * RR2_TSZ >= sizeof(double) * 3 * 64 * RR2_PLD, "the staging ring fits into the panel step's tiles");
   const long long b = blockIdx.x;
   const int n16 = F.n_inst ? ((F.n_inst[b * F.n_stride] + 15) & ~15) : F.n16;
   for (int c0 = 0; c0 < n16; c0 += RR2_NB) {
-    rr2_panel_body(F, b, c0, n16, DtMs, DtMs + 10, Mi, Dinv, skipl);
+    rr2_panel_body(F, b, c0, n16, DtMs, DtMs + 10, Mi, Dinv, skipl, candl);
     __syncthreads();                                                        // the block's factor, Minv (LDS) and the live bits are in place
     const int nbelow = (n16 >> 4) - (c0 >> 4) - 4;
     for (int g = 0; g * 4 * RT < nbelow; ++g) {
@@ -748,6 +759,69 @@ __global__ __launch_bounds__(1024) void rr2_cwc_kernel(KParams P, int RPs, const
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) tmx = fmax(tmx, __shfl_xor(tmx, off, 64));
   if (lane == 0 && tmx > 0.0) atomicMax(tmaxbits + 4 * b, (unsigned long long)__double_as_longlong(tmx));   // (four words per instance)
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The rank decision of an exact-data NOMINAL problem, judged from the pivot candidates AFTER the factorisation (round 5).
+// The reference decides ranks with a data-scaled tolerance on singular values (hankel_matrix.py:82); here a pivot below
+// tol_rel x (largest diagonal entry) counts as zero, and that fixed tolerance has a window that moves with the plant: dependent
+// rows leave rounding residues of ~1e-10 at configs[4] and up to 1.4e-8 on a 9-channel plant of the tests, genuine pivots start
+// at 1.6e-7 resp. 1.1e-5 (tools/pivot_gap_study.py).  Per instance, from the sorted candidates (relative to the largest):
+//   * more accepted pivots than rank H can be -- m (L + n) + n for exact data of an LTI system of order <= n (Willems' lemma; the
+//     reference's own N_min rests on it, controller.py:275) -- means noise was taken for a pivot: a new tolerance is set in the
+//     middle (geometric mean) of the gap behind the largest m (L + n) + n candidates and the instance is factored again (flag 2);
+//   * a decision without a clear margin -- smallest accepted candidate / largest skipped one below `safe` -- is reported, not
+//     hidden: flag bit 1, which the solve turns into the status "optimal_inaccurate".
+// rec per instance: [flag, -] ints; tol_out[b]: the tolerance of the next pass.  counter: number of instances with flag 2.
+// grid = batch, 256 threads, r <= 1024.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rr2_rank_margin_kernel(const double* __restrict__ cand, long long cand_stride, int r, int bound,
+                                                              double tol_rel, const double* __restrict__ tol_in, double safe, int allow_redo,
+                                                              double* __restrict__ tol_out, int* __restrict__ rec, int* __restrict__ counter) {
+  __shared__ double v[1024];
+  const long long b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const double* c = cand + b * cand_stride;
+  double mx = 0.0;
+  for (int i = tid; i < 1024; i += 256) { const double x = (i < r) ? c[i] : 0.0; v[i] = x > 0.0 ? x : 0.0; mx = fmax(mx, v[i]); }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+  __shared__ double red[4];
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  const double inv = mx > 0.0 ? 1.0 / mx : 0.0;
+  for (int i = tid; i < 1024; i += 256) v[i] *= inv;
+  __syncthreads();
+  for (int k = 2; k <= 1024; k <<= 1)                                       // bitonic sort, descending
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < 1024; i += 256) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool up = (i & k) == 0;
+          const double a = v[i], bq = v[l];
+          if (up ? (a < bq) : (a > bq)) { v[i] = bq; v[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  if (tid == 0) {
+    const double tol = tol_in ? tol_in[b] : tol_rel;
+    int K = 0;
+    while (K < r && v[K] > tol) ++K;                                        // (<= 1024 steps, once per instance and data set)
+    int flag = 0;
+    double tnew = tol, hi, lo;
+    if (K > bound && bound >= 1) {
+      hi = v[bound - 1]; lo = v[bound];
+      if (allow_redo) { tnew = sqrt(hi * fmax(lo, 1e-300)); flag = 2; } else flag = 1;
+    } else {
+      hi = K > 0 ? v[K - 1] : 1.0; lo = K < r ? v[K] : 0.0;
+    }
+    if (lo > 0.0 && hi < safe * lo) flag |= 1;
+    tol_out[b] = tnew;
+    rec[2 * b] = flag; rec[2 * b + 1] = K;
+    if (flag & 2) atomicAdd(counter, 1);
+  }
 }
 
 }  // namespace ddmpc

@@ -39,6 +39,7 @@ struct Rr2Solve {
   double* ZP;                                                 // Hankel partial sums [batch][RR2_NG][VL], component order
   double* sc; int* si; unsigned long long* resid;             // scalars (4 doubles, 2 ints per instance), max residual of the dependent rows (bits)
   int r, nF, nR;
+  const int* rankrec;                                         // per instance [flag, accepted pivots] of rr2_rank_margin_kernel (bit 1: no clear margin)
   int fdiv;                                                   // virtual batch of the gain build: instance b solves on the factors of b / fdiv
                                                               // with the past window e_{b % fdiv - 1} (0: the zero window); 1: a plain solve
   int unit, ubase;                                            // unit != 0: past window e_{ubase + b % fdiv - 1}
@@ -705,7 +706,10 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s15_kernel(Rr2Solve S, KParams P, 
     if (cost) cost[b] = tot;
     // (an instance that asked for another refinement pass is solved again, with all its passes, by ddmpc_nominal_rr_kernel<2>,
     //  launched behind this kernel for the instances marked 4: the rare case does not cost the batch a launch sequence per pass)
-    if (status) status[b] = (S.si[2 * b] != 0 || !(fabs(tot) < 1e300)) ? 4 : (feasible ? 0 : 2);   // 2 = "infeasible"
+    int stv = (S.si[2 * b] != 0 || !(fabs(tot) < 1e300)) ? 4 : (feasible ? 0 : 2);   // 2 = "infeasible"
+    // a rank decision without a clear margin (rr2_rank_margin_kernel) is reported: "optimal_inaccurate", never a silent "optimal"
+    if (stv == 0 && S.rankrec != nullptr && (S.rankrec[2 * (b / S.fdiv)] & 1)) stv = 1;
+    if (status) status[b] = stv;
     if (iters) iters[b] = 1;
     if (rescued) rescued[b] = 1;
   }

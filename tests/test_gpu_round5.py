@@ -285,3 +285,36 @@ def test_large_robust_phase_kernels_hand_crowded_active_sets_to_the_fall_back(gp
         assert int(iters[b]) == sol.iters, (b, int(iters[b]), sol.iters, int(nact[b]))
         assert np.max(np.abs(u[b] - sol.optimal_u)) / np.max(np.abs(sol.optimal_u)) < TOL_U
         assert abs(cost[b] - sol.cost) / abs(sol.cost) < TOL_COST
+
+
+# ------------------------------------------------------------------ the rank decision of exact-data NOMINAL problems
+def test_rank_decision_on_the_plant_whose_noise_pivot_sits_above_the_fixed_tolerance(gpu):
+    """hankel_matrix.py:82 decides ranks with a data-scaled tolerance; the phase kernels used a fixed 1e-8 x (largest diagonal)
+    pivot rule.  The 9-channel plant of `_exact_plant_case(154, 5, 4, ...)` leaves a rounding residue of 1.4e-8 on ONE dependent
+    row of ONE of its first six instances (tools/pivot_gap_study.py: instance 3 accepted 231 pivots where rank H = m (L + n) + n =
+    230, the next genuine pivot is 1.1e-5): in round 4 that instance came back "optimal" with a wrong input sequence and the
+    test was moved to other seeds.  Round 5: rr2_rank_margin_kernel judges the decision from the pivot candidates afterwards --
+    more pivots than rank H can have => a tolerance in the middle of the gap and one more factorisation; a decision without a
+    clear margin => "optimal_inaccurate", never a silent "optimal".  Both pipelines against the model-based solution at the
+    standard bars, all six instances."""
+    from oracle.nominal_exact import solve_nominal_model_based_batch
+    from test_gpu_round4 import _exact_plant_case
+    m, p, n, Lh, N, B = 5, 4, 5, 40, 1200, 6
+    spec, plant, d, up, yp = _exact_plant_case(154, m, p, n, Lh, N, B)
+    u_ref, c_ref, feas = solve_nominal_model_based_batch(spec, plant, up, yp)
+    assert np.max(feas) < 1e-10
+    res = {}
+    for mode in ("phases", "one_workgroup"):
+        with _spec_engine(spec, N, B) as eng:
+            eng.set_large_pipeline(mode)
+            eng.set_data(d["u_d"], d["y_d"])
+            res[mode] = tuple(x.copy() for x in eng.solve(up, yp))
+            if mode == "phases":
+                w = tuple(x.copy() for x in eng.step(up, yp))          # the kept factors are the re-factored ones
+                assert np.array_equal(w[0], res[mode][0]) and np.array_equal(w[2], res[mode][2])
+    for mode, (u, c, st, it) in res.items():
+        assert np.all((st == 0) | (st == 1)), (mode, st)               # optimal, or optimal_inaccurate where the margin is thin
+        eu = np.max(np.abs(u - u_ref), axis=1) / np.max(np.abs(u_ref), axis=1)
+        ec = np.abs(c - c_ref) / np.abs(c_ref)
+        assert eu.max() < TOL_U and ec.max() < TOL_COST, (mode, eu, ec)
+    print("statuses on the phase kernels:", res["phases"][2], "one workgroup:", res["one_workgroup"][2])
