@@ -167,6 +167,8 @@ struct ddmpc_handle {
   int nA3 = 0;                            // ... first position of the slack-box components in the "boxed last" order
   DevBuf d_gpre;                          // Gram tiles of ddmpc_gram_tiles_kernel (structured Gram, m + p != 4), see gram_pre_launch
   bool gram_pre = false, gpre_valid = false;
+  bool long_data = false;                  // the trajectory does not fit the cold kernel's LDS: streaming Gram + gpre, no refinement (KParams::stage_xs = 0)
+  DevBuf d_gstream, d_gsdd, d_gsperm;      // ... packed G of the streaming launch, its 4 words per instance, the identity order
   DevBuf d_rr2tol, d_rr2rank;              // ... per-instance pivot tolerance and [flag, accepted pivots] of the rank decision (+ one counter word)
   DevBuf d_rr2cand;                        // ... the pivot candidates of G's factorisation as they were met (Rr2Chol::cand)
   DevBuf d_perm, d_rr2d, d_rr2res;                   // phase kernels (ddmpc_rr2.hpp): fixed-first component order [perm | iperm]; per instance
@@ -573,13 +575,29 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   k.xs_len = ((p.N - k.Ln + 4) * k.nch + 16 * h->kc.NT + 8 + 64 + 1) & ~1;   // + lag groups past Ln in the 4x4x4 base loop
   if (k.xs_len < (p.N + 2) * k.nch) k.xs_len = ((p.N + 2) * k.nch + 1) & ~1;
   h->lds_bytes = lds_doubles_for(h->kc, k.xs_len) * sizeof(double);
+  k.stage_xs = 1;
   if (h->lds_bytes > 160 * 1024) {
-    delete h;
-    return fail(DDMPC_ERR_UNSUPPORTED, "trajectory too long for LDS staging: needs %zu bytes of LDS", h->lds_bytes);
+    // hankel_matrix.py:39-51 takes any N >= L.  A trajectory beyond the LDS is never staged: G = H H' comes from the streaming
+    // Gram kernel of the phase pipeline (trajectory in chunks), re-laid into the kernel's tiles (rr2_pack_tiles_kernel), and the
+    // cold kernel runs in its `gpre` mode with no trajectory region at all.  What needs the trajectory on chip -- the
+    // exact-Hankel residual check of AUTO refinement and the refining variant -- is not available at such N: an instance the
+    // a-priori bound cannot dismiss is reported "optimal_inaccurate" (launch_cold), DDMPC_REFINE_ALWAYS is refused.
+    const int tch = ((RR2_XCAP / k.nch) - k.Ln - 3) & ~3;
+    if (k.r > 1024 || tch < 4 || p.weight_kind == DDMPC_WEIGHT_DENSE) {
+      const size_t need = h->lds_bytes;
+      delete h;
+      return fail(DDMPC_ERR_UNSUPPORTED, "trajectory too long for LDS staging (%zu bytes) and no streaming Gram for this shape", need);
+    }
+    h->long_data = true;
+    k.stage_xs = 0;
+    k.xs_len = 2;
+    k.gram_dense = 0;
+    h->lds_bytes = lds_doubles_for(h->kc, k.xs_len) * sizeof(double);
   }
   // (trajectories whose staging does not fit the LDS of ddmpc_gram_tiles_kernel keep the dense product)
-  h->gram_pre = p.gram_mode != DDMPC_GRAM_DENSE && k.nch != 4 && k.nch != 2 &&
-                gram_tiles_lds_doubles(k.xs_len, k.r, k.nch, h->kc.NT) * sizeof(double) <= 150 * 1024;
+  h->gram_pre = h->long_data ||
+                (p.gram_mode != DDMPC_GRAM_DENSE && k.nch != 4 && k.nch != 2 &&
+                 gram_tiles_lds_doubles(k.xs_len, k.r, k.nch, h->kc.NT) * sizeof(double) <= 150 * 1024);
   if (p.gram_mode == DDMPC_GRAM_STRUCTURED && k.nch != 4 && k.nch != 2 && !h->gram_pre) {
     // AUTO falls back to the dense product silently; a caller who asked for STRUCTURED by name is told
     const int nch_ = k.nch;
@@ -596,6 +614,7 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
       // unconditionally
     const int cpad = (k.c + 1) & ~1, FB = (k.Ln + 3) / 4;
     k.res_fits = (h->kc.scratch >= cpad + (k.nch == 4 ? 16 * FB : 0)) ? 1 : 0;
+    if (h->long_data) k.res_fits = 0;         // (no trajectory on chip: an instance the a-priori bound cannot dismiss is flagged, see launch_cold)
   }
 
   if (hipSetDevice(device) != hipSuccess) { delete h; return fail(DDMPC_ERR_HIP, "hipSetDevice(%d) failed", device); }
@@ -625,7 +644,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_gpre, &h->d_perm, &h->d_rr2d, &h->d_rr2res, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz, &h->d_gz, &h->d_gres, &h->d_zvirt, &h->d_rr3w, &h->d_rr3k, &h->d_rr_fb, &h->d_rrmeta_fb, &h->d_rr2cand, &h->d_rr2tol, &h->d_rr2rank};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_gpre, &h->d_perm, &h->d_rr2d, &h->d_rr2res, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz, &h->d_gz, &h->d_gres, &h->d_zvirt, &h->d_rr3w, &h->d_rr3k, &h->d_rr_fb, &h->d_rrmeta_fb, &h->d_rr2cand, &h->d_rr2tol, &h->d_rr2rank, &h->d_gstream, &h->d_gsdd, &h->d_gsperm};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -723,6 +742,28 @@ static int gram_pre_launch(ddmpc_handle* h, KParams& kq, const double* ud, const
   kq.gpre = (const double*)h->d_gpre.p + (long long)b0 * stride;
   kq.gpre_stride = stride;
   if (cacheable && h->gpre_valid) return DDMPC_OK;
+  if (h->long_data) {
+    // streaming Gram (trajectory in chunks through LDS: rr2_gram_kernel, identity component order), then the tiles
+    const int r = h->kp.r, n16 = (r + 15) & ~15, rv = (r + 1) & ~1;
+    const long long ndbl = (long long)pk_size((size_t)n16);
+    if ((rc = h->d_gstream.ensure((size_t)h->batch * (size_t)ndbl * sizeof(double))) || (rc = h->d_gsdd.ensure((size_t)h->batch * 4 * sizeof(unsigned long long))))
+      return rc;
+    if (!h->d_gsperm.p) {
+      std::vector<int> idp(2 * (size_t)rv);
+      for (int i = 0; i < rv; ++i) idp[i] = idp[rv + i] = i;
+      if ((rc = h->d_gsperm.ensure(idp.size() * sizeof(int)))) return rc;
+      HIP_TRY(hipMemcpy(h->d_gsperm.p, idp.data(), idp.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemsetAsync(h->d_gsdd.p, 0, (size_t)h->batch * 4 * sizeof(unsigned long long), h->stream));
+    double* gs = (double*)h->d_gstream.p + (long long)b0 * ndbl;
+    hipLaunchKernelGGL(rr2_gram_kernel, dim3((unsigned)((h->kp.Ln + 4 * RR2_SL - 1) / (4 * RR2_SL)), (unsigned)nb), dim3(256), 0, h->stream,
+                       h->kp, ud, yd, (const int*)h->d_gsperm.p + rv, gs, ndbl, n16, (unsigned long long*)h->d_gsdd.p + 4 * b0);
+    hipLaunchKernelGGL(rr2_pack_tiles_kernel, dim3((unsigned)(NT * (NT + 1) / 2), (unsigned)nb), dim3(64), 0, h->stream, (const double*)gs, ndbl, r, NT,
+                       (double*)h->d_gpre.p + (long long)b0 * stride, stride);
+    HIP_TRY(hipGetLastError());
+    if (cacheable) h->gpre_valid = true;
+    return DDMPC_OK;
+  }
   const size_t lds = gram_tiles_lds_doubles(h->kp.xs_len, h->kp.r, h->kp.nch, NT) * sizeof(double);
   if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_gram_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(ddmpc_gram_tiles_kernel, dim3((unsigned)nb), dim3(256), lds, h->stream, h->kp, NT, ud, yd,
@@ -843,6 +884,35 @@ static int launch_rr3_solve(ddmpc_handle* h, const KParams& kq, const double* up
   return DDMPC_OK;
 }
 
+// Trajectories beyond the LDS (h->long_data), AUTO refinement: the plain kernel flagged what its a-priori bound could not dismiss;
+// H (H' beta) of the whole batch by the streaming Hankel kernel of the phase pipeline, then the residual decides per flagged
+// instance whether it is reported "optimal_inaccurate" (there is no refining variant without the trajectory on chip).
+static int long_data_residual_check(ddmpc_handle* h, const KParams& kq, const int* flags, const double* ud, const double* yd, const double* up,
+                                    const double* yp, const double* beta, const signed char* act, int* status, size_t nb) {
+  const int r = kq.r, VL = (r + 63) & ~63;
+  int rc;
+  if ((rc = h->d_rr2zp.ensure((size_t)h->batch * (size_t)RR2_NG * VL * sizeof(double)))) return rc;
+  Rr2Solve H{};
+  H.V = const_cast<double*>(beta); H.vstride = kq.rE; H.VL = VL; H.ZP = (double*)h->d_rr2zp.p; H.fdiv = 1; H.r = r;
+  int hk_ng = 0;
+  size_t hk_lds = 0;
+  if (kq.nch <= 16) {
+    for (int ng = RR2_NG; ng >= 1 && hk_ng == 0; --ng) {
+      const Rr2HankelGeom G = rr2_hankel_geom(kq.c, kq.Ln, kq.nch, ng);
+      const size_t bytes = rr2_hankel_mfma_lds(G, kq.Ln) * sizeof(double);
+      if ((G.cg >= 64 || ng == 1) && bytes <= 80 * 1024 && G.ntA <= 8 && G.ntZ <= 8) { hk_ng = ng; hk_lds = bytes; }
+    }
+    if (hk_ng && hk_lds > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute((const void*)rr2_hankel_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hk_lds));
+  }
+  if (hk_ng) hipLaunchKernelGGL(rr2_hankel_mfma_kernel, dim3((unsigned)RR2_NG, (unsigned)nb), dim3(512), hk_lds, h->stream, H, kq, ud, yd, 0, 0, hk_ng);
+  else hipLaunchKernelGGL(rr2_hankel_kernel, dim3(RR2_NG, (unsigned)nb), dim3(512), 0, h->stream, H, kq, ud, yd, 0, 0);
+  hipLaunchKernelGGL(ddmpc_flag_inaccurate_kernel, dim3((unsigned)nb), dim3(256), 0, h->stream, kq, 16 * h->kc.NT, kq.epoch, flags, up, yp, beta, act,
+                     (const double*)h->d_rr2zp.p, (int)RR2_NG, VL, status);
+  HIP_TRY(hipGetLastError());
+  return DDMPC_OK;
+}
+
 static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
                        int32_t* status, int32_t* iters, double* lfac = nullptr, const int* only = nullptr,
                        const KParams* kp_override = nullptr, bool want_ws = true, double* lfacT = nullptr, int large_mode = 0) {
@@ -886,6 +956,7 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
     HIP_TRY(hipGetLastError());
     return DDMPC_OK;
   }
+  if (h->long_data) { want_ws = true; h->ws_stale = false; }       // (the streamed residual check reads beta and the active set)
   if (want_ws) {
     if ((rc = h->d_beta.ensure((size_t)h->batch * h->kp.rE * sizeof(double)))) return rc;
     if ((rc = h->d_act.ensure((size_t)h->batch * h->kp.rE))) return rc;
@@ -905,6 +976,8 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
   // controllers with the slack box: the plain variant that keeps the first factor across active-set iterations (rank-k update);
   // DDMPC_OPT_CONVEX_UPDATE = 0 selects the variant that factors again in every iteration (the refining variant always does)
   const cold_kernel2_t plain = (kq.convex && h->convex_update) ? h->kc.fn2c : h->kc.fn2;
+  if (mode == DDMPC_REFINE_ALWAYS && h->long_data)
+    return fail(DDMPC_ERR_UNSUPPORTED, "DDMPC_REFINE_ALWAYS needs the trajectory in LDS: not available for N = %d at this problem size", h->prm.N);
   if (mode == DDMPC_REFINE_ALWAYS) {
     hipLaunchKernelGGL(h->kc.fn2r, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                        (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, only, 0LL, (int*)nullptr);
@@ -919,10 +992,16 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
     hipLaunchKernelGGL(plain, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                        (int*)iters, bws, aws, stp, lfac, lfacT, (int*)h->d_rflag.p, only, 0LL, rcount);
     HIP_TRY(hipGetLastError());
+    if (h->long_data) {
+      // no refining variant without the trajectory on chip: what neither the a-priori bound nor the streamed residual clears is
+      // reported "optimal_inaccurate", not hidden
+      if ((rc = long_data_residual_check(h, kq, (const int*)h->d_rflag.p, h->ud, h->yd, up, yp, bws, aws, (int*)status, (size_t)h->batch))) return rc;
+    } else {
     kq.refine = DDMPC_REFINE_ALWAYS;
     const unsigned pg = (unsigned)(h->batch < 768 ? h->batch : 768);       // persistent grid, 3 workgroups per CU
     hipLaunchKernelGGL(h->kc.fn2r, dim3(pg), block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                        (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, (const int*)h->d_rflag.p, (long long)h->batch, rcount);
+    }
     h->flag_epoch = kq.epoch;                   // the flags now carry this stamp
   } else {
     // factor export for ddmpc_prepare under AUTO: the plain kernel still records which instances AUTO would refine
@@ -1408,12 +1487,21 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
   // that need it and one filtered launch of the refining variant follows the last chunk
   const bool refinable = h->kp.lam != 0.0;
   const bool always = refinable && h->kp.refine == DDMPC_REFINE_ALWAYS;
+  if (always && h->long_data)
+    return fail(DDMPC_ERR_UNSUPPORTED, "DDMPC_REFINE_ALWAYS needs the trajectory in LDS: not available for N = %d at this problem size", h->prm.N);
   int* rflag = nullptr;
   if (refinable && h->kp.refine == DDMPC_REFINE_AUTO) {
     const bool fresh = h->d_rflag.bytes < (B + 1) * sizeof(int);
     if ((rc = h->d_rflag.ensure((B + 1) * sizeof(int)))) return rc;
     rflag = (int*)h->d_rflag.p;
     if (fresh) HIP_TRY(hipMemsetAsync(rflag, 0, (B + 1) * sizeof(int), h->stream));
+  }
+  double* lbeta = nullptr;                // trajectories beyond the LDS: the chunks write beta / the active set for the streamed residual check
+  signed char* lact = nullptr;
+  if (h->long_data) {
+    if ((rc = h->d_beta.ensure(B * h->kp.rE * sizeof(double))) || (rc = h->d_act.ensure(B * h->kp.rE))) return rc;
+    lbeta = (double*)h->d_beta.p; lact = (signed char*)h->d_act.p;
+    h->ws_stale = false;
   }
   KParams kchunk = h->kp;
   kchunk.epoch = next_refine_epoch(h);
@@ -1433,7 +1521,8 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
                        h->lds_bytes, h->stream, kck,
                        (const double*)(dud + b0 * su), (const double*)(dyd + b0 * sy), (const double*)(dup + b0 * sup),
                        (const double*)(dyp + b0 * syp), duo + b0 * suo, dco + b0, (int*)(dst + b0), (int*)(dit + b0),
-                       (double*)nullptr, (signed char*)nullptr, (unsigned long long*)nullptr, (double*)nullptr,
+                       lbeta ? lbeta + b0 * h->kp.rE : (double*)nullptr, lact ? lact + b0 * h->kp.rE : (signed char*)nullptr,
+                       (unsigned long long*)nullptr, (double*)nullptr,
                        (double*)nullptr, rflag ? rflag + b0 : (int*)nullptr, (const int*)nullptr, 0LL, rflag ? rflag + B : (int*)nullptr);
     if (hipGetLastError() != hipSuccess) rcl = fail(DDMPC_ERR_HIP, "ddmpc_solve_from_host: launch of chunk %zu failed", k);
   }
@@ -1442,6 +1531,10 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
     h->ud = dud; h->yd = dyd;
     rcl = gram_pre_launch(h, kchunk, dud, dyd, B, 0, true);
   }
+  if (rcl == DDMPC_OK && rflag && h->long_data) {
+    rcl = long_data_residual_check(h, kchunk, (const int*)rflag, dud, dyd, dup, dyp, (const double*)h->d_beta.p, (const signed char*)h->d_act.p,
+                                   (int*)dst, B);
+  } else
   if (rcl == DDMPC_OK && rflag) {
     KParams kq = kchunk;
     kq.refine = DDMPC_REFINE_ALWAYS;
@@ -1567,7 +1660,7 @@ int ddmpc_prepare(ddmpc_handle* h) {
 #undef DDMPC_INSTANCE
   if (!launched) return fail(DDMPC_ERR_UNSUPPORTED, "no gain kernel for %d tile rows", NT);
   HIP_TRY(hipGetLastError());
-  if (k.lam != 0.0 && (k.refine == DDMPC_REFINE_ALWAYS || k.refine == DDMPC_REFINE_AUTO)) {
+  if (k.lam != 0.0 && (k.refine == DDMPC_REFINE_ALWAYS || k.refine == DDMPC_REFINE_AUTO) && !h->long_data) {
     // The substitutions above went through the unrefined factor, whose error is the Gram route's (cond(H) squared).
     // Replace columns of the law by refining cold solves: beta is affine in the past window, so column 1 + f =
     // beta(e_f) - beta(0).  nf + 1 launches of the refining kernel variant, once per data set -- ALWAYS: for every

@@ -463,6 +463,43 @@ __global__ void ddmpc_or_flags_kernel(long long batch, int epoch, const int* __r
   flags[b] = epoch;
   atomicMax(flags + batch, epoch);
 }
+// Trajectories beyond the LDS (KParams::stage_xs = 0): the refining variant is not available, so an instance the plain kernel
+// flagged -- its a-priori residual bound did not dismiss it and the exact check could not run -- is reported "optimal_inaccurate".
+// ... unless the exact-Hankel residual, formed by a streaming launch (H (H' beta) from global memory: `zp`, RR2-style partial sums
+// [batch][ng][VL], component order), says the solve is fine:  res = |t - (H (H' beta) + lam D beta)|_inf / |t|_inf <= refine_res
+// clears the flag.  One workgroup per instance; only flagged instances are looked at.
+__global__ __launch_bounds__(256) void ddmpc_flag_inaccurate_kernel(KParams P, int RPs, int epoch, const int* __restrict__ flags,
+                                                                    const double* __restrict__ u_past, const double* __restrict__ y_past,
+                                                                    const double* __restrict__ beta, const signed char* __restrict__ act,
+                                                                    const double* __restrict__ zp, int ng, int VL, int* __restrict__ status) {
+  const long long b = blockIdx.x;
+  if (flags[b] != epoch || status[b] != 0) return;                         // (workgroup-uniform)
+  __shared__ double red[8];
+  const int tid = threadIdx.x, n = P.npu / P.m;
+  const double* up = u_past + b * (long long)P.npu;
+  const double* yp = y_past + b * (long long)(n * P.p);
+  double rmx = 0.0, tmx = 0.0;
+  for (int rho = tid; rho < P.r; rho += blockDim.x) {
+    const int pidx = P.tabi[1 * RPs + rho];
+    const int a = act[b * (long long)P.rE + rho];
+    const double t = ((pidx >= 0) ? ((pidx < P.npu) ? up[pidx] : yp[pidx - P.npu]) : P.tabd[2 * RPs + rho]) + a * P.bound;
+    const double D = a ? P.tabd[1 * RPs + rho] : P.tabd[0 * RPs + rho];
+    double hz = 0.0;
+    for (int g = 0; g < ng; ++g) hz += zp[(b * ng + g) * (long long)VL + rho];
+    const double rv = t - hz - P.lam * D * beta[b * (long long)P.rE + rho];
+    rmx = fmax(rmx, (rv == rv) ? fabs(rv) : 1e300);
+    tmx = fmax(tmx, fabs(t));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { rmx = fmax(rmx, __shfl_xor(rmx, off, 64)); tmx = fmax(tmx, __shfl_xor(tmx, off, 64)); }
+  if ((tid & 63) == 0) { red[tid >> 6] = rmx; red[4 + (tid >> 6)] = tmx; }
+  __syncthreads();
+  if (tid == 0) {
+    double r_ = 0.0, t_ = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { r_ = fmax(r_, red[w]); t_ = fmax(t_, red[4 + w]); }
+    if (!(r_ / fmax(t_, 1e-300) <= P.refine_res)) status[b] = 1;
+  }
+}
 __global__ void ddmpc_gain_column_kernel(long long batch, int r, int rE, int nrhs, int j, const double* __restrict__ beta,
                                          double* __restrict__ gain, const int* __restrict__ flags, int epoch) {
   const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;

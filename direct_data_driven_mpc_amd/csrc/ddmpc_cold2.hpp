@@ -1655,7 +1655,7 @@ __global__ __launch_bounds__(64 * W, DDMPC_MIN_WAVES(NT, W)) void ddmpc_cold_sol
     pwv[e()] = 0.0;
     if (i < npast) pwv[e()] = (i < P.npu) ? u_past[b * (long long)P.npu + i] : y_past[b * (long long)(npast - P.npu) + (i - P.npu)];
   });
-  {
+  if (P.stage_xs) {                          // (kernel-uniform; 0: trajectory beyond the LDS, see KParams::stage_xs)
     const double* ud = u_d + b * (long long)P.N * P.m;
     const double* yd = y_d + b * (long long)P.N * P.p;
     if (P.m == 2 && P.p == 2) {              // 16-byte loads, one time step per lane

@@ -75,6 +75,9 @@ struct KParams {
   // Gram phase of the kernel is one 32-byte load per lane and tile.  nullptr: the kernel forms G itself.
   const double* gpre;
   long long gpre_stride;
+  int stage_xs;         // 1: the trajectory is staged in LDS (default).  0: it is longer than LDS holds (round 5): G comes from a
+                        // streaming launch through `gpre`, nothing in the kernel touches xs, and what needs the trajectory -- the
+                        // exact-Hankel residual check of AUTO refinement, the refining variant -- is not available (host: launch_cold)
 };
 
 template <int N, class F>

@@ -762,6 +762,34 @@ __global__ __launch_bounds__(1024) void rr2_cwc_kernel(KParams P, int RPs, const
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Packed Gram matrix (rr2_gram_kernel, identity order) -> the accumulator-tile layout the register-resident cold-solve kernel
+// loads through KParams::gpre (tile (I, J), I >= J, at (I (I + 1) / 2 + J) * 256; double 4 * lane + j = register j of lane
+// (l4, l15) = K[16 J + l4 + 4 j][16 I + l15]; diagonal tiles filled on both sides; rows / columns past r: zero).  Used when the
+// trajectory is longer than the cold kernel's LDS holds (hankel_matrix.py:39-51 takes any N >= L): the Gram matrix then comes
+// from the streaming kernel of the phase pipeline instead of the in-kernel structured Gram.  grid = (tiles, batch), 64 threads.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void rr2_pack_tiles_kernel(const double* __restrict__ ws, long long stride, int r, int NT,
+                                                            double* __restrict__ gpre, long long gstride) {
+  const long long b = blockIdx.y;
+  const int t = blockIdx.x;
+  int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while ((I + 1) * (I + 2) / 2 <= t) ++I;
+  while (I * (I + 1) / 2 > t) --I;
+  const int J = t - I * (I + 1) / 2;
+  if (I >= NT) return;
+  const int lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
+  const double* G = ws + b * stride;
+  d4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int a = 16 * J + l4 + 4 * j, c = 16 * I + l15;
+    const int hi = a > c ? a : c, lo = a > c ? c : a;
+    v[j] = (hi < r) ? G[pk_row((size_t)hi) + lo] : 0.0;
+  }
+  *reinterpret_cast<d4*>(gpre + b * gstride + (long long)t * 256 + 4 * lane) = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // The rank decision of an exact-data NOMINAL problem, judged from the pivot candidates AFTER the factorisation (round 5).
 // The reference decides ranks with a data-scaled tolerance on singular values (hankel_matrix.py:82); here a pivot below
 // tol_rel x (largest diagonal entry) counts as zero, and that fixed tolerance has a window that moves with the plant: dependent

@@ -138,6 +138,81 @@ __global__ void probe(double* out, long long* cyc, int reps) {
   out[blockIdx.x * 64 + lane] = accum + Ad[0] + Ad[1] + Ad[2] + Ad[3] + Et[0] + Et[1] + Et[2] + Et[3] + pdg;
 }
 
+// Two instances per instruction stream (round-5 experiment): lanes 0..31 = the 16 tile rows + 16 identity rows of
+// instance A, lanes 32..63 = those of instance B.  The pivot chain, the substitution of the rows and the LDS hand-off are ONE
+// set of instructions for both (each half wave works on its own 4 x 4 block and its own rows); what cannot be shared is the
+// matrix pipe: a v_mfma_f64_16x16x4 takes its operand from all 64 lanes, so every instance needs its own pair of MFMAs, with
+// operands that first have to be spread from its half wave over the whole wave (v_permlane32_swap in front of the
+// v_permlane16_swap pair of the shipped sub-step).
+__global__ void probe_pair(double* out, long long* cyc, int reps) {
+  __shared__ double PT2[2 * 32 * 4];
+  const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lo = l15 >> 2;
+  const int x = lane & 31, inst = lane >> 5;
+  d4 Ad[2], Et[2];
+  for (int t = 0; t < 2; ++t)
+    for (int j = 0; j < 4; ++j) { Ad[t][j] = (l4 + 4 * j == l15) ? -40.0 - t : -0.01 * ((lane + j + t) & 7); Et[t][j] = (l4 + 4 * j == l15) ? -1.0 : 0.0; }
+  double accum = 0.0;
+  long long t0 = 0, t1 = 0;
+  double* P = PT2 + inst * 128;                      // this half wave's panel columns
+  for (int r = 0; r < reps + 1; ++r) {
+    if (r == 1) t0 = __builtin_amdgcn_s_memtime();
+    // panel columns of both instances out of their accumulators (one store instruction per register pair, as shipped)
+    if (lo == 0) {
+      for (int t = 0; t < 2; ++t)
+        for (int j = 0; j < 4; ++j) { PT2[t * 128 + (l4 + 4 * j) * 4 + l3] = Ad[t][j]; PT2[t * 128 + (16 + l4 + 4 * j) * 4 + l3] = Et[t][j]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const double p00 = -P[0];
+    const double p10 = -P[4], p11 = -P[5];
+    const double p20 = -P[8], p21 = -P[9], p22 = -P[10];
+    const double p30 = -P[12], p31 = -P[13], p32 = -P[14], p33 = -P[15];
+    const double r0 = P[x * 4 + 0], r1 = P[x * 4 + 1], r2 = P[x * 4 + 2], r3 = P[x * 4 + 3];
+    const double i0 = rsq_n2(p00);
+    const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
+    const double i1 = rsq_n2(p11 - l10 * l10);
+    const double l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
+    const double i2 = rsq_n2(p22 - l20 * l20 - l21 * l21);
+    const double l32 = (p32 - l30 * l20 - l31 * l21) * i2;
+    const double i3 = rsq_n2(p33 - l30 * l30 - l31 * l31 - l32 * l32);
+    const double x0 = -r0 * i0;
+    const double x1 = -(r1 + x0 * l10) * i1;
+    const double x2 = -(r2 + x0 * l20 + x1 * l21) * i2;
+    const double x3 = -(r3 + x0 * l30 + x1 * l31 + x2 * l32) * i3;
+    // operands: for instance t the values of ITS half wave in both halves (permlane32 swap with itself), then the shipped swaps
+    auto spread = [&](double v, int t) __attribute__((always_inline)) -> double {
+      const auto lo2 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+      const auto hi2 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+      // swap(v, v): result[0] = [v.lower half, v.lower half], result[1] = [v.upper half, v.upper half]
+      return t == 0 ? __hiloint2double((int)hi2[0], (int)lo2[0]) : __hiloint2double((int)hi2[1], (int)lo2[1]);
+    };
+    for (int t = 0; t < 2; ++t) {
+      const double y0 = spread(x0, t), y1 = spread(x1, t), y2 = spread(x2, t), y3 = spread(x3, t);
+      const d2 s01a = permlane16_swap_f64(y0, y1), s23a = permlane16_swap_f64(y2, y3);
+      const bool lowhalf = lane < 32;
+      const double opA = (lowhalf ? s01a[0] : s23a[0]) * 1e-3;
+      const double opE = (lowhalf ? s01a[1] : s23a[1]) * 1e-3;
+      Ad[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA, opA, Ad[t], 0, 0, 0);
+      Et[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(opE, opA, Et[t], 0, 0, 0);
+    }
+    accum += i3;
+  }
+  t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cyc[blockIdx.x] = t1 - t0;
+  out[blockIdx.x * 64 + lane] = accum + Ad[0][0] + Ad[1][1] + Et[0][2] + Et[1][3];
+}
+
+void run_pair() {
+  double* out; long long* cyc;
+  hipMalloc(&out, 64 * 8 * sizeof(double)); hipMalloc(&cyc, 8 * sizeof(long long));
+  const int reps = 2000;
+  probe_pair<<<1, 64>>>(out, cyc, reps);
+  hipDeviceSynchronize();
+  long long h; hipMemcpy(&h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+  printf("pair     %-90s %7.1f cycles per sub-step of TWO instances = %.1f per instance\n",
+         "whole sub-step, two instances per instruction stream (half wave each, 4 MFMAs, operands spread by permlane32)", (double)h / reps, (double)h / reps / 2);
+  hipFree(out); hipFree(cyc);
+}
+
 template <int MODE>
 void run(const char* what) {
   double* out; long long* cyc;
@@ -173,5 +248,6 @@ int main() {
   run<10 + 128 + 512>("... and the pivot block taken from the handed-over columns by v_readlane (no 4x4x4 MFMA)");
   run<11 + 128 + 256 + 16>("register hand-off behind the second pivot, identity-block MFMA of the previous sub-step issued behind the first pivot");
   run<11 + 128 + 256 + 32>("... hand-off behind the third pivot");
+  run_pair();
   return 0;
 }
