@@ -45,6 +45,10 @@ passw write WRITE_SIZE
 timeout -k 10 200 python tools/cold_check.py ref > "$OUT/refine_modes.log" 2>&1
 
 timeout -k 10 120 python tools/phase_stamps.py > "$OUT/phase_stamps.log" 2>&1
+timeout -k 10 200 python tools/convex_time.py --stamps > "$OUT/convex_time.log" 2>&1
+timeout -k 10 120 python tools/time_host_pipeline.py > "$OUT/host_pipeline.log" 2>&1
+timeout -k 10 120 python tools/host_pipeline_order.py >> "$OUT/host_pipeline.log" 2>&1
+timeout -k 10 60 tools/substep_probe > "$OUT/substep_probe.log" 2>&1
 timeout -k 10 300 python tools/bench_configs.py > "$OUT/other_configs.log" 2>&1
 echo "[collect] other configs done"
 
@@ -57,6 +61,11 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
     python tools/cfg5_time.py --steps 3 > "$OUT/cfg5_stats.log" 2>&1
 # counters of the phase kernels (ddmpc_rr2.hpp, ddmpc_rr2_solve.hpp): separate --pmc passes, totals per kernel over three solves
 bash tools/pmc_rr2.sh "gpurun_out/$TAG/cfg5_pmc" sq sq2 tcc fetch write > "$OUT/cfg5_pmc_totals.txt" 2>&1
+# the ROBUST scheme with the slack box at that size (ddmpc_rr3.hpp, round 5): per-kernel durations and counters incl. Scratch_Size
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg5r_stats" -- \
+    python tools/cfg5_time.py --robust --steps 3 > "$OUT/cfg5r_stats.log" 2>&1
+RR2_ARGS=--robust bash tools/pmc_rr2.sh "gpurun_out/$TAG/cfg5r_pmc" sq fetch write > "$OUT/cfg5r_pmc_totals.txt" 2>&1
+timeout -k 10 200 python tools/rr3_schedule.py > "$OUT/cfg5r_schedule.log" 2>&1
 # the affine-law step (rr2_gain_step_kernel): bytes per launch
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d "$OUT/cfg5_law_$C" -- python tools/cfg5_time.py --warm --steps 2 > "$OUT/cfg5_law_$C.log" 2>&1

@@ -32,9 +32,15 @@ shutil.copy(os.path.join(src, "phase_stamps.log"), os.path.join(dst, tag + "_pha
 shutil.copy(os.path.join(src, "other_configs.log"), os.path.join(dst, tag + "_other_configs.log"))
 
 for name in ("cfg5_time.log", "cfg5_phase_stamps.log", "cfg5_parity.log", "cfg5size_robust_parity.log", "large_kernel_fuzz.log",
-             "refine_calib.log", "refine_modes.log"):
+             "refine_calib.log", "refine_modes.log", "convex_time.log", "host_pipeline.log", "substep_probe.log",
+             "cfg5r_pmc_totals.txt", "cfg5r_schedule.log"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, tag.replace("_final", "") + "_" + name))
+if glob.glob(os.path.join(src, "cfg5r_stats/*/*_kernel_stats.csv")):
+    shutil.copy(one("cfg5r_stats/*/*_kernel_stats.csv"), os.path.join(dst, tag.replace("_final", "") + "_cfg5size_robust_kernel_stats.csv"))
+    for row in csv.DictReader(open(one("cfg5r_stats/*/*_kernel_stats.csv"))):
+        if "rr" in row["Name"] or "large_solve" in row["Name"]:
+            print("cfg5-size robust rocprof: %-60s %5s calls, avg %9.2f us" % (row["Name"][:60], row["Calls"], float(row["AverageNs"]) / 1e3))
 if glob.glob(os.path.join(src, "cfg5_stats/*/*_kernel_stats.csv")):
     shutil.copy(one("cfg5_stats/*/*_kernel_stats.csv"), os.path.join(dst, tag.replace("_final", "") + "_cfg5_kernel_stats.csv"))
     for name in ("cfg5_pmc_totals.txt", "nominal_fuzz.log", "cfg5_law_pmc.txt", "rr2_check.log", "gram_modes.log", "cfg5_two_halves.log"):

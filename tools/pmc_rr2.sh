@@ -1,6 +1,7 @@
 #!/bin/bash
 # Counters of the phase kernels of a cfg-5 solve (ddmpc_rr2.hpp, ddmpc_rr2_solve.hpp), separate --pmc passes, per-kernel totals
-# over the dispatches of three solves at the end.     bash tools/pmc_rr2.sh <outdir> [passes...]
+# over the dispatches of three solves at the end.     [RR2_ARGS=--robust] bash tools/pmc_rr2.sh <outdir> [passes...]
+# (RR2_ARGS=--robust: the ROBUST scheme with the slack box at that size, ddmpc_rr3.hpp)
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/${1:-gpurun_out/r4/pmc_rr2}
@@ -8,7 +9,7 @@ shift
 PASSES=${@:-"sq sq2 tcc fetch write"}
 mkdir -p $OUT
 cd $ROOT
-p() { name=$1; shift; timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python tools/cfg5_time.py --steps 1 > $OUT/$name.log 2>&1 || echo "pass $name failed"; }
+p() { name=$1; shift; timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python tools/cfg5_time.py $RR2_ARGS --steps 1 > $OUT/$name.log 2>&1 || echo "pass $name failed"; }
 for P in $PASSES; do
   case $P in
     sq) p sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_WAVES ;;
