@@ -314,7 +314,12 @@ int ddmpc_debug_stamps(ddmpc_handle* h, int enable, uint64_t* out);
 /* Diagnostics only (problems beyond the register-resident kernels): copies instance `b`'s slice of the global workspace
  * (packed factor of the Gram matrix, then the packed factor of the reduced normal matrix; rows on 128-byte boundaries)
  * and its pivot record [skip (rv) | skipT (rv) | nlive | nRl] to host memory, at most `ws_count` doubles / `meta_count`
- * ints; either output may be NULL.  *ws_avail / *meta_avail (may be NULL) receive the sizes of the slices. */
+ * ints; either output may be NULL.  *ws_avail / *meta_avail (may be NULL) receive the sizes of the slices.
+ * Round 5: ws_count < 0 (NOMINAL, phase kernels): the pivot candidates of G's factorisation in the order they were decided on
+ * (16 ceil(r / 16) doubles: the pivot where a column was accepted, the residue where it was skipped; tools/pivot_gap_study.py).
+ * ROBUST controllers beyond 271 rows on the phase kernels: meta_out receives the per-instance record of the last solve
+ * [k, state, iterations, k, switched positions (64), active set (r rounded up to 2), start tick, ticks (100 MHz), -, -] and
+ * *ws_avail = 0 (tools/rr3_schedule.py). */
 int ddmpc_debug_workspace(ddmpc_handle* h, int64_t b, double* ws_out, int64_t ws_count, int32_t* meta_out, int64_t meta_count,
                           int64_t* ws_avail, int64_t* meta_avail);
 

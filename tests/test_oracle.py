@@ -219,3 +219,54 @@ def test_fp64_checkers_against_the_extended_precision_golden_solutions_of_the_he
     u_c, c_c, st_c, it_c = oracle_c.solve_batch(spec, N, d["u_d"], d["y_d"], up, yp)[:4]
     assert np.all(st_c == 0)
     assert np.max(np.abs(u_c - ug) / np.max(np.abs(ug), axis=1, keepdims=True)) < 5e-11 and np.max(np.abs(c_c - cg) / cg) < 5e-11
+
+
+def test_slack_box_as_rank_k_update_of_the_first_factor():
+    """The algebra behind round 5's CONVEX path (ddmpc_cold2.hpp `rank_update`, ddmpc_rr3.hpp), on the CPU: active-set iterations
+    that keep the Cholesky factor of the EMPTY active set and treat the switched slack components as a rank-k diagonal
+    modification (Woodbury) visit the same active sets in the same number of iterations as re-factoring, and end in the same
+    solution -- which is the full-space oracle's (controller.py:631-677).  k stays tiny on the benchmark data."""
+    import scipy.linalg as sla
+    from oracle.reduced_form import component_tables
+    spec = orc.spec_from_params(slack_var_constraint_type=1)
+    n, m, p, L_, Ln = spec.n, spec.m, spec.p, spec.L, spec.Ln
+    lam = spec.lamb_alpha * spec.eps_max
+    dd = lam / spec.lamb_sigma
+    bound = spec.c * spec.eps_max
+    w_pred = slice(Ln * m + n * p, Ln * (m + p))
+    for seed in range(6):
+        inst = orc.generate_instance(seed)
+        u_d, y_d = inst["u_d"], inst["y_d"]
+        up, yp = u_d[-n:].reshape(-1), y_d[-n:].reshape(-1)
+        H = np.vstack([orc.hankel_matrix(u_d, Ln), orc.hankel_matrix(y_d, Ln)])
+        G = H @ H.T
+        act = np.zeros(L_ * p, dtype=int)
+        D0, t0 = component_tables(spec, up, yp, act)
+        L0 = np.linalg.cholesky(G + lam * np.diag(D0))
+        y0 = sla.solve_triangular(L0, t0, lower=True)
+        iters, kmax = 0, 0
+        while True:
+            iters += 1
+            S = np.nonzero(act)[0]
+            k = len(S)
+            kmax = max(kmax, k)
+            v = y0
+            if k:
+                rows = np.arange(Ln * m + n * p, Ln * (m + p))[S]
+                E = np.zeros((G.shape[0], k)); E[rows, np.arange(k)] = 1.0
+                W = sla.solve_triangular(L0, E, lower=True)
+                yq = y0 + bound * (W @ act[S])
+                Sm = np.eye(k) / dd - W.T @ W
+                assert np.all(np.linalg.eigvalsh(Sm) > 0)              # positive definite: K(act) is
+                v = yq + W @ np.linalg.solve(Sm, W.T @ yq)
+            beta = sla.solve_triangular(L0.T, v, lower=False)
+            sh = -lam * beta[w_pred] / spec.lamb_sigma
+            new = np.where(sh > bound, 1, np.where(sh < -bound, -1, 0))
+            if np.array_equal(new, act):
+                break
+            act = new
+        sol = orc.solve_fullspace(spec, u_d, y_d, up, yp)
+        assert iters == sol.iters and kmax <= 4
+        D, t = component_tables(spec, up, yp, act)
+        z = t - lam * D * beta
+        assert np.max(np.abs(z[n * m:Ln * m] - sol.optimal_u)) <= 1e-10 * np.max(np.abs(sol.optimal_u))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the per-round evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh <tag> [headline|cfg5|all]        e.g. r03_final headline
+#   bash tools/collect_profiles.sh <tag> [headline|cfg5|cfg5b|calib|all]        e.g. r05_final headline
 # (two parts so that each fits one gpurun call)
 # Writes everything under gpurun_out/<tag>/; copy the summaries into profiles/ afterwards.
 # Counter passes are separate runs with --pmc only (no trace domains), as the pool requires.
@@ -79,6 +79,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     v = [float(r["Counter_Value"]) for r in rows]
     if v: print("rr2_gain_step_kernel %s: %d launches, mean %.1f KB per launch%s" % (c, len(v), sum(v) / len(v), " (x2 on gfx950 = %.1f MB)" % (2 * sum(v) / len(v) / 1e3) if c == "FETCH_SIZE" else ""))
 PY
+echo "[collect] cfg5 timing / counters done"
+fi
+if [ "$PART" = "cfg5b" ] || [ "$PART" = "all" ]; then
 timeout -k 10 300 python tools/rr2_check.py --time > "$OUT/rr2_check.log" 2>&1
 timeout -k 10 300 python tools/gram_modes_time.py > "$OUT/gram_modes.log" 2>&1
 timeout -k 10 200 python tools/cfg5_two_halves.py > "$OUT/cfg5_two_halves.log" 2>&1
@@ -86,7 +89,10 @@ timeout -k 10 600 python tools/nominal_fuzz.py --cases 96 --no-svd --large-only 
 timeout -k 10 400 python tools/config5_check.py --check 512 > "$OUT/cfg5_parity.log" 2>&1
 timeout -k 10 600 python tools/config5_check.py --robust --check 512 > "$OUT/cfg5size_robust_parity.log" 2>&1
 timeout -k 10 400 python tools/large_fuzz.py --cases 12 > "$OUT/large_kernel_fuzz.log" 2>&1
-echo "[collect] cfg5 done"
+timeout -k 10 120 python tools/pivot_gap_study.py 6 > "$OUT/pivot_gap_study.log" 2>&1
+echo "[collect] cfg5b done"
+fi
+if [ "$PART" = "calib" ] || [ "$PART" = "all" ]; then
 # the AUTO refinement trigger on the benchmark batch and on the 96-case random-plant sweep (bound q, exact residual, off / auto / always)
 timeout -k 10 900 python tools/refine_calib.py 96 > "$OUT/refine_calib.log" 2>&1
 fi
