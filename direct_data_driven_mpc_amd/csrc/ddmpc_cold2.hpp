@@ -1157,7 +1157,8 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
       if (tid == 0) flags[1] = 0;                                    // (everybody has read it: barrier above)
       ctab_ok = false;
       const int s0 = flags[4];
-      const int sj = (l15 == 0) ? s0 : (l15 == 1) ? flags[5] : (l15 == 2) ? flags[6] : flags[7];
+      const int col = l15 & 3;                                       // column of W this lane works on (replicated over the four quads)
+      const int sj = (col == 0) ? s0 : (col == 1) ? flags[5] : (col == 2) ? flags[6] : flags[7];
       int J0 = s0 >> 4;                                              // first tile row with a nonzero row of W
       J0 = __builtin_amdgcn_readfirstlane(J0);
       // One workgroup barrier per tile row.  W_J = M_J (E_J - sum_{K<J} U(K,J)' W_K): only the term K = J - 1 needs the tile row
@@ -1166,10 +1167,22 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
       // already in LDS, beside the chain -- and applies M_J itself; the panel wave (idle here: it owns the diagonal tiles only)
       // accumulates W'W and W'y one row behind.  (First version: partial products of row J by every wave -> barrier -> the
       // panel wave -> barrier: 28 K cycles per update on the benchmark against 15 K for the back substitution.)
+      //
+      // W has KC <= 4 columns: a v_mfma_f64_16x16x4 would spend 64 cycles of the matrix pipe on a product of which a quarter is
+      // used.  The products run on v_mfma_f64_4x4x4 instead (four independent 4 x 4 x 4 blocks per instruction, ~16 cycles):
+      //   U(K,J)' W_K: block b = rows 4 b .. 4 b + 3 of the result, chunk c of the contraction per instruction -- the A operand
+      //     lane (l4 = k, l15 = 4 b + i) = U[4 c + k][4 b + i] IS accumulator register c, the B operand lane (l4 = k, l15 = 4 b + j)
+      //     = W_K[4 c + k][j], the same in every block; the result P[4 b + i][j] comes back in lane (l4 = i, l15 = 4 b + j);
+      //   M_J V: one instruction per four rows i0 .. i0 + 3, block b = chunk b of the contraction: B = V in exactly that result
+      //     layout, A lane (l4 = k, l15 = 4 b + i) = M_J[i0 + i][4 b + k] from LDS; the four blocks' partial sums meet by two
+      //     row rotations, after which EVERY quad of the row holds W_J[i0 + l4][j] -- the replicated form the next row's B operand
+      //     and the store want.
       constexpr int CW = TM::wave(1, 0);
       auto noncrit = [](int w, int J) constexpr { for (int K = 0; K + 2 <= J; ++K) if (TM::wave(J, K) == w) return true; return false; };
-      d4 sacc = d4{0.0, 0.0, 0.0, 0.0}, gacc = d4{0.0, 0.0, 0.0, 0.0}, Wprev = d4{0.0, 0.0, 0.0, 0.0};
+      d4 sacc = d4{0.0, 0.0, 0.0, 0.0}, gacc = d4{0.0, 0.0, 0.0, 0.0};
+      double Wrep[4] = {0.0, 0.0, 0.0, 0.0};                         // chain wave: W_{J-1}[4 c + l4][col], c = 0 .. 3
       const double* Mb = PB;
+      const int prow = 4 * (l15 >> 2) + l4;                          // row of the tile this lane holds in the 4x4x4 result layout
       static_for<NT + 1>([&](auto JJ) __attribute__((always_inline)) {
         constexpr int J = JJ;
         asm volatile("" : "+s"(J0));                                 // (opaque per tile row: no hoisted lane masks)
@@ -1178,36 +1191,34 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         if constexpr (J < NT) {
           if (do_chain) {
             if constexpr (WAVE == CW) {
-              d4 Pc = d4{0.0, 0.0, 0.0, 0.0};
+              double pc = 0.0;
               if constexpr (J >= 1) {
                 if (J > J0) {                                        // the term that waits for the row before
                   constexpr int S = TM::slot(J, J - 1);
-                  static_for<4>([&](auto j) __attribute__((always_inline)) {
-                    Pc = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[S][j()], Wprev[j()], Pc, 0, 0, 0);
+                  static_for<4>([&](auto c) __attribute__((always_inline)) {
+                    pc = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[S][c()], Wrep[c()], pc, 0, 0, 0);
                   });
                 }
               }
-              d4 V;
-              static_for<4>([&](auto q) __attribute__((always_inline)) {
-                const int row = 16 * J + l4 + 4 * q();
-                double v = (l15 < k && sj == row) ? 1.0 : 0.0;
-                if constexpr (J >= 2) {
-                  if (J > J0 + 1) {                                  // the terms K <= J - 2, formed during the step before
-                    static_for<W>([&](auto w) __attribute__((always_inline)) {
-                      if constexpr (noncrit(w(), J)) v -= wpart[(((J & 1) * W + w()) * 16 + l4 + 4 * q()) * KC + (l15 & (KC - 1))];
-                    });
-                  }
+              double v = (col < k && sj == 16 * J + prow) ? 1.0 : 0.0;
+              if constexpr (J >= 2) {
+                if (J > J0 + 1) {                                    // the terms K <= J - 2, formed during the step before
+                  static_for<W>([&](auto w) __attribute__((always_inline)) {
+                    if constexpr (noncrit(w(), J)) v -= wpart[(((J & 1) * W + w()) * 16 + prow) * KC + (col & (KC - 1))];
+                  });
                 }
-                V[q()] = (l15 < KC && row < rE) ? v - Pc[q()] : 0.0;
-              });
-              d4 Wt = d4{0.0, 0.0, 0.0, 0.0};
-              static_for<4>([&](auto ks) __attribute__((always_inline)) {
-                Wt = __builtin_amdgcn_mfma_f64_16x16x4f64(Mb[J * 256 + l15 * 16 + 4 * ks() + l4], V[ks()], Wt, 0, 0, 0);
+              }
+              v = (col < KC && 16 * J + prow < rE) ? v - pc : 0.0;
+              static_for<4>([&](auto g) __attribute__((always_inline)) {       // rows 4 g .. 4 g + 3 of W_J
+                const double am = Mb[J * 256 + (4 * g() + col) * 16 + 4 * (l15 >> 2) + l4];
+                double w4 = __builtin_amdgcn_mfma_f64_4x4x4f64(am, v, 0.0, 0, 0, 0);
+                w4 += dpp_mov_f64<0x124>(w4);                        // row_ror:4
+                w4 += dpp_mov_f64<0x128>(w4);                        // row_ror:8: every quad holds the sum over the four blocks
+                Wrep[g()] = w4;
               });
               if (l15 < KC) {
-                static_for<4>([&](auto q) __attribute__((always_inline)) { Wc[(16 * J + l4 + 4 * q()) * KC + l15] = Wt[q()]; });
+                static_for<4>([&](auto g) __attribute__((always_inline)) { Wc[(16 * J + 4 * g() + l4) * KC + l15] = Wrep[g()]; });
               }
-              Wprev = Wt;
             }
           }
         }
@@ -1215,23 +1226,19 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         if constexpr (J + 1 < NT && J >= 1) {
           if (J >= J0 + 1 && 16 * (J + 1) < rE) {
             if constexpr (noncrit(WAVE, J + 1)) {
-              d4 pacc = d4{0.0, 0.0, 0.0, 0.0};
+              double pacc = 0.0;
               static_for<J>([&](auto K) __attribute__((always_inline)) {
                 if constexpr (TM::wave(J + 1, K) == WAVE) {
                   if (K >= J0) {
                     constexpr int S = TM::slot(J + 1, K);
-                    static_for<4>([&](auto j) __attribute__((always_inline)) {
-                      const double wv = Wc[(16 * K + 4 * j() + l4) * KC + (l15 & (KC - 1))];
-                      pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[S][j()], (l15 < KC) ? wv : 0.0, pacc, 0, 0, 0);
+                    static_for<4>([&](auto c) __attribute__((always_inline)) {
+                      const double wv = Wc[(16 * K + 4 * c() + l4) * KC + (col & (KC - 1))];
+                      pacc = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[S][c()], (col < KC) ? wv : 0.0, pacc, 0, 0, 0);
                     });
                   }
                 }
               });
-              if (l15 < KC) {
-                static_for<4>([&](auto q) __attribute__((always_inline)) {
-                  wpart[((((J + 1) & 1) * W + WAVE) * 16 + l4 + 4 * q()) * KC + l15] = pacc[q()];
-                });
-              }
+              if (col < KC) wpart[((((J + 1) & 1) * W + WAVE) * 16 + prow) * KC + col] = pacc;
             }
           }
         }
@@ -1257,6 +1264,22 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
         if (l15 < KS) sS[l4 * KS + l15] = sacc[0];                   // (W'W)[x = l4][y = l15]
         if (l15 == 0) sS[16 + l4] = gacc[0];                         // (W'y)[x = l4]
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // in-wave hand-off through LDS (see factor_begin)
+        if (k <= 2) {
+          // One or two switched components -- every instance of the benchmark configurations (tools/convex_update_study.py): the
+          // 2 x 2 system in closed form, every lane the same arithmetic (the general path below took 3.6 K cycles of a 40 K update)
+          const int sr0 = flags[4], sr1 = (k == 2) ? flags[5] : sr0;
+          const double d0 = P.lam * (cD0[sr0] - cD1[sr0]), d1 = P.lam * (cD0[sr1] - cD1[sr1]);
+          const double sg0 = (double)act[sr0] * P.bound, sg1 = (k == 2) ? (double)act[sr1] * P.bound : 0.0;
+          const double g00 = sS[0], g01 = (k == 2) ? sS[1] : 0.0, g11 = (k == 2) ? sS[KS + 1] : 0.0;
+          const double h0 = sS[16] + g00 * sg0 + g01 * sg1, h1 = (k == 2) ? sS[17] + g01 * sg0 + g11 * sg1 : 0.0;
+          const double a = 1.0 / d0 - g00, cc = (k == 2) ? 1.0 / d1 - g11 : 1.0;
+          const double det = a * cc - g01 * g01;
+          const bool ok2 = (d0 > 1e-300) && (d1 > 1e-300) && (a > 0.0) && (det > 0.0);
+          const double c0 = (cc * h0 + g01 * h1) / det, c1 = (k == 2) ? (a * h1 + g01 * h0) / det : 0.0;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          if (lane < KS) sS[24 + lane] = (lane == 0) ? c0 + sg0 : (lane == 1 && k == 2) ? c1 + sg1 : 0.0;
+          if (lane == 0) flags[3] = ok2 ? 0 : 1;
+        } else {
         // lane 4 x + y (< 16) holds entry (x, y) of Sm = diag(1/d) - W'W (identity on the padding) in ONE register; the
         // Cholesky runs across the lanes (three shuffles per column) -- a register-resident 4 x 4 factorisation in every lane
         // took 56 VGPRs next to the nine accumulator tiles and pushed three of those into scratch for the whole kernel
@@ -1300,6 +1323,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
           sS[24 + lane] = cv + ((lane < k) ? (double)act[srl] * P.bound : 0.0);
         }
         if (lane == 0) flags[3] = ok ? 0 : 1;
+        }
       }
       __syncthreads();
       const long long tu2 = now();

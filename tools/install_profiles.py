@@ -15,8 +15,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
 KERNEL = "ddmpc_cold_solve_kernel2"         # bench.py looks traffic up under this name
-MAIN = "ddmpc_cold_solve_kernel2<9, 4, false>"   # the plain variant: the dominant kernel of the headline run
-REFP = "ddmpc_cold_solve_kernel2<9, 4, true>"    # the filtered refinement pass of DDMPC_REFINE_AUTO (usually finds nothing to do)
+MAIN = "ddmpc_cold_solve_kernel2<9, 4, false, false>"   # the plain variant (REF = false, CVX = false): the dominant kernel of the headline run
+REFP = "ddmpc_cold_solve_kernel2<9, 4, true, false>"    # the filtered refinement pass of DDMPC_REFINE_AUTO (usually finds nothing to do)
 
 
 def one(pattern):
