@@ -31,9 +31,16 @@ def show(tag, spec, N, d, up, yp, B):
             ratios = small[1:] / small[:-1]
             j = int(np.argmax(ratios)) if len(ratios) else 0
             acc = rel[rel > 1e-8]
-            print("%-22s b=%d status %d: candidates > 0: %d, accepted (> 1e-8): %d; smallest accepted %.2e, largest rejected %.2e; "
-                  "largest gap below 1e-3: %.2e .. %.2e (x%.0f)" % (tag, b, status[b], len(pos), len(acc), acc.min(), rel[(rel > 0) & (rel <= 1e-8)].max() if np.any((rel > 0) & (rel <= 1e-8)) else 0.0,
-                                                                   small[j], small[j + 1], ratios[j]), flush=True)
+            bound = spec.m * (spec.L + spec.n) + spec.n              # rank H <= m (L + n) + n for exact data (Willems' lemma)
+            desc = np.sort(rel)[::-1]
+            note = ""
+            if len(acc) > bound:                                      # what rr2_rank_margin_kernel does with this instance
+                note = "  -> MORE than the rank bound %d: tolerance moved to %.2e (between %.2e and %.2e), factored again" % (
+                    bound, np.sqrt(desc[bound - 1] * desc[bound]), desc[bound], desc[bound - 1])
+            print("%-22s b=%d status %d: candidates > 0: %d, above the fixed 1e-8: %d (rank bound %d); smallest of them %.2e, largest below %.2e; "
+                  "largest gap below 1e-3: %.2e .. %.2e (x%.0f)%s" % (tag, b, status[b], len(pos), len(acc), bound, acc.min(),
+                                                                     rel[(rel > 0) & (rel <= 1e-8)].max() if np.any((rel > 0) & (rel <= 1e-8)) else 0.0,
+                                                                     small[j], small[j + 1], ratios[j], note), flush=True)
 
 
 if __name__ == "__main__":
