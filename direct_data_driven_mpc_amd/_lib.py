@@ -26,6 +26,7 @@ OPT_REFINE, OPT_REFINE_MAX, OPT_REFINE_RES_LOG10 = 3, 4, 5
 OPT_LARGE_PIPELINE = 6
 OPT_LARGE_AFFINE_LAW = 7
 OPT_CONVEX_UPDATE = 8
+OPT_GRAM_LAUNCH = 9
 PIPELINE_ONE_WORKGROUP, PIPELINE_PHASES = 0, 1
 REFINE_OFF, REFINE_AUTO, REFINE_ALWAYS = 0, 1, 2
 PATH_AUTO, PATH_COLD, PATH_WARM = 0, 1, 2

@@ -167,8 +167,9 @@ struct ddmpc_handle {
   int nA3 = 0;                            // ... first position of the slack-box components in the "boxed last" order
   DevBuf d_gpre;                          // Gram tiles of ddmpc_gram_tiles_kernel (structured Gram, m + p != 4), see gram_pre_launch
   bool gram_pre = false, gpre_valid = false;
+  int gram_launch = 0;                     // DDMPC_OPT_GRAM_LAUNCH: 0 streaming matrix-pipe kernel (rr2_gram_tiles*_kernel), 1 ddmpc_gram_tiles_kernel
+  bool gram_stream_ok = false, gram_valu_ok = false;      // which of the two can serve this shape
   bool long_data = false;                  // the trajectory does not fit the cold kernel's LDS: streaming Gram + gpre, no refinement (KParams::stage_xs = 0)
-  DevBuf d_gstream, d_gsdd, d_gsperm;      // ... packed G of the streaming launch, its 4 words per instance, the identity order
   DevBuf d_rr2tol, d_rr2rank;              // ... per-instance pivot tolerance and [flag, accepted pivots] of the rank decision (+ one counter word)
   DevBuf d_rr2cand;                        // ... the pivot candidates of G's factorisation as they were met (Rr2Chol::cand)
   DevBuf d_perm, d_rr2d, d_rr2res;                   // phase kernels (ddmpc_rr2.hpp): fixed-first component order [perm | iperm]; per instance
@@ -578,7 +579,7 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   k.stage_xs = 1;
   if (h->lds_bytes > 160 * 1024) {
     // hankel_matrix.py:39-51 takes any N >= L.  A trajectory beyond the LDS is never staged: G = H H' comes from the streaming
-    // Gram kernel of the phase pipeline (trajectory in chunks), re-laid into the kernel's tiles (rr2_pack_tiles_kernel), and the
+    // Gram kernel of the phase pipeline (trajectory in chunks), written into the kernel's tiles (rr2_gram_tiles*_kernel), and the
     // cold kernel runs in its `gpre` mode with no trajectory region at all.  What needs the trajectory on chip -- the
     // exact-Hankel residual check of AUTO refinement and the refining variant -- is not available at such N: an instance the
     // a-priori bound cannot dismiss is reported "optimal_inaccurate" (launch_cold), DDMPC_REFINE_ALWAYS is refused.
@@ -594,16 +595,22 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
     k.gram_dense = 0;
     h->lds_bytes = lds_doubles_for(h->kc, k.xs_len) * sizeof(double);
   }
-  // (trajectories whose staging does not fit the LDS of ddmpc_gram_tiles_kernel keep the dense product)
-  h->gram_pre = h->long_data ||
-                (p.gram_mode != DDMPC_GRAM_DENSE && k.nch != 4 && k.nch != 2 &&
-                 gram_tiles_lds_doubles(k.xs_len, k.r, k.nch, h->kc.NT) * sizeof(double) <= 150 * 1024);
+  // Structured Gram ahead of the kernel for plants of other than two or four channels: the streaming matrix-pipe launch
+  // (rr2_gram_tiles*_kernel: a chunk of its LDS must hold four time steps next to the L + n of overlap) or the launch that stages
+  // the whole trajectory (ddmpc_gram_tiles_kernel, DDMPC_OPT_GRAM_LAUNCH); shapes neither serves keep the dense product
+  h->gram_stream_ok = (((RR2_XCAP / k.nch) - k.Ln - 3) & ~3) >= 4 && 16 * h->kc.NT <= 1024;
+  h->gram_valu_ok = !h->long_data && gram_tiles_lds_doubles(k.xs_len, k.r, k.nch, h->kc.NT) * sizeof(double) <= 150 * 1024;
+  // (measured, tools/gram_modes_time.py: up to five channels the staged launch is the faster one -- long walks, few lags --, from
+  //  seven on the streaming one; DDMPC_OPT_GRAM_LAUNCH overrides)
+  h->gram_launch = (!h->gram_stream_ok || (h->gram_valu_ok && k.nch <= 5)) ? 1 : 0;
+  if (!h->gram_valu_ok) h->gram_launch = 0;
+  h->gram_pre = h->long_data || (p.gram_mode != DDMPC_GRAM_DENSE && k.nch != 4 && k.nch != 2 && (h->gram_stream_ok || h->gram_valu_ok));
   if (p.gram_mode == DDMPC_GRAM_STRUCTURED && k.nch != 4 && k.nch != 2 && !h->gram_pre) {
     // AUTO falls back to the dense product silently; a caller who asked for STRUCTURED by name is told
     const int nch_ = k.nch;
     delete h;
-    return fail(DDMPC_ERR_UNSUPPORTED, "DDMPC_GRAM_STRUCTURED cannot be served for this shape (m+p = %d channels: the trajectory "
-                "staging of the Gram launch must fit 150 KB of LDS); use DDMPC_GRAM_AUTO or DDMPC_GRAM_DENSE", nch_);
+    return fail(DDMPC_ERR_UNSUPPORTED, "DDMPC_GRAM_STRUCTURED cannot be served for this shape (m+p = %d channels: neither Gram launch "
+                "holds it in LDS); use DDMPC_GRAM_AUTO or DDMPC_GRAM_DENSE", nch_);
   }
   if (p.n * k.nch > h->kc.max_past) {       // (implied by L >= n and the instance table; kept as a guard of the LDS aliasing)
     delete h;
@@ -644,7 +651,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_gpre, &h->d_perm, &h->d_rr2d, &h->d_rr2res, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz, &h->d_gz, &h->d_gres, &h->d_zvirt, &h->d_rr3w, &h->d_rr3k, &h->d_rr_fb, &h->d_rrmeta_fb, &h->d_rr2cand, &h->d_rr2tol, &h->d_rr2rank, &h->d_gstream, &h->d_gsdd, &h->d_gsperm};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_gpre, &h->d_perm, &h->d_rr2d, &h->d_rr2res, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz, &h->d_gz, &h->d_gres, &h->d_zvirt, &h->d_rr3w, &h->d_rr3k, &h->d_rr_fb, &h->d_rrmeta_fb, &h->d_rr2cand, &h->d_rr2tol, &h->d_rr2rank};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -727,6 +734,14 @@ static int next_refine_epoch(ddmpc_handle* h) {
   return ++h->epoch;
 }
 
+// Structured Gram of the phase pipelines (rr2_gram_kernel; plants of at most eight channels: several lags per matrix tile).
+static void launch_rr2_gram(hipStream_t st, const KParams& k, const double* ud, const double* yd, const int* iperm, double* ws, long long stride,
+                            int n16, unsigned long long* dd, size_t nb) {
+  const dim3 grid(rr2_gram_grid(k.Ln, k.nch), (unsigned)nb);
+  if (k.nch <= 8) hipLaunchKernelGGL(rr2_gram_packed_kernel, grid, dim3(256), 0, st, k, ud, yd, iperm, ws, stride, n16, dd);
+  else hipLaunchKernelGGL(rr2_gram_kernel, grid, dim3(256), 0, st, k, ud, yd, iperm, ws, stride, n16, dd);
+}
+
 // large_mode (ROBUST controllers beyond the register-resident kernels only): 0 whole solve, 1 the data-dependent part alone
 // (ddmpc_prepare), 2 a solve on what that left in the workspace (ddmpc_step) -- see ddmpc_large_solve_kernel.
 // Structured Gram for channel counts other than four: the Gram tiles of `nb` instances (data at ud / yd) into slots b0 .. of
@@ -742,24 +757,13 @@ static int gram_pre_launch(ddmpc_handle* h, KParams& kq, const double* ud, const
   kq.gpre = (const double*)h->d_gpre.p + (long long)b0 * stride;
   kq.gpre_stride = stride;
   if (cacheable && h->gpre_valid) return DDMPC_OK;
-  if (h->long_data) {
-    // streaming Gram (trajectory in chunks through LDS: rr2_gram_kernel, identity component order), then the tiles
-    const int r = h->kp.r, n16 = (r + 15) & ~15, rv = (r + 1) & ~1;
-    const long long ndbl = (long long)pk_size((size_t)n16);
-    if ((rc = h->d_gstream.ensure((size_t)h->batch * (size_t)ndbl * sizeof(double))) || (rc = h->d_gsdd.ensure((size_t)h->batch * 4 * sizeof(unsigned long long))))
-      return rc;
-    if (!h->d_gsperm.p) {
-      std::vector<int> idp(2 * (size_t)rv);
-      for (int i = 0; i < rv; ++i) idp[i] = idp[rv + i] = i;
-      if ((rc = h->d_gsperm.ensure(idp.size() * sizeof(int)))) return rc;
-      HIP_TRY(hipMemcpy(h->d_gsperm.p, idp.data(), idp.size() * sizeof(int), hipMemcpyHostToDevice));
-    }
-    HIP_TRY(hipMemsetAsync(h->d_gsdd.p, 0, (size_t)h->batch * 4 * sizeof(unsigned long long), h->stream));
-    double* gs = (double*)h->d_gstream.p + (long long)b0 * ndbl;
-    hipLaunchKernelGGL(rr2_gram_kernel, dim3((unsigned)((h->kp.Ln + 4 * RR2_SL - 1) / (4 * RR2_SL)), (unsigned)nb), dim3(256), 0, h->stream,
-                       h->kp, ud, yd, (const int*)h->d_gsperm.p + rv, gs, ndbl, n16, (unsigned long long*)h->d_gsdd.p + 4 * b0);
-    hipLaunchKernelGGL(rr2_pack_tiles_kernel, dim3((unsigned)(NT * (NT + 1) / 2), (unsigned)nb), dim3(64), 0, h->stream, (const double*)gs, ndbl, r, NT,
-                       (double*)h->d_gpre.p + (long long)b0 * stride, stride);
+  if (h->long_data || h->gram_launch == 0) {
+    // streaming Gram on the matrix pipe (trajectory in chunks through LDS, several lags per tile for plants of at most eight
+    // channels), written straight into the tiles
+    const dim3 grid(rr2_gram_grid(h->kp.Ln, h->kp.nch), (unsigned)nb);
+    double* gp = (double*)h->d_gpre.p + (long long)b0 * stride;
+    if (h->kp.nch <= 8) hipLaunchKernelGGL(rr2_gram_tiles_packed_kernel, grid, dim3(256), 0, h->stream, h->kp, ud, yd, gp, stride, 16 * NT);
+    else hipLaunchKernelGGL(rr2_gram_tiles_kernel, grid, dim3(256), 0, h->stream, h->kp, ud, yd, gp, stride, 16 * NT);
     HIP_TRY(hipGetLastError());
     if (cacheable) h->gpre_valid = true;
     return DDMPC_OK;
@@ -790,8 +794,7 @@ static int launch_rr3_factors(ddmpc_handle* h) {
   unsigned long long* dd = (unsigned long long*)h->d_rr2d.p;
   const int* perm = (const int*)h->d_perm.p;
   double* scratch = (double*)h->d_rr.p;
-  hipLaunchKernelGGL(rr2_gram_kernel, dim3((unsigned)((k.Ln + 4 * RR2_SL - 1) / (4 * RR2_SL)), (unsigned)B), dim3(256), 0, h->stream,
-                     k, h->ud, h->yd, perm + rv, scratch, ndbl, n16, dd);
+  launch_rr2_gram(h->stream, k, h->ud, h->yd, perm + rv, scratch, ndbl, n16, dd, B);
   hipLaunchKernelGGL(rr3_shift_kernel, dim3((unsigned)B), dim3(256), 0, h->stream, k, 16 * h->kc.NT, perm, scratch, ndbl);
   Rr2Chol FG{};
   FG.ws = scratch; FG.stride = ndbl; FG.off = 0; FG.n16 = n16; FG.n_inst = nullptr; FG.n_stride = 0;
@@ -1143,8 +1146,7 @@ static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, 
   const int* perm = (const int*)h->d_perm.p;
   const int* iperm = perm + rv;
   auto gram = [&]() {
-    hipLaunchKernelGGL(rr2_gram_kernel, dim3((unsigned)((k.Ln + 4 * RR2_SL - 1) / (4 * RR2_SL)), (unsigned)B), dim3(256), 0, h->stream,
-                       k, h->ud, h->yd, iperm, scratch, ndbl, n16, dd);
+    launch_rr2_gram(h->stream, k, h->ud, h->yd, iperm, scratch, ndbl, n16, dd, B);
   };
   gram();
   auto cholesky = [&](const Rr2Chol& F, int nmax16) {
@@ -1769,6 +1771,14 @@ int ddmpc_set_option(ddmpc_handle* h, int option, int value) {
       return DDMPC_OK;
     case DDMPC_OPT_CONVEX_UPDATE:
       h->convex_update = value != 0;
+      return DDMPC_OK;
+    case DDMPC_OPT_GRAM_LAUNCH:
+      if (value != 0 && value != 1) return fail(DDMPC_ERR_INVALID, "Gram launch must be 0 (matrix pipe) or 1 (ddmpc_gram_tiles_kernel)");
+      if (value == 1 && !h->gram_valu_ok) return fail(DDMPC_ERR_UNSUPPORTED, "ddmpc_gram_tiles_kernel stages the whole trajectory in LDS: not at this shape");
+      if (value == 0 && !h->gram_stream_ok) return fail(DDMPC_ERR_UNSUPPORTED, "the streaming Gram launch does not hold this shape");
+      h->gram_launch = value;
+      h->gpre_valid = false;
+      h->prepared = false;
       return DDMPC_OK;
     case DDMPC_OPT_LARGE_PIPELINE:
       if (value != DDMPC_PIPELINE_ONE_WORKGROUP && value != DDMPC_PIPELINE_PHASES)

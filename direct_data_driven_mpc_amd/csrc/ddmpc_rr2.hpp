@@ -91,9 +91,18 @@ __device__ __forceinline__ double rr2_bits_to_double(unsigned long long v) { ret
 // The lag sums stay in the accumulators they were formed in; the window update of a whole 16x16 block is ONE MFMA with the
 // contraction index (tail term, -head term, 0, 0).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void rr2_gram_kernel(KParams P, const double* __restrict__ u_d, const double* __restrict__ y_d,
-                                                       const int* __restrict__ iperm, double* __restrict__ ws, long long stride,
-                                                       int n16, unsigned long long* __restrict__ dmaxbits) {
+// PACKED (nch <= 8, one channel tile): the 16 rows of the A operand carry LP = 16 / nch consecutive lags of the nch channels --
+// row l = (lag d0 + l / nch, channel l % nch) -- so one MFMA forms LP lag blocks instead of one in a corner of the tile (a
+// four-channel plant: 4 x fewer matrix instructions; what a trajectory of thousands of steps is bound by).  A "lag" of the
+// distribution over waves and workgroups is then a group of LP lags.
+// TILES: G goes straight into the accumulator-tile layout the register-resident cold-solve kernel loads through KParams::gpre
+// (tile (I, J), I >= J, at (I (I + 1) / 2 + J) * 256; double 4 * lane + j = register j of lane (l4, l15) = K[16 J + l4 + 4 j][16 I + l15];
+// diagonal tiles filled on both sides; rows / columns r .. n16 - 1, n16 = 16 NT: zero) in the identity component order (iperm, dmaxbits
+// unused): the structured Gram of plants with other than two or four channels, and of trajectories beyond that kernel's LDS.
+template <bool PACKED, bool TILES>
+__device__ __forceinline__ void rr2_gram_body(const KParams& P, const double* __restrict__ u_d, const double* __restrict__ y_d,
+                                              const int* __restrict__ iperm, double* __restrict__ ws, long long stride,
+                                              int n16, unsigned long long* __restrict__ dmaxbits) {
   __shared__ __attribute__((aligned(16))) double xc[RR2_XCAP];
   __shared__ int ipl[1024];                                                 // component -> row of G (a global load per stored entry
                                                                             // put one memory round trip into every step of the walk)
@@ -101,7 +110,14 @@ __global__ __launch_bounds__(256, 4) void rr2_gram_kernel(KParams P, const doubl
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int m = P.m, p = P.p, nch = P.nch, c = P.c, Ln = P.Ln, r = P.r;
   __shared__ int prl[1024];                                                 // pk_row(i): start of row i of G
-  for (int i = tid; i < r; i += nthr) { ipl[i] = iperm[i]; prl[i] = (int)pk_row((size_t)i); }
+  if constexpr (TILES) {                                                    // entry K[x][y], x <= y, at prl[x] + ipl[y]
+    for (int i = tid; i < n16; i += nthr) {
+      prl[i] = (i >> 4) * 256 + 4 * ((i & 3) * 16) + ((i & 15) >> 2);
+      ipl[i] = ((i >> 4) * ((i >> 4) + 1) / 2) * 256 + 4 * (i & 15);
+    }
+  } else {
+    for (int i = tid; i < r; i += nthr) { ipl[i] = iperm[i]; prl[i] = (int)pk_row((size_t)i); }
+  }
   for (int i = tid; i < RR2_XCAP; i += nthr) xc[i] = 0.0;                   // (masked MFMA terms multiply whatever lies behind a chunk by zero: finite)
   const double* ud = u_d + b * (long long)P.N * m;
   const double* yd = y_d + b * (long long)P.N * p;
@@ -109,22 +125,40 @@ __global__ __launch_bounds__(256, 4) void rr2_gram_kernel(KParams P, const doubl
   const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6;
   const int dg = blockIdx.x * nwave * RR2_SL;
-  const int nat = (nch + 15) >> 4;
+  const int nat = PACKED ? 1 : (nch + 15) >> 4;
+  const int LP = PACKED ? 16 / nch : 1;                                     // lags per tile
+  const int djA = PACKED ? ((l15 / nch < LP) ? l15 / nch : LP - 1) : 0;    // the A-operand row of this lane: lag offset ...
+  int djq[4], aq[4];                                                        // ... and of the accumulator rows l4 + 4q
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    djq[q] = PACKED ? (l4 + 4 * q) / nch : 0;
+    aq[q] = PACKED ? (l4 + 4 * q) - djq[q] * nch : l4 + 4 * q;
+  }
   const int TCH = ((RR2_XCAP / nch) - Ln - 3) & ~3;                        // time steps per chunk next to the lag overlap (+ 3 rows of slack)
   const int nw = Ln - 1;
   double* xh = xc;                                                          // walk: rows 0 .. Ln-2
   double* xt = xc + nw * nch;                                               //       rows c .. c+Ln-2
   double dmx = 0.0;
   if (blockIdx.x == 0) {                                                    // padding rows r .. n16-1: zero (their pivots are skipped)
-    for (int i = r; i < n16; ++i)
-      for (int j = tid; j <= i; j += nthr) G[pk_row(i) + j] = 0.0;
+    if constexpr (TILES) {
+      __syncthreads();                                                      // (the tables)
+      for (int i = r; i < n16; ++i)
+        for (int j = tid; j <= i; j += nthr) {
+          G[prl[j] + ipl[i]] = 0.0;
+          if ((j >> 4) == (i >> 4)) G[prl[i] + ipl[j]] = 0.0;
+        }
+    } else {
+      for (int i = r; i < n16; ++i)
+        for (int j = tid; j <= i; j += nthr) G[pk_row(i) + j] = 0.0;
+    }
   }
   for (int at = 0; at < nat; ++at)
     for (int bt = 0; bt < nat; ++bt) {
       d4 acc[RR2_SL];
 #pragma unroll
       for (int sl = 0; sl < RR2_SL; ++sl) acc[sl] = d4{0.0, 0.0, 0.0, 0.0};
-      const int ca = (16 * at + l15 < nch) ? 16 * at + l15 : nch - 1;       // clamped: entries past nch are not stored
+      const int al = PACKED ? l15 - djA * nch : 16 * at + l15;
+      const int ca = (al < nch) ? al : nch - 1;                             // clamped: entries past nch are not stored
       const int cb = (16 * bt + l15 < nch) ? 16 * bt + l15 : nch - 1;
       // (Staging with all of a thread's 16 loads of a chunk in flight at once, or in two rounds of eight, or issued ahead of
       //  the previous chunk's MFMA loop: 562 / 562 / 710 us against 565 as it stands -- the first two spill 28 - 120 B, the
@@ -139,13 +173,28 @@ __global__ __launch_bounds__(256, 4) void rr2_gram_kernel(KParams P, const doubl
         // lane (l15, l4): B operand x_b[t], A operand x_a[t + d], t = s4 + l4; terms t >= nt are masked by a zero in B (what
         // A reads there -- rows up to nload + 2 -- is finite: the region was zero-filled, later chunks leave older data)
         const double* pb = xc + l4 * nch + cb;
-        const double* pa = xc + (l4 + dg + wave) * nch + ca;
-        const int lstep = nwave * nch;
-        for (int s4 = 0; s4 < nt; s4 += 4) {
-          const double bv = (s4 + l4 < nt) ? pb[s4 * nch] : 0.0;
+        if constexpr (PACKED) {
+          const double* pas[RR2_SL];                                        // (a lane's lag clamped to Ln - 1: inside what was staged)
 #pragma unroll
-          for (int sl = 0; sl < RR2_SL; ++sl)
-            if (dg + wave + nwave * sl < Ln) acc[sl] = rr2_mfma(pa[s4 * nch + sl * lstep], bv, acc[sl]);   // (wave-uniform)
+          for (int sl = 0; sl < RR2_SL; ++sl) {
+            const int dl = LP * (dg + wave + nwave * sl) + djA;
+            pas[sl] = xc + (l4 + (dl < Ln ? dl : Ln - 1)) * nch + ca;
+          }
+          for (int s4 = 0; s4 < nt; s4 += 4) {
+            const double bv = (s4 + l4 < nt) ? pb[s4 * nch] : 0.0;
+#pragma unroll
+            for (int sl = 0; sl < RR2_SL; ++sl)
+              if (LP * (dg + wave + nwave * sl) < Ln) acc[sl] = rr2_mfma(pas[sl][s4 * nch], bv, acc[sl]);   // (wave-uniform)
+          }
+        } else {
+          const double* pa = xc + (l4 + dg + wave) * nch + ca;
+          const int lstep = nwave * nch;
+          for (int s4 = 0; s4 < nt; s4 += 4) {
+            const double bv = (s4 + l4 < nt) ? pb[s4 * nch] : 0.0;
+#pragma unroll
+            for (int sl = 0; sl < RR2_SL; ++sl)
+              if (dg + wave + nwave * sl < Ln) acc[sl] = rr2_mfma(pa[s4 * nch + sl * lstep], bv, acc[sl]);   // (wave-uniform)
+          }
         }
       }
       __syncthreads();
@@ -156,28 +205,61 @@ __global__ __launch_bounds__(256, 4) void rr2_gram_kernel(KParams P, const doubl
       const double sga = (l4 == 0) ? 1.0 : (l4 == 1 ? -1.0 : 0.0), sgb = (l4 < 2) ? 1.0 : 0.0;
 #pragma unroll
       for (int sl = 0; sl < RR2_SL; ++sl) {
-        const int d = dg + wave + nwave * sl;
-        if (d >= Ln) continue;
-        for (int k = 0; k + d < Ln; ++k) {
-          if (k > 0) acc[sl] = rr2_mfma(sga * xsel[(k - 1 + d) * nch + ca], sgb * xsel[(k - 1) * nch + cb], acc[sl]);
+        const int d0 = LP * (dg + wave + nwave * sl);                       // (first) lag of the tile
+        if (d0 >= Ln) continue;
+        for (int k = 0; k + d0 < Ln; ++k) {
+          if (k > 0) {
+            const int ra = k - 1 + d0 + djA;                                // (rows past the walk: entries that are no longer stored)
+            acc[sl] = rr2_mfma(sga * xsel[(ra < nw ? ra : nw - 1) * nch + ca], sgb * xsel[(k - 1) * nch + cb], acc[sl]);
+          }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int a = 16 * at + l4 + 4 * q, bb = 16 * bt + l15;
-            if (a < nch && bb < nch && (d > 0 || a >= bb)) {
-              const int pi = ipl[(k + d) * nch + a], pj = ipl[k * nch + bb];
-              const int hi = pi > pj ? pi : pj, lo = pi > pj ? pj : pi;
-              G[prl[hi] + lo] = acc[sl][q];
-              if (d == 0 && a == bb) dmx = fmax(dmx, acc[sl][q]);
+            const int a = 16 * at + aq[q], bb = 16 * bt + l15, d = d0 + djq[q];
+            if (a < nch && bb < nch && djq[q] < LP && k + d < Ln && (d > 0 || a >= bb)) {
+              if constexpr (TILES) {
+                const int hi = (k + d) * nch + a, lo = k * nch + bb;        // (hi >= lo)
+                G[prl[lo] + ipl[hi]] = acc[sl][q];
+                if ((hi >> 4) == (lo >> 4)) G[prl[hi] + ipl[lo]] = acc[sl][q];
+              } else {
+                const int pi = ipl[(k + d) * nch + a], pj = ipl[k * nch + bb];
+                const int hi = pi > pj ? pi : pj, lo = pi > pj ? pj : pi;
+                G[prl[hi] + lo] = acc[sl][q];
+                if (d == 0 && a == bb) dmx = fmax(dmx, acc[sl][q]);
+              }
             }
           }
         }
       }
     }
-  if (dg + wave == 0) {                                                     // the wave that owns lag 0 has met every diagonal entry
+  if (!TILES && dg + wave == 0) {                                           // the wave that owns lag 0 has met every diagonal entry
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) dmx = fmax(dmx, __shfl_xor(dmx, off, 64));
     if (lane == 0) atomicMax(dmaxbits + 4 * b, (unsigned long long)__double_as_longlong(fmax(dmx, 0.0)));   // (four words per instance)
   }
+}
+__global__ __launch_bounds__(256, 4) void rr2_gram_kernel(KParams P, const double* __restrict__ u_d, const double* __restrict__ y_d,
+                                                       const int* __restrict__ iperm, double* __restrict__ ws, long long stride,
+                                                       int n16, unsigned long long* __restrict__ dmaxbits) {
+  rr2_gram_body<false, false>(P, u_d, y_d, iperm, ws, stride, n16, dmaxbits);
+}
+__global__ __launch_bounds__(256, 4) void rr2_gram_packed_kernel(KParams P, const double* __restrict__ u_d, const double* __restrict__ y_d,
+                                                              const int* __restrict__ iperm, double* __restrict__ ws, long long stride,
+                                                              int n16, unsigned long long* __restrict__ dmaxbits) {
+  rr2_gram_body<true, false>(P, u_d, y_d, iperm, ws, stride, n16, dmaxbits);
+}
+// ... into the tiles of the register-resident cold-solve kernel (n16 = 16 NT <= 1024)
+__global__ __launch_bounds__(256, 4) void rr2_gram_tiles_kernel(KParams P, const double* __restrict__ u_d, const double* __restrict__ y_d,
+                                                             double* __restrict__ gpre, long long gstride, int n16) {
+  rr2_gram_body<false, true>(P, u_d, y_d, nullptr, gpre, gstride, n16, nullptr);
+}
+__global__ __launch_bounds__(256, 4) void rr2_gram_tiles_packed_kernel(KParams P, const double* __restrict__ u_d, const double* __restrict__ y_d,
+                                                                    double* __restrict__ gpre, long long gstride, int n16) {
+  rr2_gram_body<true, true>(P, u_d, y_d, nullptr, gpre, gstride, n16, nullptr);
+}
+// grid.x of the two (a workgroup's four waves own RR2_SL lags -- groups of 16 / nch lags -- each)
+inline unsigned rr2_gram_grid(int Ln, int nch) {
+  const int groups = nch <= 8 ? (Ln + 16 / nch - 1) / (16 / nch) : Ln;
+  return (unsigned)((groups + 4 * RR2_SL - 1) / (4 * RR2_SL));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -759,34 +841,6 @@ __global__ __launch_bounds__(1024) void rr2_cwc_kernel(KParams P, int RPs, const
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) tmx = fmax(tmx, __shfl_xor(tmx, off, 64));
   if (lane == 0 && tmx > 0.0) atomicMax(tmaxbits + 4 * b, (unsigned long long)__double_as_longlong(tmx));   // (four words per instance)
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Packed Gram matrix (rr2_gram_kernel, identity order) -> the accumulator-tile layout the register-resident cold-solve kernel
-// loads through KParams::gpre (tile (I, J), I >= J, at (I (I + 1) / 2 + J) * 256; double 4 * lane + j = register j of lane
-// (l4, l15) = K[16 J + l4 + 4 j][16 I + l15]; diagonal tiles filled on both sides; rows / columns past r: zero).  Used when the
-// trajectory is longer than the cold kernel's LDS holds (hankel_matrix.py:39-51 takes any N >= L): the Gram matrix then comes
-// from the streaming kernel of the phase pipeline instead of the in-kernel structured Gram.  grid = (tiles, batch), 64 threads.
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void rr2_pack_tiles_kernel(const double* __restrict__ ws, long long stride, int r, int NT,
-                                                            double* __restrict__ gpre, long long gstride) {
-  const long long b = blockIdx.y;
-  const int t = blockIdx.x;
-  int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-  while ((I + 1) * (I + 2) / 2 <= t) ++I;
-  while (I * (I + 1) / 2 > t) --I;
-  const int J = t - I * (I + 1) / 2;
-  if (I >= NT) return;
-  const int lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
-  const double* G = ws + b * stride;
-  d4 v;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int a = 16 * J + l4 + 4 * j, c = 16 * I + l15;
-    const int hi = a > c ? a : c, lo = a > c ? c : a;
-    v[j] = (hi < r) ? G[pk_row((size_t)hi) + lo] : 0.0;
-  }
-  *reinterpret_cast<d4*>(gpre + b * gstride + (long long)t * 256 + 4 * lane) = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -256,6 +256,12 @@ class BatchedDDMPC:
         factor (rank-k update), False = every iteration factors the system again (DDMPC_OPT_CONVEX_UPDATE)."""
         L.check(self._lib.ddmpc_set_option(self._h, L.OPT_CONVEX_UPDATE, 1 if on else 0))
 
+    def set_gram_launch(self, kind: str) -> None:
+        """Structured Gram of plants with other than two or four channels on the register-resident kernels: "matrix_pipe"
+        (default: streaming launch, lag sums and window walk by MFMA) or "staged" (round 4's launch with the whole trajectory
+        in LDS) -- DDMPC_OPT_GRAM_LAUNCH."""
+        L.check(self._lib.ddmpc_set_option(self._h, L.OPT_GRAM_LAUNCH, {"matrix_pipe": 0, "staged": 1}[kind]))
+
     def set_large_affine_law(self, on: bool) -> None:
         """NOMINAL controllers beyond the register-resident kernels: `prepare` also forms the affine law z(past) and `step`
         evaluates it (DDMPC_OPT_LARGE_AFFINE_LAW; default off: `step` repeats the solve on the kept factors)."""

@@ -127,6 +127,13 @@ extern "C" {
                                          back substitution); more components, or anything unusual, falls back to 0 = the whole system is
                                          formed and factored again in every iteration (rounds 1-4).  Same active sets, iteration
                                          counts and -- to rounding -- solutions */
+#define DDMPC_OPT_GRAM_LAUNCH 9        /* register-resident kernels, structured Gram of plants with other than two or four channels
+                                         (hankel_matrix.py:5-53): which launch ahead of the solve forms the Gram tiles.  0 = the
+                                         streaming matrix-pipe kernel (trajectory in chunks, several lags per tile for at most eight
+                                         channels; the default from six channels on, and what trajectories beyond the LDS take), 1 = the
+                                         launch of round 4 that stages the whole trajectory and walks on the vector units (the default
+                                         up to five channels).  Same tiles to rounding; DDMPC_ERR_UNSUPPORTED when the requested launch
+                                         cannot hold the shape */
 #define DDMPC_REFINE_RES_DEFAULT 107  /* 2e-11: benchmark data stays below ~2e-12, the parity bars are missed from ~1.3e-10 on */
 
 typedef struct ddmpc_handle ddmpc_handle;

@@ -276,8 +276,8 @@ def test_results_do_not_depend_on_what_the_allocator_hands_back():
 @pytest.mark.parametrize("m,p", [(1, 1), (2, 1), (1, 2), (3, 2), (2, 3), (3, 3), (4, 4), (5, 3)])
 def test_structured_gram_for_any_channel_count(m, p):
     """hankel_matrix.py:5-53 is generic in the channel count, and so is the Hankel-structured Gram now: for m + p != 4 the
-    register-resident kernels take G = H H' from ddmpc_gram_tiles_kernel (first rows by MFMA, the rest by the sliding-window
-    recurrence) instead of the dense r^2 c product.  Both Gram modes against the full-space oracle and against each other,
+    register-resident kernels take G = H H' from a launch ahead of them (ddmpc_gram_tiles_kernel: first rows by MFMA, the rest by
+    the sliding-window recurrence; round 5: rr2_gram_tiles*_kernel) instead of the dense r^2 c product.  Both Gram modes against the full-space oracle and against each other,
     ROBUST with the slack box (active-set iterations reload the tiles) and without, through ddmpc_solve, the chunked
     ddmpc_solve_from_host and ddmpc_prepare / ddmpc_step."""
     from direct_data_driven_mpc_amd.harness import generate_batch
@@ -321,6 +321,20 @@ def test_structured_gram_for_any_channel_count(m, p):
         assert np.max(np.abs(dn[0] - st[0])) <= 1e-9 * np.max(np.abs(dn[0]))
         assert np.array_equal(res[L.GRAM_AUTO][0], st[0])                      # AUTO is the structured Gram for every channel count
         assert dn[4] > 1.5 * st[4]                                             # the dense Gram is charged r^2 c flops
+        if nch not in (2, 4):
+            # both launches that can form the tiles ahead of the kernel (DDMPC_OPT_GRAM_LAUNCH; round 5: the streaming
+            # matrix-pipe launch with several lags per tile, the default from six channels on)
+            for launch in ("matrix_pipe", "staged"):
+                with BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=2.0, R=0.05, u_s=spec.u_s, y_s=spec.y_s, batch=B, controller_type=L.ROBUST,
+                                  slack_type=L.SLACK_CONVEX if slack == "convex" else L.SLACK_NONE, eps_max=0.002, lamb_alpha=20.0,
+                                  lamb_sigma=500.0, c=1.0, gram_mode=L.GRAM_STRUCTURED) as eng:
+                    eng.set_refinement("always")
+                    eng.set_gram_launch(launch)
+                    eng.set_data(d["u_d"], d["y_d"])
+                    u2, cost2, status2, iters2 = eng.solve(up, yp)
+                assert np.array_equal(iters2, st[3]) and np.array_equal(status2, st[2]), launch
+                assert np.max(np.abs(u2 - st[0])) <= 1e-9 * np.max(np.abs(st[0])), launch
+                assert np.max(np.abs(cost2 - st[1]) / np.abs(st[1])) <= 1e-9, launch
 
 
 @pytest.mark.gpu

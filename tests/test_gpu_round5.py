@@ -378,3 +378,63 @@ def test_trajectories_beyond_the_lds(gpu, N, slack):
         ref_u, ref_c, ref_it = red["optimal_u"], red["cost"], red["iters"]
     assert int(iters[0]) == ref_it
     assert np.max(np.abs(u[0] - ref_u)) / np.max(np.abs(ref_u)) < TOL_U and abs(cost[0] - ref_c) / abs(ref_c) < TOL_COST
+
+
+# ------------------------------------------------------------------ phase pipelines: several lags per matrix tile
+@pytest.mark.parametrize("m,p", [(1, 1), (1, 2), (2, 3), (3, 3), (3, 4), (4, 4)])
+def test_robust_phase_pipeline_gram_with_several_lags_per_tile(gpu, m, p):
+    """hankel_matrix.py:5-53 through controller.py:506-538 on the phase kernels (more than 271 rows).  Plants of at most eight
+    channels take rr2_gram_packed_kernel -- 16 / (m + p) lags in the rows of one matrix tile, with rows left over when the channel
+    count does not divide 16: channel counts two to eight of the ROBUST scheme with the slack box against the full-space oracle."""
+    rng = np.random.default_rng(1200 + 10 * m + p)
+    n = 2
+    nch = m + p
+    Lh = 300 // nch                                       # r = nch (Lh + n) > 271 rows
+    N = (m + 1) * (Lh + 2 * n) + 90
+    A = rng.normal(size=(n, n)); A *= 0.8 / max(abs(np.linalg.eigvals(A)))
+    plant = dict(A=A, B=rng.normal(size=(n, m)), C=rng.normal(size=(p, n)), D=np.zeros((p, m)), eps_max=0.002)
+    B = 3
+    d = harness.generate_batch(range(B), N=N, plant=plant)
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    spec = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=2.0 * np.eye(p * Lh), R=0.05 * np.eye(m * Lh), u_s=rng.uniform(-0.3, 0.3, m),
+                      y_s=rng.uniform(-0.3, 0.3, p), robust=True, eps_max=0.002, lamb_alpha=20.0, lamb_sigma=500.0, c=1.0,
+                      slack="convex", tec=True)
+    with _spec_engine(spec, N, B) as eng:
+        assert nch * (Lh + n) > 271 and "large" in eng.kernel_name()
+        eng.set_refinement("always")
+        eng.set_data(d["u_d"], d["y_d"])
+        u, cost, status, iters = (x.copy() for x in eng.solve(up, yp))
+    for b in range(B):
+        sol = orc.solve_fullspace(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
+        assert L.STATUS_STRINGS[int(status[b])] == sol.status == "optimal"
+        assert np.max(np.abs(u[b] - sol.optimal_u)) / max(np.max(np.abs(sol.optimal_u)), 1e-3) < TOL_U, b
+        assert abs(cost[b] - sol.cost) <= TOL_COST * max(abs(sol.cost), 1e-6), b
+
+
+@pytest.mark.parametrize("shape,seed", [((1, 2, 3, 100, 700), 31), ((3, 3, 3, 50, 900), 32), ((3, 4, 4, 40, 900), 33), ((4, 4, 4, 36, 900), 34)],
+                         ids=["3ch", "6ch", "7ch", "8ch"])
+def test_nominal_phase_pipeline_gram_with_several_lags_per_tile(gpu, shape, seed):
+    """The same for the NOMINAL scheme on exact data (rank-revealing factorisation of the packed Gram matrix): the phase kernels
+    against the model-based solution of the QP and against the one-workgroup kernels, which form their Gram matrix themselves
+    (channel counts 2, 4, 5 and 9: tests/test_gpu_round4.py)."""
+    from oracle.nominal_exact import solve_nominal_model_based_batch
+    from test_gpu_round4 import _exact_plant_case
+    m, p, n, Lh, N = shape
+    B = 3
+    spec, plant, d, up, yp = _exact_plant_case(seed, m, p, n, Lh, N, B)
+    u_ref, c_ref, feas = solve_nominal_model_based_batch(spec, plant, up, yp)
+    assert np.max(feas) < 1e-10
+    res = {}
+    for mode in ("phases", "one_workgroup"):
+        with _spec_engine(spec, N, B) as eng:
+            assert (m + p) * (Lh + n) > 271 and "nominal_rr" in eng.kernel_name()
+            eng.set_large_pipeline(mode)
+            eng.set_data(d["u_d"], d["y_d"])
+            res[mode] = tuple(x.copy() for x in eng.solve(up, yp))
+    u, c, st, it = res["phases"]
+    assert np.all(st == 0), st
+    eu = np.max(np.max(np.abs(u - u_ref), axis=1) / np.max(np.abs(u_ref), axis=1))
+    ec = np.max(np.abs(c - c_ref) / np.abs(c_ref))
+    assert eu < TOL_U and ec < TOL_COST, (eu, ec)
+    a, bq = res["phases"], res["one_workgroup"]
+    assert np.max(np.abs(a[0] - bq[0])) < 1e-7 * np.max(np.abs(bq[0]))
