@@ -876,10 +876,11 @@ static int launch_rr3_solve(ddmpc_handle* h, const KParams& kq, const double* up
     const size_t nB = kq.convex ? (size_t)h->prm.p * h->prm.L : 0;
     const size_t nlag = (size_t)kq.Ln * kq.nch * kq.nch, sb = 2 * pk_size(nB);
     const size_t stride = (npk + (nlag > sb ? nlag : sb) + 15) & ~(size_t)15;
-    if ((rc = h->d_rr_fb.ensure(B * stride * sizeof(double))) || (rc = h->d_rrmeta_fb.ensure(B * sizeof(int)))) return rc;
+    const size_t nfb = B < 8 ? B : 8;                       // (one slice of workspace per workgroup of the fall-back grid)
+    if ((rc = h->d_rr_fb.ensure(nfb * stride * sizeof(double))) || (rc = h->d_rrmeta_fb.ensure(nfb * sizeof(int)))) return rc;
     const size_t flds = 6 * rvv * sizeof(double) + 4 * rvv * sizeof(int) + (size_t)PSD_PAN * sizeof(double);
     if (flds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_large_solve_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-    hipLaunchKernelGGL(ddmpc_large_solve_kernel<0>, dim3((unsigned)(B < 8 ? B : 8)), dim3(large_threads(rr)), flds, h->stream, kq, RPs, h->ud, h->yd, up, yp, uo,
+    hipLaunchKernelGGL(ddmpc_large_solve_kernel<0>, dim3((unsigned)nfb), dim3(large_threads(rr)), flds, h->stream, kq, RPs, h->ud, h->yd, up, yp, uo,
                        cost, (int*)status, (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, (double*)h->d_rr_fb.p, (long long)stride,
                        (int*)h->d_rrmeta_fb.p, 5, (long long)B);
     HIP_TRY(hipGetLastError());

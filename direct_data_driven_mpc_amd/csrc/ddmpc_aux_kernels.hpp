@@ -2178,7 +2178,8 @@ __device__ __forceinline__ void ddmpc_large_solve_body(const KParams& P, int RPs
                                                        int* __restrict__ status, int* __restrict__ iters,
                                                        double* __restrict__ beta_ws,
                                                        signed char* __restrict__ act_ws, double* scratch,
-                                                       long long scratch_stride, int* __restrict__ meta_ws, const long long b) {
+                                                       long long scratch_stride, int* __restrict__ meta_ws, const long long b,
+                                                       const long long slot) {      // slot: which slice of scratch / word of meta_ws
   extern __shared__ __attribute__((aligned(16))) double lsm_lds[];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int r = P.r, m = P.m, p = P.p;
@@ -2197,7 +2198,7 @@ __device__ __forceinline__ void ddmpc_large_solve_body(const KParams& P, int RPs
   int* iperm = perm + rv;                               // component -> position
   double* pan = reinterpret_cast<double*>(iperm + rv);
   const int npk = pk_row(r);
-  double* G = scratch + b * scratch_stride;             // Gram -> [L_AA; L_BA] in its first nA columns
+  double* G = scratch + slot * scratch_stride;          // Gram -> [L_AA; L_BA] in its first nA columns
   __shared__ double red[16];
   __shared__ int flag[1];
   __shared__ int cnt[2];
@@ -2259,10 +2260,10 @@ __device__ __forceinline__ void ddmpc_large_solve_body(const KParams& P, int RPs
   __syncthreads();
   // S = K_BB - L_BA L_BA'  (the diagonal shift of B is added per active set)
   if (st == 0) packed_schur_mfma(G, nA, nB, nA, S);
-  if (tid == 0) meta_ws[b] = st;                        // (a whole solve leaves the same record behind as MODE 1)
+  if (tid == 0) meta_ws[slot] = st;                        // (a whole solve leaves the same record behind as MODE 1)
   if constexpr (MODE == 1) return;
   } else {
-    st = meta_ws[b];                                    // uniform: how the factorisation of the A columns went
+    st = meta_ws[slot];                                    // uniform: how the factorisation of the A columns went
   }
   if (st == 0) {
     // L_AA y_A = t_A (t_A does not depend on the active set), zb = L_BA y_A
@@ -2429,13 +2430,13 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
                                                                 long long nbatch) {
   if (only_status == 0) {
     ddmpc_large_solve_body<MODE>(P, RPs, u_d, y_d, u_past, y_past, u_opt, cost, status, iters, beta_ws, act_ws, scratch, scratch_stride,
-                                 meta_ws, (long long)blockIdx.x);
+                                 meta_ws, (long long)blockIdx.x, (long long)blockIdx.x);
     return;
   }
   for (long long b = blockIdx.x; b < nbatch; b += gridDim.x) {
     if (status[b] == only_status)                                  // (workgroup-uniform)
       ddmpc_large_solve_body<MODE>(P, RPs, u_d, y_d, u_past, y_past, u_opt, cost, status, iters, beta_ws, act_ws, scratch, scratch_stride,
-                                   meta_ws, b);
+                                   meta_ws, b, (long long)blockIdx.x);     // (a workspace slice per WORKGROUP of the small grid)
     __syncthreads();                                               // LDS is reused by the next instance
   }
 }
