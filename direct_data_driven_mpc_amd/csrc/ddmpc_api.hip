@@ -10,8 +10,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace ddmpc;
@@ -121,6 +124,23 @@ const KernelChoice kKernels[] = {
 #undef DDMPC_INSTANCE
 };
 
+// Dynamic LDS beyond 64 KB is a per-function limit that has to be raised before the launch.  The limit is a property of the
+// function, not of a handle: it is only ever RAISED here (a second controller with a smaller footprint must not lower it under
+// the first one's launches), per device, behind a lock.
+static hipError_t raise_lds_limit(const void* fn, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> limit;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& cur = limit[std::make_pair(fn, dev)];
+  if (bytes <= cur) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) cur = bytes;
+  return e;
+}
+
 // LDS doubles of a launch: the compile-time carve-up of the instance (Lds2<NT, W>::total) -- the same struct the kernel
 // takes its offsets from.
 size_t lds_doubles_for(const KernelChoice& kc, int xs_len) { return ((size_t)kc.lds_fixed + (size_t)xs_len + 1) & ~(size_t)1; }
@@ -169,6 +189,8 @@ struct ddmpc_handle {
   bool gram_pre = false, gpre_valid = false;
   int gram_launch = 0;                     // DDMPC_OPT_GRAM_LAUNCH: 0 streaming matrix-pipe kernel (rr2_gram_tiles*_kernel), 1 ddmpc_gram_tiles_kernel
   bool gram_stream_ok = false, gram_valu_ok = false;      // which of the two can serve this shape
+  int ld_window = 0;                       // long_data: doubles of the trajectory window the refining variant stages chunk by chunk
+  size_t ld_lds_bytes = 0;                 // ... and the LDS of such a launch
   bool long_data = false;                  // the trajectory does not fit the cold kernel's LDS: streaming Gram + gpre, no refinement (KParams::stage_xs = 0)
   DevBuf d_rr2tol, d_rr2rank;              // ... per-instance pivot tolerance and [flag, accepted pivots] of the rank decision (+ one counter word)
   DevBuf d_rr2cand;                        // ... the pivot candidates of G's factorisation as they were met (Rr2Chol::cand)
@@ -594,6 +616,10 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
     k.xs_len = 2;
     k.gram_dense = 0;
     h->lds_bytes = lds_doubles_for(h->kc, k.xs_len) * sizeof(double);
+    // the refining variant passes the trajectory through a window of ~2048 doubles + the L + n rows of overlap, chunk by chunk
+    const int wcols = (2048 / k.nch) > 64 ? (2048 / k.nch) : 64;
+    h->ld_window = ((wcols + k.Ln - 1) * k.nch + 1) & ~1;
+    h->ld_lds_bytes = lds_doubles_for(h->kc, h->ld_window) * sizeof(double);
   }
   // Structured Gram ahead of the kernel for plants of other than two or four channels: the streaming matrix-pipe launch
   // (rr2_gram_tiles*_kernel: a chunk of its LDS must hold four time steps next to the L + n of overlap) or the launch that stages
@@ -631,12 +657,16 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
   }
   h->own_stream = true;
   if (h->lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(h->kc.fn2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+    hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(h->kc.fn2), h->lds_bytes);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(h->kc.fn2r), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+      e = raise_lds_limit(reinterpret_cast<const void*>(h->kc.fn2r), h->lds_bytes);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(h->kc.fn2c), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+      e = raise_lds_limit(reinterpret_cast<const void*>(h->kc.fn2c), h->lds_bytes);
     if (e != hipSuccess) { ddmpc_destroy(h); return fail(DDMPC_ERR_HIP, "hipFuncSetAttribute(LDS=%zu) failed: %s", h->lds_bytes, hipGetErrorString(e)); }
+  }
+  if (h->ld_lds_bytes > 64 * 1024) {
+    hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(h->kc.fn2r), h->ld_lds_bytes);
+    if (e != hipSuccess) { ddmpc_destroy(h); return fail(DDMPC_ERR_HIP, "hipFuncSetAttribute(LDS=%zu) failed: %s", h->ld_lds_bytes, hipGetErrorString(e)); }
   }
   int rc = upload_params(h);
   if (rc) { ddmpc_destroy(h); return rc; }
@@ -769,7 +799,7 @@ static int gram_pre_launch(ddmpc_handle* h, KParams& kq, const double* ud, const
     return DDMPC_OK;
   }
   const size_t lds = gram_tiles_lds_doubles(h->kp.xs_len, h->kp.r, h->kp.nch, NT) * sizeof(double);
-  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_gram_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (lds > 64 * 1024) HIP_TRY(raise_lds_limit((const void*)ddmpc_gram_tiles_kernel, lds));
   hipLaunchKernelGGL(ddmpc_gram_tiles_kernel, dim3((unsigned)nb), dim3(256), lds, h->stream, h->kp, NT, ud, yd,
                      (double*)h->d_gpre.p + (long long)b0 * stride, stride);
   HIP_TRY(hipGetLastError());
@@ -843,8 +873,8 @@ static int launch_rr3_solve(ddmpc_handle* h, const KParams& kq, const double* up
   const int RPs = 16 * h->kc.NT;
   const bool refine = kq.refine != DDMPC_REFINE_OFF && kq.lam != 0.0;
   if (lds > 64 * 1024) {
-    HIP_TRY(hipFuncSetAttribute((const void*)rr3_solve_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)rr3_solve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(raise_lds_limit((const void*)rr3_solve_kernel<false>, lds));
+    HIP_TRY(raise_lds_limit((const void*)rr3_solve_kernel<true>, lds));
   }
   hipLaunchKernelGGL(rr3_solve_kernel<false>, dim3((unsigned)B), dim3(RR2_TS), lds, h->stream, S, kq, RPs, up, yp, uo, cost, (int*)status,
                      (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, refine ? 1 : 0);
@@ -861,7 +891,7 @@ static int launch_rr3_solve(ddmpc_handle* h, const KParams& kq, const double* up
         if ((G.cg >= 64 || ng == 1) && bytes <= 80 * 1024 && G.ntA <= 8 && G.ntZ <= 8) { hk_ng = ng; hk_lds = bytes; }
       }
       if (hk_ng && hk_lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)rr2_hankel_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hk_lds));
+        HIP_TRY(raise_lds_limit((const void*)rr2_hankel_mfma_kernel, hk_lds));
     }
     if (hk_ng) hipLaunchKernelGGL(rr2_hankel_mfma_kernel, dim3((unsigned)RR2_NG, (unsigned)B), dim3(512), hk_lds, h->stream, H, kq, h->ud, h->yd, (int)R3_X, 0, hk_ng);
     else hipLaunchKernelGGL(rr2_hankel_kernel, dim3(RR2_NG, (unsigned)B), dim3(512), 0, h->stream, H, kq, h->ud, h->yd, (int)R3_X, 0);
@@ -879,7 +909,7 @@ static int launch_rr3_solve(ddmpc_handle* h, const KParams& kq, const double* up
     const size_t nfb = B < 8 ? B : 8;                       // (one slice of workspace per workgroup of the fall-back grid)
     if ((rc = h->d_rr_fb.ensure(nfb * stride * sizeof(double))) || (rc = h->d_rrmeta_fb.ensure(nfb * sizeof(int)))) return rc;
     const size_t flds = 6 * rvv * sizeof(double) + 4 * rvv * sizeof(int) + (size_t)PSD_PAN * sizeof(double);
-    if (flds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_large_solve_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+    if (flds > 64 * 1024) HIP_TRY(raise_lds_limit((const void*)ddmpc_large_solve_kernel<0>, flds));
     hipLaunchKernelGGL(ddmpc_large_solve_kernel<0>, dim3((unsigned)nfb), dim3(large_threads(rr)), flds, h->stream, kq, RPs, h->ud, h->yd, up, yp, uo,
                        cost, (int*)status, (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, (double*)h->d_rr_fb.p, (long long)stride,
                        (int*)h->d_rrmeta_fb.p, 5, (long long)B);
@@ -890,8 +920,8 @@ static int launch_rr3_solve(ddmpc_handle* h, const KParams& kq, const double* up
 
 // Trajectories beyond the LDS (h->long_data), AUTO refinement: the plain kernel flagged what its a-priori bound could not dismiss;
 // H (H' beta) of the whole batch by the streaming Hankel kernel of the phase pipeline, then the residual decides per flagged
-// instance whether it is reported "optimal_inaccurate" (there is no refining variant without the trajectory on chip).
-static int long_data_residual_check(ddmpc_handle* h, const KParams& kq, const int* flags, const double* ud, const double* yd, const double* up,
+// instance whether the flag stays (the caller launches the refining variant on what is still flagged).
+static int long_data_residual_check(ddmpc_handle* h, const KParams& kq, int* flags, const double* ud, const double* yd, const double* up,
                                     const double* yp, const double* beta, const signed char* act, int* status, size_t nb) {
   const int r = kq.r, VL = (r + 63) & ~63;
   int rc;
@@ -907,7 +937,7 @@ static int long_data_residual_check(ddmpc_handle* h, const KParams& kq, const in
       if ((G.cg >= 64 || ng == 1) && bytes <= 80 * 1024 && G.ntA <= 8 && G.ntZ <= 8) { hk_ng = ng; hk_lds = bytes; }
     }
     if (hk_ng && hk_lds > 64 * 1024)
-      HIP_TRY(hipFuncSetAttribute((const void*)rr2_hankel_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hk_lds));
+      HIP_TRY(raise_lds_limit((const void*)rr2_hankel_mfma_kernel, hk_lds));
   }
   if (hk_ng) hipLaunchKernelGGL(rr2_hankel_mfma_kernel, dim3((unsigned)RR2_NG, (unsigned)nb), dim3(512), hk_lds, h->stream, H, kq, ud, yd, 0, 0, hk_ng);
   else hipLaunchKernelGGL(rr2_hankel_kernel, dim3(RR2_NG, (unsigned)nb), dim3(512), 0, h->stream, H, kq, ud, yd, 0, 0);
@@ -947,7 +977,7 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
     if (lds + 1024 > 160 * 1024) return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: %zu rows", r);
     if ((rc = h->d_rrmeta.ensure((size_t)h->batch * sizeof(int)))) return rc;
     auto launch = [&](auto fn) -> int {
-      if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (lds > 64 * 1024) HIP_TRY(raise_lds_limit((const void*)fn, lds));
       hipLaunchKernelGGL(fn, dim3((unsigned)h->batch), dim3(large_threads(r)), lds, h->stream,
                          kp_override ? *kp_override : h->kp, 16 * h->kc.NT, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                          (int*)iters, (double*)h->d_beta.p, (signed char*)h->d_act.p, (double*)h->d_rr.p, (long long)stride,
@@ -980,10 +1010,12 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
   // controllers with the slack box: the plain variant that keeps the first factor across active-set iterations (rank-k update);
   // DDMPC_OPT_CONVEX_UPDATE = 0 selects the variant that factors again in every iteration (the refining variant always does)
   const cold_kernel2_t plain = (kq.convex && h->convex_update) ? h->kc.fn2c : h->kc.fn2;
-  if (mode == DDMPC_REFINE_ALWAYS && h->long_data)
-    return fail(DDMPC_ERR_UNSUPPORTED, "DDMPC_REFINE_ALWAYS needs the trajectory in LDS: not available for N = %d at this problem size", h->prm.N);
+  // the refining variant on a trajectory beyond the LDS: a window of the trajectory instead of the whole of it (ddmpc_cold2.hpp)
+  KParams kref = kq;
+  size_t ref_lds = h->lds_bytes;
+  if (h->long_data) { kref.xs_len = h->ld_window; ref_lds = h->ld_lds_bytes; }
   if (mode == DDMPC_REFINE_ALWAYS) {
-    hipLaunchKernelGGL(h->kc.fn2r, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
+    hipLaunchKernelGGL(h->kc.fn2r, grid, block, ref_lds, h->stream, kref, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                        (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, only, 0LL, (int*)nullptr);
   } else if (mode == DDMPC_REFINE_AUTO) {
     // flags [batch] + one counter word behind them (the largest stamp that flagged anything)
@@ -996,16 +1028,14 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
     hipLaunchKernelGGL(plain, grid, block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                        (int*)iters, bws, aws, stp, lfac, lfacT, (int*)h->d_rflag.p, only, 0LL, rcount);
     HIP_TRY(hipGetLastError());
-    if (h->long_data) {
-      // no refining variant without the trajectory on chip: what neither the a-priori bound nor the streamed residual clears is
-      // reported "optimal_inaccurate", not hidden
-      if ((rc = long_data_residual_check(h, kq, (const int*)h->d_rflag.p, h->ud, h->yd, up, yp, bws, aws, (int*)status, (size_t)h->batch))) return rc;
-    } else {
-    kq.refine = DDMPC_REFINE_ALWAYS;
+    // (trajectory beyond the LDS: the exact residual check the plain kernel could not run, streamed; it clears the flags it can)
+    if (h->long_data && (rc = long_data_residual_check(h, kq, (int*)h->d_rflag.p, h->ud, h->yd, up, yp, bws, aws, (int*)status, (size_t)h->batch)))
+      return rc;
+    kref.refine = DDMPC_REFINE_ALWAYS;
+    kref.epoch = kq.epoch;
     const unsigned pg = (unsigned)(h->batch < 768 ? h->batch : 768);       // persistent grid, 3 workgroups per CU
-    hipLaunchKernelGGL(h->kc.fn2r, dim3(pg), block, h->lds_bytes, h->stream, kq, h->ud, h->yd, up, yp, uo, cost, (int*)status,
+    hipLaunchKernelGGL(h->kc.fn2r, dim3(pg), block, ref_lds, h->stream, kref, h->ud, h->yd, up, yp, uo, cost, (int*)status,
                        (int*)iters, bws, aws, stp, lfac, lfacT, (int*)nullptr, (const int*)h->d_rflag.p, (long long)h->batch, rcount);
-    }
     h->flag_epoch = kq.epoch;                   // the flags now carry this stamp
   } else {
     // factor export for ddmpc_prepare under AUTO: the plain kernel still records which instances AUTO would refine
@@ -1098,7 +1128,7 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
   // pivots of dependent rows come out as rounding residue up to ~3e-10, genuine ones are >= ~5e-7 on exact
   // four-tank data (L = 10 .. 60)
   auto launch = [&](auto fn) -> int {
-    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) HIP_TRY(raise_lds_limit((const void*)fn, lds));
     hipLaunchKernelGGL(fn, dim3((unsigned)h->batch), dim3(large_threads(r)), lds, h->stream, h->kp, 16 * h->kc.NT,
                        h->ud, h->yd, up, yp, uo, cost, (int*)status, (int*)iters, 1e-8, 1e-7, scratch, (long long)ndbl,
                        (double*)h->d_alpha.p,
@@ -1200,7 +1230,7 @@ static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, 
     const int ldw = ((nR16 + 31) / 32) * 32 + 16;                         // LDS row of the C'WC kernel: 16 mod 32 doubles
     const size_t cwlds = ((size_t)16 * ldw + 16) * sizeof(double);
     if (cwlds > 64 * 1024)
-      HIP_TRY(hipFuncSetAttribute((const void*)rr2_cwc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cwlds));
+      HIP_TRY(raise_lds_limit((const void*)rr2_cwc_kernel, cwlds));
     hipLaunchKernelGGL(rr2_cwc_kernel, dim3((unsigned)B), dim3(1024), cwlds, h->stream, k, 16 * h->kc.NT, perm, scratch, ndbl,
                        (long long)pk_size((size_t)n16), (const int*)meta, mstride, rv, nF, nR, dd + 1, ldw);
     Rr2Chol FT{};
@@ -1264,7 +1294,7 @@ static int rr2_solve_sequence(ddmpc_handle* h, const Rr2Solve& S, unsigned B, co
       if ((G.cg >= 64 || ng == 1) && bytes <= 80 * 1024 && G.ntA <= 8 && G.ntZ <= 8) { hk_ng = ng; hk_lds = bytes; }
     }
     if (hk_ng && hk_lds > 64 * 1024)
-      HIP_TRY(hipFuncSetAttribute((const void*)rr2_hankel_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hk_lds));
+      HIP_TRY(raise_lds_limit((const void*)rr2_hankel_mfma_kernel, hk_lds));
   }
   auto hankel = [&](int slot, int pass) {
     // (RR2_NG workgroups per instance whatever hk_ng is: the consumers sum RR2_NG partial results, and a workgroup past the
@@ -1490,8 +1520,6 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
   // that need it and one filtered launch of the refining variant follows the last chunk
   const bool refinable = h->kp.lam != 0.0;
   const bool always = refinable && h->kp.refine == DDMPC_REFINE_ALWAYS;
-  if (always && h->long_data)
-    return fail(DDMPC_ERR_UNSUPPORTED, "DDMPC_REFINE_ALWAYS needs the trajectory in LDS: not available for N = %d at this problem size", h->prm.N);
   int* rflag = nullptr;
   if (refinable && h->kp.refine == DDMPC_REFINE_AUTO) {
     const bool fresh = h->d_rflag.bytes < (B + 1) * sizeof(int);
@@ -1520,8 +1548,9 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
     }
     KParams kck = kchunk;
     if ((rcl = gram_pre_launch(h, kck, (const double*)(dud + b0 * su), (const double*)(dyd + b0 * sy), nb, b0, false))) break;
+    if (always && h->long_data) kck.xs_len = h->ld_window;            // (the refining variant's trajectory window)
     hipLaunchKernelGGL(always ? h->kc.fn2r : ((h->kp.convex && h->convex_update) ? h->kc.fn2c : h->kc.fn2), dim3((unsigned)nb), dim3(64 * h->kc.W),
-                       h->lds_bytes, h->stream, kck,
+                       (always && h->long_data) ? h->ld_lds_bytes : h->lds_bytes, h->stream, kck,
                        (const double*)(dud + b0 * su), (const double*)(dyd + b0 * sy), (const double*)(dup + b0 * sup),
                        (const double*)(dyp + b0 * syp), duo + b0 * suo, dco + b0, (int*)(dst + b0), (int*)(dit + b0),
                        lbeta ? lbeta + b0 * h->kp.rE : (double*)nullptr, lact ? lact + b0 * h->kp.rE : (signed char*)nullptr,
@@ -1534,14 +1563,14 @@ int ddmpc_solve_from_host(ddmpc_handle* h, const double* u_d, const double* y_d,
     h->ud = dud; h->yd = dyd;
     rcl = gram_pre_launch(h, kchunk, dud, dyd, B, 0, true);
   }
-  if (rcl == DDMPC_OK && rflag && h->long_data) {
-    rcl = long_data_residual_check(h, kchunk, (const int*)rflag, dud, dyd, dup, dyp, (const double*)h->d_beta.p, (const signed char*)h->d_act.p,
+  if (rcl == DDMPC_OK && rflag && h->long_data)
+    rcl = long_data_residual_check(h, kchunk, rflag, dud, dyd, dup, dyp, (const double*)h->d_beta.p, (const signed char*)h->d_act.p,
                                    (int*)dst, B);
-  } else
   if (rcl == DDMPC_OK && rflag) {
     KParams kq = kchunk;
     kq.refine = DDMPC_REFINE_ALWAYS;
-    hipLaunchKernelGGL(h->kc.fn2r, dim3((unsigned)(B < 768 ? B : 768)), dim3(64 * h->kc.W), h->lds_bytes, h->stream, kq,
+    if (h->long_data) kq.xs_len = h->ld_window;
+    hipLaunchKernelGGL(h->kc.fn2r, dim3((unsigned)(B < 768 ? B : 768)), dim3(64 * h->kc.W), h->long_data ? h->ld_lds_bytes : h->lds_bytes, h->stream, kq,
                        (const double*)dud, (const double*)dyd, (const double*)dup, (const double*)dyp, duo, dco, (int*)dst, (int*)dit,
                        (double*)nullptr, (signed char*)nullptr, (unsigned long long*)nullptr, (double*)nullptr, (double*)nullptr,
                        (int*)nullptr, (const int*)rflag, (long long)B, rflag + B);
@@ -1653,7 +1682,7 @@ int ddmpc_prepare(ddmpc_handle* h) {
   if (!launched && NT == NT_) {                                                                               \
     const size_t glds = (size_t)(2 * NT_ * 256 + 32) * sizeof(double);                                        \
     if (glds > 64 * 1024)                                                                                     \
-      HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_gain_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds)); \
+      HIP_TRY(raise_lds_limit((const void*)ddmpc_gain_kernel<NT_>, glds)); \
     hipLaunchKernelGGL(ddmpc_gain_kernel<NT_>, dim3((unsigned)B), dim3(256), glds, h->stream, k, 16 * NT, nf, \
                        (const double*)h->d_lfac.p, (const double*)h->d_lfacT.p, (const double*)h->d_beta.p,  \
                        (double*)h->d_gain.p);                                                                 \
@@ -1946,7 +1975,7 @@ int ddmpc_pe_guard(const double* u_d, int64_t batch, int32_t N, int32_t m, int32
     lds = 0;
   }
   if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void*)ddmpc_pe_guard_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(raise_lds_limit((const void*)ddmpc_pe_guard_kernel, lds));
   hipError_t e = hipSuccess;
   double *dX = nullptr, *dR = nullptr;
   const size_t nx = (size_t)batch * N * m * sizeof(double);

@@ -463,17 +463,22 @@ __global__ void ddmpc_or_flags_kernel(long long batch, int epoch, const int* __r
   flags[b] = epoch;
   atomicMax(flags + batch, epoch);
 }
-// Trajectories beyond the LDS (KParams::stage_xs = 0): the refining variant is not available, so an instance the plain kernel
-// flagged -- its a-priori residual bound did not dismiss it and the exact check could not run -- is reported "optimal_inaccurate".
-// ... unless the exact-Hankel residual, formed by a streaming launch (H (H' beta) from global memory: `zp`, RR2-style partial sums
-// [batch][ng][VL], component order), says the solve is fine:  res = |t - (H (H' beta) + lam D beta)|_inf / |t|_inf <= refine_res
-// clears the flag.  One workgroup per instance; only flagged instances are looked at.
-__global__ __launch_bounds__(256) void ddmpc_flag_inaccurate_kernel(KParams P, int RPs, int epoch, const int* __restrict__ flags,
+// Trajectories beyond the LDS (KParams::stage_xs = 0): the plain kernel cannot run its exact residual check, it flags every
+// instance its a-priori residual bound does not dismiss.  Here the check is made up for with the exact-Hankel residual formed by a
+// streaming launch (H (H' beta) from global memory: `zp`, RR2-style partial sums [batch][ng][VL], component order):
+//   res = |t - (H (H' beta) + lam D beta)|_inf / |t|_inf <= refine_res   clears the flag;
+// what stays flagged is solved again by the refining variant (windowed trajectory, ddmpc_cold2.hpp).  One workgroup per
+// instance; only flagged instances are looked at.
+__global__ __launch_bounds__(256) void ddmpc_flag_inaccurate_kernel(KParams P, int RPs, int epoch, int* __restrict__ flags,
                                                                     const double* __restrict__ u_past, const double* __restrict__ y_past,
                                                                     const double* __restrict__ beta, const signed char* __restrict__ act,
                                                                     const double* __restrict__ zp, int ng, int VL, int* __restrict__ status) {
   const long long b = blockIdx.x;
-  if (flags[b] != epoch || status[b] != 0) return;                         // (workgroup-uniform)
+  if (flags[b] != epoch) return;                                           // (workgroup-uniform)
+  if (status[b] != 0) {                                                    // (nothing to refine: the solve itself failed)
+    if (threadIdx.x == 0) flags[b] = 0;
+    return;
+  }
   __shared__ double red[8];
   const int tid = threadIdx.x, n = P.npu / P.m;
   const double* up = u_past + b * (long long)P.npu;
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(256) void ddmpc_flag_inaccurate_kernel(KParams P, i
   if (tid == 0) {
     double r_ = 0.0, t_ = 0.0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { r_ = fmax(r_, red[w]); t_ = fmax(t_, red[4 + w]); }
-    if (!(r_ / fmax(t_, 1e-300) <= P.refine_res)) status[b] = 1;
+    if (r_ / fmax(t_, 1e-300) <= P.refine_res) flags[b] = 0;
   }
 }
 __global__ void ddmpc_gain_column_kernel(long long batch, int r, int rE, int nrhs, int j, const double* __restrict__ beta,

@@ -216,7 +216,10 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
                                            double* __restrict__ beta_ws, signed char* __restrict__ act_ws,
                                            unsigned long long* __restrict__ stamps, double* __restrict__ lfac,
                                            double* __restrict__ lfacT, int* __restrict__ refine_flag,
-                                           int* __restrict__ refine_count, const double* __restrict__ gpre) {
+                                           int* __restrict__ refine_count, const double* __restrict__ gpre,
+                                           const double* __restrict__ ud_b, const double* __restrict__ yd_b) {
+  // (ud_b, yd_b: this instance's trajectories in global memory -- read by the refinement loop of the REF variant when the
+  //  trajectory is not staged, KParams::stage_xs = 0)
   using TM = TileMap2<NT, W>;
   using WT = WaveTiles2<NT, W, WAVE>;
   using LD = Lds2<NT, W>;
@@ -1020,14 +1023,29 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
       double prev = 1e300;
       for (int pass = 0; go && pass < P.refine_max; ++pass) {
         // alpha = H' beta in chunks that fit the (now free) panel buffer, z += H[:, chunk] alpha[chunk]
+        // Trajectories beyond the LDS (P.stage_xs == 0, hankel_matrix.py:39-51 takes any N >= L): the xs region is a WINDOW of
+        // P.xs_len doubles; every chunk of columns stages its rows [i0, i0 + nc + Ln - 1) of the trajectory from global memory
+        // first (the refining variant is the rare path: plain loads, one division per entry)
         const int c = P.c;
-        constexpr int CH = 16 * RSB;
+        constexpr int CHF = 16 * RSB;
+        const bool windowed = P.stage_xs == 0;
+        const int CHW = P.xs_len / nch - (P.Ln - 1);
+        const int CH = (windowed && CHW < CHF) ? CHW : CHF;
         double zacc[NE];
         static_for<NE>([&](auto e) __attribute__((always_inline)) { zacc[e()] = 0.0; });
         for (int i0 = 0; i0 < c; i0 += CH) {
           const int nc = (c - i0) < CH ? (c - i0) : CH;
+          if (windowed) {
+            const int nrow = nc + P.Ln - 1, nu = nrow * P.m, ny = nrow * P.p;
+            const double* us = ud_b + (long long)i0 * P.m;
+            const double* ys = yd_b + (long long)i0 * P.p;
+            for (int i = tid; i < nu; i += NTHR) { const int t = i / P.m, ch = i - t * P.m; xs[t * nch + ch] = us[i]; }
+            for (int i = tid; i < ny; i += NTHR) { const int t = i / P.p, ch = i - t * P.p; xs[t * nch + P.m + ch] = ys[i]; }
+            __syncthreads();
+          }
+          const double* xw = windowed ? xs : xs + (long long)i0 * nch;       // column 0 of the chunk
           for (int i = tid; i < nc; i += NTHR) {
-            const double* xp = xs + (long long)(i0 + i) * nch;
+            const double* xp = xw + (long long)i * nch;
             double s = 0.0;
             for (int rho = 0; rho < r; ++rho) s = fma(xp[rho], beta[rho], s);
             PB[i] = s;
@@ -1036,7 +1054,7 @@ __device__ __forceinline__ void wave_body2(const KParams& P, double* __restrict_
           static_for<NE>([&](auto e) __attribute__((always_inline)) {
             const int rho = tid + e * NTHR;
             if (rho < r) {
-              const double* xq = xs + (long long)i0 * nch + rho;
+              const double* xq = xw + rho;
               double s = zacc[e()];
               for (int ii = 0; ii < nc; ++ii) s = fma(xq[(long long)ii * nch], PB[ii], s);
               zacc[e()] = s;
@@ -1729,7 +1747,8 @@ __global__ __launch_bounds__(64 * W, DDMPC_MIN_WAVES(NT, W)) void ddmpc_cold_sol
     if (wave == WV)
       wave_body2<NT, W, WV, REF, CVX && !REF>(P, sm, up, yp, uo, cost + b, status + b, it, bw, aw, st, lf, lft,
                                  refine_flag ? refine_flag + b : nullptr, REF ? nullptr : refine_count,
-                                 P.gpre ? P.gpre + b * P.gpre_stride : nullptr);
+                                 P.gpre ? P.gpre + b * P.gpre_stride : nullptr, u_d + b * (long long)P.N * P.m,
+                                 y_d + b * (long long)P.N * P.p);
   });
   if constexpr (REF) __syncthreads();          // persistent grid: LDS is reused by the next instance
   }

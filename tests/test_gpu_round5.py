@@ -353,9 +353,9 @@ def test_trajectories_beyond_the_lds(gpu, N, slack):
         uh = tuple(x.copy() for x in eng.solve_from_host(d["u_d"], d["y_d"], up, yp))
         eng.set_data(d["u_d"], d["y_d"])
         uw = tuple(x.copy() for x in eng.step(up, yp))
-        eng.set_refinement("always")
-        with pytest.raises(L.DDMPCError, match="REFINE_ALWAYS"):
-            eng.solve(up, yp)
+        eng.set_refinement("always")                      # (refused for such handles until the refining variant learnt to
+        ur = tuple(x.copy() for x in eng.solve(up, yp))   #  window the trajectory: test_refinement_on_trajectories_beyond_the_lds)
+    assert np.array_equal(ur[2], status) and np.array_equal(ur[3], iters) and np.max(np.abs(ur[0] - u)) <= 1e-9 * np.max(np.abs(u))
     assert np.array_equal(uh[0], u) and np.array_equal(uh[2], status)
     assert np.max(np.abs(uw[0] - u)) <= 1e-9 * np.max(np.abs(u)) and np.array_equal(uw[2], status)
     Hu = orc.hankel_matrix(d["u_d"][0], spec.Ln)
@@ -438,3 +438,78 @@ def test_nominal_phase_pipeline_gram_with_several_lags_per_tile(gpu, shape, seed
     assert eu < TOL_U and ec < TOL_COST, (eu, ec)
     a, bq = res["phases"], res["one_workgroup"]
     assert np.max(np.abs(a[0] - bq[0])) < 1e-7 * np.max(np.abs(bq[0]))
+
+
+@pytest.mark.parametrize("m,p,N", [(3, 2, 5000), (1, 2, 9000), (4, 4, 3000), (5, 5, 2600)])
+def test_trajectories_beyond_the_lds_with_other_channel_counts(gpu, m, p, N):
+    """hankel_matrix.py:39-51 takes any N >= L for any channel count.  Plants of 3, 5, 8 and 10 channels with trajectories the cold
+    kernel cannot stage: the streaming Gram launch passes the trajectory through its LDS in several chunks, with 5 / 3 / 2 lags per
+    matrix tile (one tile row left over at five and three channels) or one (ten channels), and writes the kernel's tiles directly.
+    Against the compiled C restatement on every instance and the full-space oracle on one; slack box on."""
+    from oracle import oracle_c
+    rng = np.random.default_rng(7000 + 10 * m + p)
+    n = 3
+    nch = m + p
+    Lh = 130 // nch - n
+    A = rng.normal(size=(n, n)); A *= 0.85 / max(abs(np.linalg.eigvals(A)))
+    plant = dict(A=A, B=rng.normal(size=(n, m)), C=rng.normal(size=(p, n)), D=np.zeros((p, m)), eps_max=0.02)
+    B = 4
+    d = harness.generate_batch(range(B), N=N, plant=plant)
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    spec = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=2.0 * np.eye(p * Lh), R=0.05 * np.eye(m * Lh), u_s=rng.uniform(-0.3, 0.3, m),
+                      y_s=rng.uniform(-0.3, 0.3, p), robust=True, eps_max=0.02, lamb_alpha=20.0, lamb_sigma=500.0, c=0.2,
+                      slack="convex", tec=True)
+    with _spec_engine(spec, N, B) as eng:
+        assert "cold" in eng.kernel_name()
+        eng.set_data(d["u_d"], d["y_d"])
+        u, cost, status, iters = (x.copy() for x in eng.solve(up, yp))
+        with pytest.raises(L.DDMPCError):                 # the staged launch cannot hold this trajectory
+            eng.set_gram_launch("staged")
+    u_c, c_c, st_c, it_c = oracle_c.solve_batch(spec, N, d["u_d"], d["y_d"], up, yp, threads=2)
+    # every instance against the compiled restatement -- itself a Gram-route solve without refinement, good to ~1e-9 on these
+    # plants, while the GPU refines what its streamed residual check keeps flagged -- and one against the full-space oracle
+    assert not np.count_nonzero(st_c) and np.all(status == 0), status
+    assert np.array_equal(iters, it_c)
+    assert np.max(np.max(np.abs(u - u_c), axis=1) / np.max(np.abs(u_c), axis=1)) < TOL_U
+    assert np.max(np.abs(cost - c_c) / np.abs(c_c)) < 1e-8
+    sol = orc.solve_fullspace(spec, d["u_d"][0], d["y_d"][0], up[0], yp[0])
+    assert np.max(np.abs(u[0] - sol.optimal_u)) / np.max(np.abs(sol.optimal_u)) < TOL_U
+    assert abs(cost[0] - sol.cost) / abs(sol.cost) < TOL_COST and int(iters[0]) == sol.iters
+
+
+@pytest.mark.parametrize("m,p,N", [(3, 2, 5000), (2, 2, 6000)])
+def test_refinement_on_trajectories_beyond_the_lds(gpu, m, p, N):
+    """The refining kernel variant on a trajectory the kernel cannot stage: its products with the implicit Hankel matrix pass the
+    trajectory through a window of LDS chunk by chunk (ddmpc_cold2.hpp, KParams::stage_xs = 0).  Random plants with the noise level
+    of the four-tank example leave the Gram route at ~5e-8 (the compiled restatement is no better): under AUTO the streamed
+    residual check keeps those instances flagged and the refining variant brings them inside the bars against the full-space
+    oracle; DDMPC_REFINE_ALWAYS, refused for such handles until this round, does the same for every instance; OFF shows what
+    the refinement bought.  ddmpc_solve and the chunked ddmpc_solve_from_host."""
+    rng = np.random.default_rng(7100 + 10 * m + p)
+    n = 3
+    nch = m + p
+    Lh = 130 // nch - n
+    A = rng.normal(size=(n, n)); A *= 0.85 / max(abs(np.linalg.eigvals(A)))
+    plant = dict(A=A, B=rng.normal(size=(n, m)), C=rng.normal(size=(p, n)), D=np.zeros((p, m)), eps_max=0.002)
+    B = 300                                               # (ddmpc_solve_from_host splits 256 instances and more into chunks)
+    d = harness.generate_batch(range(B), N=N, plant=plant)
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    spec = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=2.0 * np.eye(p * Lh), R=0.05 * np.eye(m * Lh), u_s=rng.uniform(-0.3, 0.3, m),
+                      y_s=rng.uniform(-0.3, 0.3, p), robust=True, eps_max=0.002, lamb_alpha=20.0, lamb_sigma=500.0, c=1.0,
+                      slack="convex", tec=True)
+    sols = [orc.solve_fullspace(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b]) for b in range(2)]
+    err = {}
+    for mode in ("off", "auto", "always"):
+        with _spec_engine(spec, N, B) as eng:
+            eng.set_refinement(mode)
+            eng.set_data(d["u_d"], d["y_d"])
+            u, cost, status, iters = (x.copy() for x in eng.solve(up, yp))
+            uh, ch, sh, ih = eng.solve_from_host(d["u_d"], d["y_d"], up, yp)
+        assert np.all(status == 0), (mode, np.unique(status))
+        assert np.array_equal(uh, u) and np.array_equal(ch, cost) and np.array_equal(sh, status) and np.array_equal(ih, iters), mode
+        err[mode] = max(np.max(np.abs(u[b] - s.optimal_u)) / np.max(np.abs(s.optimal_u)) for b, s in enumerate(sols))
+        ec = max(abs(cost[b] - s.cost) / abs(s.cost) for b, s in enumerate(sols))
+        assert all(int(iters[b]) == s.iters for b, s in enumerate(sols)), mode
+        if mode != "off":
+            assert err[mode] < TOL_U and ec < TOL_COST, (mode, err[mode], ec)
+    assert err["always"] <= err["off"]

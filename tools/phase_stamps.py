@@ -1,4 +1,6 @@
-"""Dev tool: per-phase shader-clock breakdown of the cold-solve kernel (diagnostic stamps)."""
+"""Dev tool: per-phase shader-clock breakdown of the cold-solve kernel (diagnostic stamps).
+
+    python tools/phase_stamps.py [batch] [gram_mode] [L] [N]      (defaults 4096 0 30 400; configs[3]: 1024 0 60 1000)"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -8,11 +10,13 @@ from direct_data_driven_mpc_amd.harness import controller_params, generate_batch
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 gram = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-cfg = controller_params()
-d = generate_batch(range(B))
+LH = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+NN = int(sys.argv[4]) if len(sys.argv) > 4 else 400
+cfg = controller_params(dict(L=LH, N=NN)) if LH != 30 else controller_params()
+d = generate_batch(range(B), N=NN)
 n = 4
 up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
-eng = BatchedDDMPC(n=4, m=2, p=2, L_=30, N=400, Q=cfg["Q"], R=cfg["R"], u_s=cfg["u_s"], y_s=cfg["y_s"], batch=B,
+eng = BatchedDDMPC(n=4, m=2, p=2, L_=LH, N=NN, Q=cfg["Q"], R=cfg["R"], u_s=cfg["u_s"], y_s=cfg["y_s"], batch=B,
                    controller_type=L.ROBUST, slack_type=L.SLACK_NONE, eps_max=cfg["eps_max"], lamb_alpha=cfg["lamb_alpha"],
                    lamb_sigma=cfg["lamb_sigma"], c=cfg["c"], gram_mode=gram)
 eng.set_data(d["u_d"], d["y_d"])
