@@ -1692,7 +1692,7 @@ int ddmpc_prepare(ddmpc_handle* h) {
 #undef DDMPC_INSTANCE
   if (!launched) return fail(DDMPC_ERR_UNSUPPORTED, "no gain kernel for %d tile rows", NT);
   HIP_TRY(hipGetLastError());
-  if (k.lam != 0.0 && (k.refine == DDMPC_REFINE_ALWAYS || k.refine == DDMPC_REFINE_AUTO) && !h->long_data) {
+  if (k.lam != 0.0 && (k.refine == DDMPC_REFINE_ALWAYS || k.refine == DDMPC_REFINE_AUTO)) {
     // The substitutions above went through the unrefined factor, whose error is the Gram route's (cond(H) squared).
     // Replace columns of the law by refining cold solves: beta is affine in the past window, so column 1 + f =
     // beta(e_f) - beta(0).  nf + 1 launches of the refining kernel variant, once per data set -- ALWAYS: for every
@@ -1716,7 +1716,9 @@ int ddmpc_prepare(ddmpc_handle* h) {
         if ((rc = h->d_act.ensure(B * k.rE))) return rc;
         kr.epoch = h->prep_epoch;
         if ((rc = gram_pre_launch(h, kr, h->ud, h->yd, B, 0, true))) return rc;
-        hipLaunchKernelGGL(h->kc.fn2r, dim3((unsigned)(B < 768 ? B : 768)), dim3(64 * h->kc.W), h->lds_bytes, h->stream, kr, h->ud,
+        if (h->long_data) kr.xs_len = h->ld_window;       // (trajectory beyond the LDS: the refining variant's window; there the
+                                                          //  flags are those of the a-priori bound alone, no streamed check)
+        hipLaunchKernelGGL(h->kc.fn2r, dim3((unsigned)(B < 768 ? B : 768)), dim3(64 * h->kc.W), h->long_data ? h->ld_lds_bytes : h->lds_bytes, h->stream, kr, h->ud,
                            h->yd, (const double*)pu, (const double*)py, (double*)h->d_uopt.p, (double*)h->d_cost.p,
                            (int*)h->d_prep_status.p, (int*)nullptr, (double*)h->d_beta.p, (signed char*)h->d_act.p,
                            (unsigned long long*)nullptr, (double*)nullptr, (double*)nullptr, (int*)nullptr,

@@ -505,7 +505,11 @@ def test_refinement_on_trajectories_beyond_the_lds(gpu, m, p, N):
             eng.set_data(d["u_d"], d["y_d"])
             u, cost, status, iters = (x.copy() for x in eng.solve(up, yp))
             uh, ch, sh, ih = eng.solve_from_host(d["u_d"], d["y_d"], up, yp)
+            eng.set_data(d["u_d"], d["y_d"])
+            uw = eng.step(up, yp)                         # (the affine law of ddmpc_prepare is refined the same way)
         assert np.all(status == 0), (mode, np.unique(status))
+        if mode != "off":
+            assert np.array_equal(uw[2], status) and np.max(np.abs(uw[0] - u)) <= 1e-8 * np.max(np.abs(u)), mode
         assert np.array_equal(uh, u) and np.array_equal(ch, cost) and np.array_equal(sh, status) and np.array_equal(ih, iters), mode
         err[mode] = max(np.max(np.abs(u[b] - s.optimal_u)) / np.max(np.abs(s.optimal_u)) for b, s in enumerate(sols))
         ec = max(abs(cost[b] - s.cost) / abs(s.cost) for b, s in enumerate(sols))
