@@ -90,6 +90,11 @@ timeout -k 10 400 python tools/config5_check.py --check 512 > "$OUT/cfg5_parity.
 timeout -k 10 600 python tools/config5_check.py --robust --check 512 > "$OUT/cfg5size_robust_parity.log" 2>&1
 timeout -k 10 400 python tools/large_fuzz.py --cases 12 > "$OUT/large_kernel_fuzz.log" 2>&1
 timeout -k 10 120 python tools/pivot_gap_study.py 6 > "$OUT/pivot_gap_study.log" 2>&1
+# round 5, second half: trajectories beyond the LDS, the two structured-Gram launches side by side, all of configs[2] with the slack box
+timeout -k 10 200 python tools/long_data_time.py > "$OUT/long_data_time.log" 2>&1
+bash tools/gram_launches.sh "gpurun_out/$TAG/gram_launches" > "$OUT/gram_launches.log" 2>&1
+timeout -k 10 600 python tools/config3_full_parity.py --slack convex > "$OUT/cfg3_convex_full_parity.log" 2>&1
+timeout -k 10 900 python tools/small_fuzz.py --cases 96 --refine auto > "$OUT/small_fuzz_auto.log" 2>&1
 echo "[collect] cfg5b done"
 fi
 if [ "$PART" = "calib" ] || [ "$PART" = "all" ]; then

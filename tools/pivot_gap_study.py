@@ -40,7 +40,8 @@ def show(tag, spec, N, d, up, yp, B):
             print("%-22s b=%d status %d: candidates > 0: %d, above the fixed 1e-8: %d (rank bound %d); smallest of them %.2e, largest below %.2e; "
                   "largest gap below 1e-3: %.2e .. %.2e (x%.0f)%s" % (tag, b, status[b], len(pos), len(acc), bound, acc.min(),
                                                                      rel[(rel > 0) & (rel <= 1e-8)].max() if np.any((rel > 0) & (rel <= 1e-8)) else 0.0,
-                                                                     small[j], small[j + 1], ratios[j], note), flush=True)
+                                                                     small[j] if len(small) else 0.0, small[j + 1] if len(small) > j + 1 else 0.0,
+                                                                     ratios[j] if len(ratios) else 0.0, note), flush=True)
 
 
 if __name__ == "__main__":
