@@ -205,6 +205,8 @@ struct ddmpc_handle {
   int flag_epoch = 0;                      // latest stamp written into d_rflag
   bool ws_stale = false;                   // the last solve was a cold solve that skipped the beta / active-set workspace                 // the last solve launched the rescue kernel (its flags are current)
   HostBuf h_io;
+  HostBuf h_flag;                          // one pinned word: the "factor again" count of the rank decision (launch_rr2_factors)
+  hipEvent_t ev_flag = nullptr;            // ... and the event behind its copy
   bool prepared = false;
   int closed_loop_path = DDMPC_PATH_AUTO;
   bool closed_loop_graph = false;
@@ -684,6 +686,8 @@ int ddmpc_destroy(ddmpc_handle* h) {
                     &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_gpre, &h->d_perm, &h->d_rr2d, &h->d_rr2res, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz, &h->d_gz, &h->d_gres, &h->d_zvirt, &h->d_rr3w, &h->d_rr3k, &h->d_rr_fb, &h->d_rrmeta_fb, &h->d_rr2cand, &h->d_rr2tol, &h->d_rr2rank};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
+  h->h_flag.release();
+  if (h->ev_flag) (void)hipEventDestroy(h->ev_flag);
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1199,6 +1203,29 @@ static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, 
   if ((rc = h->d_rr2cand.ensure(B * (size_t)n16 * sizeof(double)))) return rc;
   FG.cand = (double*)h->d_rr2cand.p; FG.cand_stride = n16;
   cholesky(FG, n16);
+  // what follows the factor of G: pivot counts, T = C'WC, its factor
+  auto downstream = [&]() -> int {
+    hipLaunchKernelGGL(rr2_meta_kernel, dim3((unsigned)B), dim3(256), 0, h->stream, meta, mstride, rv, r, nF, nR);
+    if (nR > 0) {
+      const int ldw = ((nR16 + 31) / 32) * 32 + 16;                         // LDS row of the C'WC kernel: 16 mod 32 doubles
+      const size_t cwlds = ((size_t)16 * ldw + 16) * sizeof(double);
+      if (cwlds > 64 * 1024)
+        HIP_TRY(raise_lds_limit((const void*)rr2_cwc_kernel, cwlds));
+      hipLaunchKernelGGL(rr2_cwc_kernel, dim3((unsigned)B), dim3(1024), cwlds, h->stream, k, 16 * h->kc.NT, perm, scratch, ndbl,
+                         (long long)pk_size((size_t)n16), (const int*)meta, mstride, rv, nF, nR, dd + 1, ldw);
+      Rr2Chol FT{};
+      FT.ws = scratch; FT.stride = ndbl; FT.off = (long long)pk_size((size_t)n16); FT.n16 = nR16;
+      FT.n_inst = meta + 2 * rv + 1; FT.n_stride = mstride;
+      FT.dmax = dd + 1; FT.d_stride = 4; FT.tol_rel = 1e-14; FT.skip = meta + rv; FT.s_stride = mstride; FT.nflag = nR;
+      FT.live = dd + 3; FT.l_stride = 4; FT.m64 = (double*)h->d_rr2mt.p + m64G; FT.m64_stride = m64G + m64T;
+      if (nR16 <= 384)            // a few panels: one launch, one workgroup per instance walks them (rr2_chol_small_kernel)
+        hipLaunchKernelGGL(rr2_chol_small_kernel<2>, dim3((unsigned)B), dim3(256), 0, h->stream, FT);
+      else
+        cholesky(FT, nR16);
+    }
+    HIP_TRY(hipGetLastError());
+    return DDMPC_OK;
+  };
   {
     // The rank decision, judged from the pivot candidates (rr2_rank_margin_kernel): an instance that accepted more pivots than
     // rank H can be gets a tolerance inside the gap behind the largest m (L + n) + n candidates and the batch is factored once
@@ -1212,10 +1239,19 @@ static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, 
     HIP_TRY(hipMemsetAsync(rec + 2 * B, 0, sizeof(int), h->stream));
     hipLaunchKernelGGL(rr2_rank_margin_kernel, dim3((unsigned)B), dim3(256), 0, h->stream, (const double*)h->d_rr2cand.p, (long long)n16, r, bound,
                        rank_tol, (const double*)nullptr, safe, 1, (double*)h->d_rr2tol.p, rec, rec + 2 * B);
-    int nredo = 0;
-    HIP_TRY(hipMemcpyAsync(&nredo, rec + 2 * B, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (nredo > 0) {
+    // ... read back WITHOUT draining the stream: the copy lands in a pinned word behind an event, everything downstream of the
+    // factor (pivot counts, C'WC, its factor) is queued at once as if no instance needed the second pass -- the usual case -- and
+    // the host waits for the event while the GPU works on that; a batch that does need it is factored again and the downstream
+    // launches are repeated
+    if ((rc = h->h_flag.ensure(sizeof(int)))) return rc;
+    if (!h->ev_flag) HIP_TRY(hipEventCreateWithFlags(&h->ev_flag, hipEventDisableTiming));
+    volatile int* nredo = (volatile int*)h->h_flag.p;
+    *nredo = 0;
+    HIP_TRY(hipMemcpyAsync(h->h_flag.p, rec + 2 * B, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(h->ev_flag, h->stream));
+    if ((rc = downstream())) return rc;
+    HIP_TRY(hipEventSynchronize(h->ev_flag));
+    if (*nredo > 0) {
       HIP_TRY(hipMemsetAsync(h->d_rr2d.p, 0, B * 4 * sizeof(unsigned long long), h->stream));
       HIP_TRY(hipMemset2DAsync(h->d_rr2res.p, (size_t)rstride * sizeof(double), 0, 2 * sizeof(unsigned long long), B, h->stream));
       gram();
@@ -1223,25 +1259,8 @@ static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, 
       cholesky(FG, n16);
       hipLaunchKernelGGL(rr2_rank_margin_kernel, dim3((unsigned)B), dim3(256), 0, h->stream, (const double*)h->d_rr2cand.p, (long long)n16, r, bound,
                          rank_tol, (const double*)h->d_rr2tol.p, safe, 0, (double*)h->d_rr2tol.p, rec, rec + 2 * B);
+      if ((rc = downstream())) return rc;
     }
-  }
-  hipLaunchKernelGGL(rr2_meta_kernel, dim3((unsigned)B), dim3(256), 0, h->stream, meta, mstride, rv, r, nF, nR);
-  if (nR > 0) {
-    const int ldw = ((nR16 + 31) / 32) * 32 + 16;                         // LDS row of the C'WC kernel: 16 mod 32 doubles
-    const size_t cwlds = ((size_t)16 * ldw + 16) * sizeof(double);
-    if (cwlds > 64 * 1024)
-      HIP_TRY(raise_lds_limit((const void*)rr2_cwc_kernel, cwlds));
-    hipLaunchKernelGGL(rr2_cwc_kernel, dim3((unsigned)B), dim3(1024), cwlds, h->stream, k, 16 * h->kc.NT, perm, scratch, ndbl,
-                       (long long)pk_size((size_t)n16), (const int*)meta, mstride, rv, nF, nR, dd + 1, ldw);
-    Rr2Chol FT{};
-    FT.ws = scratch; FT.stride = ndbl; FT.off = (long long)pk_size((size_t)n16); FT.n16 = nR16;
-    FT.n_inst = meta + 2 * rv + 1; FT.n_stride = mstride;
-    FT.dmax = dd + 1; FT.d_stride = 4; FT.tol_rel = 1e-14; FT.skip = meta + rv; FT.s_stride = mstride; FT.nflag = nR;
-    FT.live = dd + 3; FT.l_stride = 4; FT.m64 = (double*)h->d_rr2mt.p + m64G; FT.m64_stride = m64G + m64T;
-    if (nR16 <= 384)            // a few panels: one launch, one workgroup per instance walks them (rr2_chol_small_kernel)
-      hipLaunchKernelGGL(rr2_chol_small_kernel<2>, dim3((unsigned)B), dim3(256), 0, h->stream, FT);
-    else
-      cholesky(FT, nR16);
   }
   HIP_TRY(hipGetLastError());
   return DDMPC_OK;

@@ -875,29 +875,48 @@ __global__ __launch_bounds__(256) void rr2_rank_margin_kernel(const double* __re
   const double inv = mx > 0.0 ? 1.0 / mx : 0.0;
   for (int i = tid; i < 1024; i += 256) v[i] *= inv;
   __syncthreads();
-  for (int k = 2; k <= 1024; k <<= 1)                                       // bitonic sort, descending
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < 1024; i += 256) {
-        const int l = i ^ j;
-        if (l > i) {
-          const bool up = (i & k) == 0;
-          const double a = v[i], bq = v[l];
-          if (up ? (a < bq) : (a > bq)) { v[i] = bq; v[l] = a; }
+  // the common case needs no order statistics: count the accepted candidates, the smallest of them and the largest skipped one
+  const double tol = tol_in ? tol_in[b] : tol_rel;
+  int cnt = 0;
+  double amin = 2.0, smax = 0.0;
+  for (int i = tid; i < 1024; i += 256) {
+    const double x = v[i];
+    if (x > tol) { ++cnt; amin = fmin(amin, x); } else smax = fmax(smax, x);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    cnt += __shfl_xor(cnt, off, 64); amin = fmin(amin, __shfl_xor(amin, off, 64)); smax = fmax(smax, __shfl_xor(smax, off, 64));
+  }
+  __shared__ double ra[4], rs[4];
+  __shared__ int rc[4];
+  if ((tid & 63) == 0) { rc[tid >> 6] = cnt; ra[tid >> 6] = amin; rs[tid >> 6] = smax; }
+  __syncthreads();
+  const int K = rc[0] + rc[1] + rc[2] + rc[3];
+  amin = fmin(fmin(ra[0], ra[1]), fmin(ra[2], ra[3]));
+  smax = fmax(fmax(rs[0], rs[1]), fmax(rs[2], rs[3]));
+  const bool over = K > bound && bound >= 1;                                // (workgroup-uniform) more pivots than rank H can have
+  if (over) {
+    for (int k = 2; k <= 1024; k <<= 1)                                     // bitonic sort, descending: v[bound - 1], v[bound] are needed
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < 1024; i += 256) {
+          const int l = i ^ j;
+          if (l > i) {
+            const bool up = (i & k) == 0;
+            const double a = v[i], bq = v[l];
+            if (up ? (a < bq) : (a > bq)) { v[i] = bq; v[l] = a; }
+          }
         }
+        __syncthreads();
       }
-      __syncthreads();
-    }
+  }
   if (tid == 0) {
-    const double tol = tol_in ? tol_in[b] : tol_rel;
-    int K = 0;
-    while (K < r && v[K] > tol) ++K;                                        // (<= 1024 steps, once per instance and data set)
     int flag = 0;
     double tnew = tol, hi, lo;
-    if (K > bound && bound >= 1) {
+    if (over) {
       hi = v[bound - 1]; lo = v[bound];
       if (allow_redo) { tnew = sqrt(hi * fmax(lo, 1e-300)); flag = 2; } else flag = 1;
     } else {
-      hi = K > 0 ? v[K - 1] : 1.0; lo = K < r ? v[K] : 0.0;
+      hi = K > 0 ? amin : 1.0; lo = K < r ? smax : 0.0;
     }
     if (lo > 0.0 && hi < safe * lo) flag |= 1;
     tol_out[b] = tnew;
