@@ -2438,6 +2438,12 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
                                  meta_ws, (long long)blockIdx.x, (long long)blockIdx.x);
     return;
   }
+  {                                                                // usually nothing is marked: find that out with one parallel sweep
+    int mine = 0;
+    for (long long b = blockIdx.x + (long long)gridDim.x * threadIdx.x; b < nbatch; b += (long long)gridDim.x * blockDim.x)
+      mine |= (status[b] == only_status) ? 1 : 0;
+    if (!__syncthreads_or(mine)) return;
+  }
   for (long long b = blockIdx.x; b < nbatch; b += gridDim.x) {
     if (status[b] == only_status)                                  // (workgroup-uniform)
       ddmpc_large_solve_body<MODE>(P, RPs, u_d, y_d, u_past, y_past, u_opt, cost, status, iters, beta_ws, act_ws, scratch, scratch_stride,
