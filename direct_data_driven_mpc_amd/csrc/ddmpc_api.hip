@@ -1232,13 +1232,13 @@ static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, 
     // more with per-instance tolerances (every other instance keeps its tolerance: bit-identical factors); a decision without a
     // clear margin is flagged and the solve reports "optimal_inaccurate".  One 4-byte read-back per data set decides on the
     // second pass -- none on the benchmark configurations.
-    if ((rc = h->d_rr2tol.ensure(B * sizeof(double))) || (rc = h->d_rr2rank.ensure((2 * B + 1) * sizeof(int)))) return rc;
+    if ((rc = h->d_rr2tol.ensure(2 * B * sizeof(double))) || (rc = h->d_rr2rank.ensure((2 * B + 1) * sizeof(int)))) return rc;
     const int bound = k.m * k.Ln + h->prm.n;
     const double safe = 20.0;
     int* rec = (int*)h->d_rr2rank.p;
     HIP_TRY(hipMemsetAsync(rec + 2 * B, 0, sizeof(int), h->stream));
     hipLaunchKernelGGL(rr2_rank_margin_kernel, dim3((unsigned)B), dim3(256), 0, h->stream, (const double*)h->d_rr2cand.p, (long long)n16, r, bound,
-                       rank_tol, (const double*)nullptr, safe, 1, (double*)h->d_rr2tol.p, rec, rec + 2 * B);
+                       rank_tol, (const double*)nullptr, safe, 1, (double*)h->d_rr2tol.p, rec, rec + 2 * B, (double*)h->d_rr2tol.p + B);
     // ... read back WITHOUT draining the stream: the copy lands in a pinned word behind an event, everything downstream of the
     // factor (pivot counts, C'WC, its factor) is queued at once as if no instance needed the second pass -- the usual case -- and
     // the host waits for the event while the GPU works on that; a batch that does need it is factored again and the downstream
@@ -1258,7 +1258,7 @@ static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, 
       FG.tol_inst = (const double*)h->d_rr2tol.p;
       cholesky(FG, n16);
       hipLaunchKernelGGL(rr2_rank_margin_kernel, dim3((unsigned)B), dim3(256), 0, h->stream, (const double*)h->d_rr2cand.p, (long long)n16, r, bound,
-                         rank_tol, (const double*)h->d_rr2tol.p, safe, 0, (double*)h->d_rr2tol.p, rec, rec + 2 * B);
+                         rank_tol, (const double*)h->d_rr2tol.p, safe, 0, (double*)h->d_rr2tol.p, rec, rec + 2 * B, (double*)h->d_rr2tol.p + B);
       if ((rc = downstream())) return rc;
     }
   }
@@ -1286,6 +1286,7 @@ static int rr2_solve_desc(ddmpc_handle* h, double* scratch, long long ndbl, Rr2S
   S.perm = (const int*)h->d_perm.p;
   S.wz = (const double*)h->d_wz.p;
   S.rankrec = (const int*)h->d_rr2rank.p;
+  S.noise = h->d_rr2tol.p ? (const double*)h->d_rr2tol.p + h->batch : nullptr;
   S.V = (double*)h->d_rr2v.p; S.vstride = (long long)V_NV * VL; S.VL = VL;
   S.ZP = (double*)h->d_rr2zp.p;
   S.sc = (double*)h->d_rr2sc.p;

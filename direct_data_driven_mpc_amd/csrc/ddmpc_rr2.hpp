@@ -859,7 +859,10 @@ __global__ __launch_bounds__(1024) void rr2_cwc_kernel(KParams P, int RPs, const
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rr2_rank_margin_kernel(const double* __restrict__ cand, long long cand_stride, int r, int bound,
                                                               double tol_rel, const double* __restrict__ tol_in, double safe, int allow_redo,
-                                                              double* __restrict__ tol_out, int* __restrict__ rec, int* __restrict__ counter) {
+                                                              double* __restrict__ tol_out, int* __restrict__ rec, int* __restrict__ counter,
+                                                              double* __restrict__ noise_out) {
+  // noise_out[b]: the largest candidate that counts as zero, relative to the largest: the level to which a dependent row is
+  // reproduced by the accepted ones at best, sqrt of it in the rows themselves (the feasibility test of the solve scales with it)
   __shared__ double v[1024];
   const long long b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -920,6 +923,7 @@ __global__ __launch_bounds__(256) void rr2_rank_margin_kernel(const double* __re
     }
     if (lo > 0.0 && hi < safe * lo) flag |= 1;
     tol_out[b] = tnew;
+    if (noise_out) noise_out[b] = lo;
     rec[2 * b] = flag; rec[2 * b + 1] = K;
     if (flag & 2) atomicAdd(counter, 1);
   }

@@ -19,7 +19,7 @@ ap.add_argument("--pipeline", default=None, help="phases | one_workgroup (DDMPC_
 ap.add_argument("--no-svd", action="store_true", help="compare with the model-based solution only (faster)")
 ap.add_argument("--large-only", action="store_true", help="only the cases beyond the register-resident kernels")
 a = ap.parse_args()
-worst = 0.0; bad = 0
+worst = 0.0; bad = 0; flagged = 0
 for case in range(a.cases):
     rng = np.random.default_rng(9000 + case)
     m, p = [(2, 2), (1, 3), (3, 1), (2, 3), (4, 2), (1, 1)][case % 6]
@@ -48,7 +48,9 @@ for case in range(a.cases):
     for b in range(B):
         mod = solve_nominal_model_based(spec, plant, up[b], yp[b])
         ref = mod if a.no_svd else solve_nominal_exact(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
-        ok &= (a.no_svd or ref["status"] == "optimal") and L.STATUS_STRINGS[int(status[b])] == "optimal"
+        # ("optimal_inaccurate": a rank decision without a clear margin is reported, not hidden -- counted, not a failure)
+        ok &= (a.no_svd or ref["status"] == "optimal") and L.STATUS_STRINGS[int(status[b])] in ("optimal", "optimal_inaccurate")
+        flagged += L.STATUS_STRINGS[int(status[b])] == "optimal_inaccurate"
         sc = max(np.max(np.abs(mod["optimal_u"])), 1e-3)
         e_svd = max(e_svd, np.max(np.abs(u[b] - ref["optimal_u"])) / sc)
         e_mod = max(e_mod, np.max(np.abs(u[b] - mod["optimal_u"])) / sc)
@@ -56,5 +58,6 @@ for case in range(a.cases):
     print("case %2d m=%d p=%d n=%d L=%3d N=%4d r=%3d %-32s status %s  rel err u: vs SVD solve %.1e, vs model-based %.1e" % (
         case, m, p, n, Lh, N, r, name, "ok" if ok else "MISMATCH " + str(status.tolist()), e_svd, e_mod), flush=True)
     bad += (not ok) or not (e_mod < 1e-8)
-print("worst rel err vs the model-based solution over %d cases: %.2e; cases off the bars (1e-8) or not optimal: %d" % (a.cases, worst, bad))
+print("worst rel err vs the model-based solution over %d cases: %.2e; cases off the bars (1e-8) or not optimal: %d; instances reported optimal_inaccurate "
+      "(thin rank margin): %d" % (a.cases, worst, bad, flagged))
 assert bad == 0
