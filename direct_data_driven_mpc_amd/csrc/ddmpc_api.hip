@@ -796,7 +796,10 @@ static int gram_pre_launch(ddmpc_handle* h, KParams& kq, const double* ud, const
     // channels), written straight into the tiles
     const dim3 grid(rr2_gram_grid(h->kp.Ln, h->kp.nch), (unsigned)nb);
     double* gp = (double*)h->d_gpre.p + (long long)b0 * stride;
-    if (h->kp.nch <= 8) hipLaunchKernelGGL(rr2_gram_tiles_packed_kernel, grid, dim3(256), 0, h->stream, h->kp, ud, yd, gp, stride, 16 * NT);
+    if (h->kp.nch == 4)                     // the four-tank plant of the reference's example: lag blocks on v_mfma_f64_4x4x4
+      hipLaunchKernelGGL(rr2_gram_tiles_c4_kernel, dim3((unsigned)(((h->kp.Ln + 3) / 4 + 4 * RR2_C4_SL - 1) / (4 * RR2_C4_SL)), (unsigned)nb), dim3(256), 0,
+                         h->stream, h->kp, ud, yd, gp, stride, 16 * NT);
+    else if (h->kp.nch <= 8) hipLaunchKernelGGL(rr2_gram_tiles_packed_kernel, grid, dim3(256), 0, h->stream, h->kp, ud, yd, gp, stride, 16 * NT);
     else hipLaunchKernelGGL(rr2_gram_tiles_kernel, grid, dim3(256), 0, h->stream, h->kp, ud, yd, gp, stride, 16 * NT);
     HIP_TRY(hipGetLastError());
     if (cacheable) h->gpre_valid = true;

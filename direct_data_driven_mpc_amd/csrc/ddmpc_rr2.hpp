@@ -256,6 +256,94 @@ __global__ __launch_bounds__(256, 4) void rr2_gram_tiles_packed_kernel(KParams P
                                                                     double* __restrict__ gpre, long long gstride, int n16) {
   rr2_gram_body<true, true>(P, u_d, y_d, nullptr, gpre, gstride, n16, nullptr);
 }
+// ---------------------------------------------------------------------------------------------------------------
+// The same for FOUR channels (the four-tank plant of the reference's example) on v_mfma_f64_4x4x4: four independent 4 x 4 x 4
+// products per instruction -- block blk of lane group l15 = 4 blk + i is the lag block C_d, d = 4 g + blk: A = x_i[t + k + d],
+// B = x_j[t + k], D_blk[i][j] -- at a quarter of the cycles of a 16x16x4 whose tile holds the same four lags (64 clocks on gfx950).
+// One accumulator register per group of four lags; the walk is the same instruction with the contraction slots (tail term,
+// -head term, 0, 0); every lane stores its one entry per step.  Writes the cold-solve kernel's tiles (see TILES above): what a
+// trajectory beyond that kernel's LDS takes.  grid = (ceil(ceil(Ln / 4) / (4 RR2_C4_SL)), batch), 256 threads.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int RR2_C4_SL = 4;        // groups of four lags per wave
+__global__ __launch_bounds__(256, 4) void rr2_gram_tiles_c4_kernel(KParams P, const double* __restrict__ u_d, const double* __restrict__ y_d,
+                                                                double* __restrict__ gpre, long long gstride, int n16) {
+  __shared__ __attribute__((aligned(16))) double xc[RR2_XCAP];
+  __shared__ int ipl[1024], prl[1024];                                      // entry K[x][y], x <= y, at prl[x] + ipl[y]
+  const long long b = blockIdx.y;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int m = P.m, p = P.p, c = P.c, Ln = P.Ln, r = P.r;
+  constexpr int nch = 4;
+  for (int i = tid; i < n16; i += nthr) {
+    prl[i] = (i >> 4) * 256 + 4 * ((i & 3) * 16) + ((i & 15) >> 2);
+    ipl[i] = ((i >> 4) * ((i >> 4) + 1) / 2) * 256 + 4 * (i & 15);
+  }
+  for (int i = tid; i < RR2_XCAP; i += nthr) xc[i] = 0.0;                   // (masked terms multiply whatever lies behind a chunk by zero: finite)
+  const double* ud = u_d + b * (long long)P.N * m;
+  const double* yd = y_d + b * (long long)P.N * p;
+  double* G = gpre + b * gstride;
+  const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4, blk = l15 >> 2, ij = l15 & 3;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6;
+  const int gtot = (Ln + 3) >> 2;
+  const int dg = blockIdx.x * nwave * RR2_C4_SL;
+  const int TCH = ((RR2_XCAP / nch) - Ln - 3) & ~3;
+  const int nw = Ln - 1;
+  double* xh = xc;                                                          // walk: rows 0 .. Ln-2
+  double* xt = xc + nw * nch;                                               //       rows c .. c+Ln-2
+  __syncthreads();                                                          // (the tables)
+  if (blockIdx.x == 0)                                                      // padding rows r .. n16-1: zero
+    for (int i = r; i < n16; ++i)
+      for (int j = tid; j <= i; j += nthr) {
+        G[prl[j] + ipl[i]] = 0.0;
+        if ((j >> 4) == (i >> 4)) G[prl[i] + ipl[j]] = 0.0;
+      }
+  double acc[RR2_C4_SL];
+  int dl[RR2_C4_SL];                                                        // this lane's lag in group sl, clamped to what is staged
+#pragma unroll
+  for (int sl = 0; sl < RR2_C4_SL; ++sl) {
+    acc[sl] = 0.0;
+    const int d = 4 * (dg + wave + nwave * sl) + blk;
+    dl[sl] = d < Ln ? d : Ln - 1;
+  }
+  for (int t0 = 0; t0 < c; t0 += TCH) {
+    const int nt = (c - t0) < TCH ? (c - t0) : TCH;
+    __syncthreads();
+    stage_trajectory<4>(P, ud, yd, t0, nt + Ln - 1, xc);
+    __syncthreads();
+    const double* pb = xc + l4 * nch + ij;
+    for (int s4 = 0; s4 < nt; s4 += 4) {
+      const double bv = (s4 + l4 < nt) ? pb[s4 * nch] : 0.0;
+#pragma unroll
+      for (int sl = 0; sl < RR2_C4_SL; ++sl)
+        if (dg + wave + nwave * sl < gtot)                                  // (wave-uniform)
+          acc[sl] = __builtin_amdgcn_mfma_f64_4x4x4f64(xc[(s4 + l4 + dl[sl]) * nch + ij], bv, acc[sl], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  stage_trajectory<4>(P, ud, yd, 0, nw, xh);
+  stage_trajectory<4>(P, ud, yd, c, nw, xt);
+  __syncthreads();
+  // accumulator: lane (l4 = a, l15 = 4 blk + bb) holds C_d(a, bb), d = 4 g + blk
+  const double* xsel = (l4 == 0) ? xt : xh;
+  const double sga = (l4 == 0) ? 1.0 : (l4 == 1 ? -1.0 : 0.0), sgb = (l4 < 2) ? 1.0 : 0.0;
+#pragma unroll
+  for (int sl = 0; sl < RR2_C4_SL; ++sl) {
+    const int g = dg + wave + nwave * sl;
+    if (g >= gtot) continue;                                                // (wave-uniform)
+    const int d = 4 * g + blk, a = l4, bb = ij;
+    for (int k = 0; k + 4 * g < Ln; ++k) {
+      if (k > 0) {
+        const int ra = k - 1 + dl[sl];                                      // (rows past the walk: entries that are no longer stored)
+        acc[sl] = __builtin_amdgcn_mfma_f64_4x4x4f64(sga * xsel[(ra < nw ? ra : nw - 1) * nch + ij], sgb * xsel[(k - 1) * nch + ij], acc[sl], 0, 0, 0);
+      }
+      if (k + d < Ln && (d > 0 || a >= bb)) {
+        const int hi = (k + d) * nch + a, lo = k * nch + bb;
+        G[prl[lo] + ipl[hi]] = acc[sl];
+        if ((hi >> 4) == (lo >> 4)) G[prl[hi] + ipl[lo]] = acc[sl];
+      }
+    }
+  }
+}
+
 // grid.x of the two (a workgroup's four waves own RR2_SL lags -- groups of 16 / nch lags -- each)
 inline unsigned rr2_gram_grid(int Ln, int nch) {
   const int groups = nch <= 8 ? (Ln + 16 / nch - 1) / (16 / nch) : Ln;
