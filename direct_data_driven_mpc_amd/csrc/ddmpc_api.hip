@@ -965,7 +965,7 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)status, 4, (size_t)h->batch, h->stream));
     return DDMPC_OK;
   }
-  if (h->large && h->prm.weight_kind != DDMPC_WEIGHT_DENSE && h->large_pipeline == DDMPC_PIPELINE_PHASES && h->batch <= 65535 && !h->stamps_on) {
+  if (h->large && h->large_pipeline == DDMPC_PIPELINE_PHASES && h->batch <= 65535 && !h->stamps_on) {
     // ... on the phase kernels (ddmpc_rr3.hpp): lock-step factorisation of the whole batch, then one workgroup per instance
     // that streams the factor twice and runs the active-set iterations on its trailing block
     if (large_mode != 2 && (rc = launch_rr3_factors(h))) return rc;

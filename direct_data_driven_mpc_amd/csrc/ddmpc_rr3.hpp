@@ -52,11 +52,38 @@ struct Rr3 {
 enum : int { R3_X = 0 /* beta, component order: what the Hankel kernel reads */, R3_BETA /* position order */, R3_T0, R3_NV };
 
 // ---------------------------------------------------------------------------------------------------------------
-// + lam D0 on the diagonal of the permuted Gram matrix (the Gram kernel wrote G itself).  grid = batch, 256 threads.
+// + lam D0 on the diagonal of the permuted Gram matrix (the Gram kernel wrote G itself); dense weighting matrices
+// (controller.py:708-710): + lam W^-1 on every pair of components (P.dmat, component order, shared by the batch -- L2).
+// grid = batch, 256 threads.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rr3_shift_kernel(KParams P, int RPs, const int* __restrict__ perm, double* __restrict__ ws, long long stride) {
   double* G = ws + blockIdx.x * stride;
   for (int i = threadIdx.x; i < P.r; i += blockDim.x) G[pk_row((size_t)i) + i] += P.lam * P.tabd[0 * RPs + perm[i]];
+  if (P.dense_w) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
+    for (int i = wave; i < P.r; i += nwave) {                               // a wave per row: its lanes on consecutive columns
+      const double* dr = P.dmat + (long long)perm[i] * RPs;
+      double* Gi = G + pk_row((size_t)i);
+      for (int j = lane; j <= i; j += 64) Gi[j] += P.lam * dr[perm[j]];
+    }
+  }
+}
+
+// Dense weighting matrices: out[rho] = (W^-1 x)[rho] for x in COMPONENT order (LDS), a wave per row with its lanes on consecutive
+// columns of P.dmat (coalesced, from L2: the matrix is shared by the batch).  All threads of the workgroup; no barrier inside.
+__device__ __forceinline__ void rr3_dense_times(const KParams& P, int RPs, const double* xc, double* out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = blockDim.x >> 6, r = P.r;
+  for (int rho = wave; rho < r; rho += nwave) {
+    const double* dr = P.dmat + (long long)rho * RPs;
+    double s0 = 0.0, s1 = 0.0;
+    int c = lane;
+    for (; c + 64 < r; c += 128) { s0 = fma(dr[c], xc[c], s0); s1 = fma(dr[c + 64], xc[c + 64], s1); }
+    if (c < r) s0 = fma(dr[c], xc[c], s0);
+    double sacc = s0 + s1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
+    if (lane == 0) out[rho] = sacc;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -384,11 +411,19 @@ __device__ __forceinline__ void rr3_small_solve(const double* Sm, int k, const d
 __device__ __forceinline__ void rr3_outputs(const KParams& P, int RPs, const Rr3& S, long long b, const int* perm, const double* tv, const double* bv,
                                             const int* act, int st, int iter, double* red, double* __restrict__ u_opt, double* __restrict__ cost,
                                             int* __restrict__ status, int* __restrict__ iters, double* __restrict__ beta_ws,
-                                            signed char* __restrict__ act_ws) {
+                                            signed char* __restrict__ act_ws, double* wa, double* wb) {
+  // wa, wb: two LDS vectors of r doubles that are free by now (dense weighting matrices: beta in component order, W^-1 beta)
   const int tid = threadIdx.x, nthr = blockDim.x, r = P.r;
   const int n = P.npu / P.m;
   double part = 0.0, bad = 0.0;
   double* uo = u_opt + b * (long long)((P.Ln - n) * P.m);
+  if (st == 0 && P.dense_w) {                                               // (kernel-uniform)
+    __syncthreads();
+    for (int i = tid; i < r; i += nthr) wa[perm[i]] = bv[i];
+    __syncthreads();
+    rr3_dense_times(P, RPs, wa, wb);
+    __syncthreads();
+  }
   if (st == 0) {
     for (int i = tid; i < r; i += nthr) {
       const int rho = perm[i];
@@ -396,13 +431,19 @@ __device__ __forceinline__ void rr3_outputs(const KParams& P, int RPs, const Rr3
       const double bb = bv[i];
       const double D = s_act ? P.tabd[1 * RPs + rho] : P.tabd[0 * RPs + rho];
       const double t = tv[i] + s_act * P.bound;
-      const double z = t - P.lam * D * bb;
+      const double z = t - P.lam * (D * bb + (P.dense_w ? wb[rho] : 0.0));
       const double wq = P.tabd[3 * RPs + rho];
       const double tb = P.tabd[2 * RPs + rho];
       const int oidx = P.tabi[2 * RPs + rho];
       const int kind = P.tabi[0 * RPs + rho];
       if (!(fabs(bb) < 1e300)) bad = 1.0;
       double contrib = P.lam * bb * z;
+      if (P.dense_w && (kind == K_UFREE || kind == K_YFREE || kind == K_WPRED)) {
+        // (z - t)' W (z - t) summed over the weighted components equals -lam beta' (z - t); a sigma held at its bound adds
+        // lamb_sigma bound^2 (as in ddmpc_large_solve_kernel and the register-resident kernels)
+        contrib -= P.lam * bb * (z - t);
+        if (s_act != 0) contrib += P.box_cost;
+      } else
       if (kind == K_UFREE || kind == K_YFREE) { const double dlt = z - tb; contrib += wq * dlt * dlt; }
       else if (kind == K_WINT) { const double sg = z - tv[i]; contrib += P.lamb_sigma * sg * sg; }
       else if (kind == K_WTERM) { const double sg = z - tb; contrib += P.lamb_sigma * sg * sg; }
@@ -618,7 +659,7 @@ __global__ __launch_bounds__(RR2_TS, 4) void rr3_solve_kernel(Rr3 S, KParams P, 
     }
     if (!defer_outputs || st != 0) {
       __syncthreads();
-      rr3_outputs(P, RPs, S, b, perm, tv, bv, act, st == 5 ? 4 : st, iter, tmp, u_opt, cost, status, iters, beta_ws, act_ws);
+      rr3_outputs(P, RPs, S, b, perm, tv, bv, act, st == 5 ? 4 : st, iter, tmp, u_opt, cost, status, iters, beta_ws, act_ws, y2, yv);
       __syncthreads();
       if (tid == 0 && st == 5) status[b] = 5;                             // (host: finished by ddmpc_large_solve_kernel)
     }
@@ -631,6 +672,12 @@ __global__ __launch_bounds__(RR2_TS, 4) void rr3_solve_kernel(Rr3 S, KParams P, 
     const double* vbeta = Vb + (size_t)R3_BETA * S.VL;
     const double* vt0 = Vb + (size_t)R3_T0 * S.VL;
     const double* zp = S.ZP + b * RR2_NG * (long long)S.VL;
+    if (P.dense_w) {                                                      // (kernel-uniform) yv := W^-1 beta, component order
+      for (int i = tid; i < r; i += nthr) y2[perm[i]] = vbeta[i];
+      __syncthreads();
+      rr3_dense_times(P, RPs, y2, yv);
+      __syncthreads();
+    }
     for (int i = tid; i < LD.VL; i += nthr) {
       double bb = 0.0, t0 = 0.0, rho_v = 0.0;
       int a = 0;
@@ -641,9 +688,9 @@ __global__ __launch_bounds__(RR2_TS, 4) void rr3_solve_kernel(Rr3 S, KParams P, 
 #pragma unroll
         for (int g = 0; g < RR2_NG; ++g) hz += zp[g * (long long)S.VL + rho];
         const double D = a ? P.tabd[1 * RPs + rho] : P.tabd[0 * RPs + rho];
-        rho_v = (t0 + a * P.bound) - hz - P.lam * D * bb;
+        rho_v = (t0 + a * P.bound) - hz - P.lam * (D * bb + (P.dense_w ? yv[rho] : 0.0));
       }
-      tv[i] = t0; bv[i] = bb; act[i] = a; y2[i] = rho_v;
+      tv[i] = t0; bv[i] = bb; act[i] = a; y2[i] = rho_v;                  // (dense: y2 = beta in component order has been consumed)
     }
     __syncthreads();
     rr3_trsv_fwd<1>(G, m64, r, live, 0, [&](int, int i) { return y2[i]; }, [&](int) { return yv; }, tmp);     // y_rho
@@ -657,7 +704,7 @@ __global__ __launch_bounds__(RR2_TS, 4) void rr3_solve_kernel(Rr3 S, KParams P, 
     rr3_trsv_bwd(G, m64, r, live, nb, 0, yv, y2, red, tmp);                                                   // delta
     for (int i = tid; i < r; i += nthr) bv[i] += y2[i];
     __syncthreads();
-    rr3_outputs(P, RPs, S, b, perm, tv, bv, act, 0, iter, tmp, u_opt, cost, status, iters, beta_ws, act_ws);
+    rr3_outputs(P, RPs, S, b, perm, tv, bv, act, 0, iter, tmp, u_opt, cost, status, iters, beta_ws, act_ws, y2, yv);
   }
 }
 

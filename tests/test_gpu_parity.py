@@ -401,10 +401,13 @@ def test_robust_scheme_beyond_the_register_resident_kernels(gpu, slack):
             _engine(orc.spec_from_params(L=300, N=1000), 1000, 1)
 
 
+@pytest.mark.parametrize("pipeline", ["phases", "one_workgroup"])
 @pytest.mark.parametrize("slack", [0, 1], ids=["none", "convex"])
-def test_dense_weighting_matrices_beyond_the_register_resident_kernels(gpu, slack):
-    # dense SPD Q, R (controller.py:121-124,708-710) at 296 rows: ddmpc_large_solve_kernel adds lam * W^-1 to the whole
-    # Gram matrix, the slack box still only switches diagonal entries; outputs and variables against the full-space oracle
+def test_dense_weighting_matrices_beyond_the_register_resident_kernels(gpu, slack, pipeline):
+    # dense SPD Q, R (controller.py:121-124,708-710) at 296 rows: lam * W^-1 is added to the whole Gram matrix (rr3_shift_kernel of
+    # the phase pipeline since round 5, ddmpc_large_solve_kernel on the one-workgroup pipeline), the slack box still only switches
+    # diagonal entries -- the Woodbury updates of the phase pipeline are unchanged --, z = t - lam W^-1 beta is a product with the
+    # matrix shared by the batch; outputs and variables against the full-space oracle
     spec = orc.spec_from_params(L=70, N=1200, slack_var_constraint_type=slack)
     rng = np.random.default_rng(12)
     spec.Q = _spd(rng, spec.p * spec.L, 3.0, 3)
@@ -413,9 +416,13 @@ def test_dense_weighting_matrices_beyond_the_register_resident_kernels(gpu, slac
     u_d, y_d, up, yp = _instances(B, N=1200, seed0=31)
     with _engine(spec, 1200, B) as eng:
         assert "large_solve" in eng.kernel_name()
+        eng.set_large_pipeline(pipeline)
         eng.set_data(u_d, y_d)
         u, cost, status, iters = eng.solve(up, yp)
         sg = eng.get_solution("sigma"); yb = eng.get_solution("ybar"); ub = eng.get_solution("ubar")
+        eng.set_data(u_d, y_d)
+        uw = eng.step(up, yp)                             # (the solve on the kept factors)
+    assert np.array_equal(uw[0], u) and np.array_equal(uw[2], status)
     _check(spec, u_d, y_d, up, yp, u, cost, status, range(B))
     for b in range(B):
         ref = orc.solve_fullspace(spec, u_d[b], y_d[b], up[b], yp[b])
