@@ -9,7 +9,7 @@ has a unique [ubar; ybar] but no unique alpha when H is rank-deficient.  This so
 orthogonal factorisations only (SVD of H for a basis of its range, SVD of the constraint block for its null
 space, least squares for the rest) -- deliberately a different route from the Gram/Cholesky one the GPU
 kernels take.  Parity unpinned against the reference (cvxpy absent), like the rest of the QP oracle.
-Diagonal Q, R only."""
+solve_nominal_exact: diagonal Q, R only; solve_nominal_model_based also takes dense ones."""
 from __future__ import annotations
 
 import numpy as np
@@ -105,6 +105,8 @@ def solve_nominal_model_based(spec, plant, u_past, y_past, _parts=False):
     u_s = np.asarray(spec.u_s, float).reshape(-1); y_s = np.asarray(spec.y_s, float).reshape(-1)
     u_past = np.asarray(u_past, float).reshape(-1); y_past = np.asarray(y_past, float).reshape(-1)
     rdiag, qdiag = np.diag(spec.R), np.diag(spec.Q)
+    Rm, Qm = np.asarray(spec.R, float), np.asarray(spec.Q, float)
+    dense = not (np.array_equal(Rm, np.diag(rdiag)) and np.array_equal(Qm, np.diag(qdiag)))
     M = np.zeros((Ln * (m + p), ns + Ln * m))
     for k in range(Ln):
         M[k * m:(k + 1) * m, ns + k * m: ns + (k + 1) * m] = np.eye(m)
@@ -115,28 +117,45 @@ def solve_nominal_model_based(spec, plant, u_past, y_past, _parts=False):
         M[Ln * m + k * p: Ln * m + (k + 1) * p, :ns] = O[k]
         for j in range(k):
             M[Ln * m + k * p: Ln * m + (k + 1) * p, ns + j * m: ns + (j + 1) * m] = O[k - 1 - j] @ B_
-    F, R, f, W, zs, fmap = [], [], [], [], [], []
+    F, R, f, W, zs, fmap, widx = [], [], [], [], [], [], []
     for k in range(Ln):
         kp = k - n
         for ch in range(m):
             i = k * m + ch
             if kp < 0: F.append(i); f.append(u_past[k * m + ch]); fmap.append(("u", k * m + ch))
             elif spec.tec and kp >= Lh - n: F.append(i); f.append(u_s[ch]); fmap.append(("s", 0))
-            else: R.append(i); W.append(rdiag[kp * m + ch]); zs.append(u_s[ch])
+            else: R.append(i); W.append(rdiag[kp * m + ch]); zs.append(u_s[ch]); widx.append(("R", kp * m + ch))
     for k in range(Ln):
         kp = k - n
         for ch in range(p):
             i = Ln * m + k * p + ch
             if kp < 0: F.append(i); f.append(y_past[k * p + ch]); fmap.append(("y", k * p + ch))
             elif spec.tec and kp >= Lh - n: F.append(i); f.append(y_s[ch]); fmap.append(("s", 0))
-            else: R.append(i); W.append(qdiag[kp * p + ch]); zs.append(y_s[ch])
+            else: R.append(i); W.append(qdiag[kp * p + ch]); zs.append(y_s[ch]); widx.append(("Q", kp * p + ch))
     f, W, zs = np.array(f), np.array(W), np.array(zs)
+    Wd = None
+    if dense:
+        # dense weighting matrices (controller.py:708-710): the weight of the free components as one matrix (inputs and outputs do
+        # not mix), and a square-root factor of it for the least-squares form (eigendecomposition: W may be singular)
+        Wd = np.zeros((len(R), len(R)))
+        for a_, (ka, ia) in enumerate(widx):
+            for b_, (kb, ib) in enumerate(widx):
+                if ka == kb: Wd[a_, b_] = (Rm if ka == "R" else Qm)[ia, ib]
+        ev, Ev = np.linalg.eigh(Wd)
+        Wh = (Ev * np.sqrt(np.clip(ev, 0.0, None))).T                               # Wh' Wh = Wd
     Qb, _ = np.linalg.qr(M)
     Uf, Sf, Vft = np.linalg.svd(Qb[F], True)
     kf = int(np.sum(Sf > Sf[0] * 1e-9))
     if _parts:
+        if dense:
+            raise NotImplementedError("solve_nominal_model_based_batch takes diagonal Q, R")
         return dict(Qb=Qb, F=F, R=R, W=W, zs=zs, Uf=Uf, Sf=Sf, Vft=Vft, kf=kf, fmap=fmap, f=f)
     c_p = Vft[:kf].T @ ((Uf[:, :kf].T @ f) / Sf[:kf]); Nn = Vft[kf:].T
+    if dense:
+        dd = np.linalg.lstsq(Wh @ (Qb[R] @ Nn), Wh @ (zs - Qb[R] @ c_p), rcond=None)[0]
+        z = Qb @ (c_p + Nn @ dd)
+        dz = z[R] - zs
+        return dict(optimal_u=z[:Ln * m][n * m:], cost=float(dz @ Wd @ dz), feas_residual=float(np.max(np.abs(Qb[F] @ c_p - f))))
     sw = np.sqrt(W)
     dd = np.linalg.lstsq(sw[:, None] * (Qb[R] @ Nn), sw * (zs - Qb[R] @ c_p), rcond=None)[0]
     z = Qb @ (c_p + Nn @ dd)

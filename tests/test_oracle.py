@@ -270,3 +270,34 @@ def test_slack_box_as_rank_k_update_of_the_first_factor():
         D, t = component_tables(spec, up, yp, act)
         z = t - lam * D * beta
         assert np.max(np.abs(z[n * m:Ln * m] - sol.optimal_u)) <= 1e-10 * np.max(np.abs(sol.optimal_u))
+
+
+def test_model_based_nominal_oracle_with_dense_weighting_matrices():
+    """controller.py:708-710 takes any PSD Q, R.  The model-based restatement of the NOMINAL QP on exact data (oracle/nominal_exact.py:
+    the yardstick of the kernels beyond 271 rows) with dense matrices: against the full-space KKT oracle on a small exact-data case,
+    and its dense code path against the diagonal one on diagonal matrices."""
+    from oracle.nominal_exact import solve_nominal_model_based
+    from direct_data_driven_mpc_amd.harness import generate_batch
+    rng = np.random.default_rng(3)
+    n, m, p, Lh = 2, 2, 2, 10
+    A = rng.normal(size=(n, n)); A *= 0.8 / max(abs(np.linalg.eigvals(A)))
+    plant = dict(A=A, B=rng.normal(size=(n, m)), C=rng.normal(size=(p, n)), D=np.zeros((p, m)), eps_max=0.0)
+    u_s = 0.1 * np.ones(m); y_s = (plant["C"] @ np.linalg.inv(np.eye(n) - A) @ plant["B"]) @ u_s
+
+    def spd(k, s):
+        X = rng.normal(size=(k, k))
+        return s * (np.eye(k) + 0.1 * (X @ X.T) / k)
+    Q, R = spd(p * Lh, 3.0), spd(m * Lh, 0.05)
+    mk = lambda Q_, R_: orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=Q_, R=R_, u_s=u_s, y_s=y_s, robust=False, eps_max=0.0, lamb_alpha=0.0,
+                                   lamb_sigma=0.0, c=0.0, slack="none", tec=True)
+    d = generate_batch(range(1), N=120, plant=plant)
+    up = d["u_d"][0, -n:, :].reshape(-1); yp = d["y_d"][0, -n:, :].reshape(-1)
+    mod = solve_nominal_model_based(mk(Q, R), plant, up, yp)
+    fs = orc.solve_fullspace(mk(Q, R), d["u_d"][0], d["y_d"][0], up, yp)
+    assert fs.status == "optimal" and mod["feas_residual"] < 1e-10
+    assert np.max(np.abs(mod["optimal_u"] - fs.optimal_u)) / np.max(np.abs(fs.optimal_u)) < 1e-9
+    assert abs(mod["cost"] - fs.cost) / abs(fs.cost) < 1e-9
+    Qd, Rd = np.diag(np.diag(Q)), np.diag(np.diag(R))
+    a = solve_nominal_model_based(mk(Qd, Rd), plant, up, yp)
+    b = solve_nominal_model_based(mk(Qd + 1e-300, Rd), plant, up, yp)       # (not diagonal to the letter: the dense path)
+    assert np.max(np.abs(a["optimal_u"] - b["optimal_u"])) < 1e-12 and abs(a["cost"] - b["cost"]) < 1e-12 * max(1.0, abs(a["cost"]))
