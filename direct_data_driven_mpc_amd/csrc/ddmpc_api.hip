@@ -192,6 +192,8 @@ struct ddmpc_handle {
   int ld_window = 0;                       // long_data: doubles of the trajectory window the refining variant stages chunk by chunk
   size_t ld_lds_bytes = 0;                 // ... and the LDS of such a launch
   bool long_data = false;                  // the trajectory does not fit the cold kernel's LDS: streaming Gram + gpre, no refinement (KParams::stage_xs = 0)
+  DevBuf d_wd, d_rr2y;                     // dense weighting matrices of a NOMINAL controller beyond 271 rows: W of the free components (position
+                                           //   order, shared by the batch); Y = W C per instance (rr2_wc_kernel)
   DevBuf d_rr2tol, d_rr2rank;              // ... per-instance pivot tolerance and [flag, accepted pivots] of the rank decision (+ one counter word)
   DevBuf d_rr2cand;                        // ... the pivot candidates of G's factorisation as they were met (Rr2Chol::cand)
   DevBuf d_perm, d_rr2d, d_rr2res;                   // phase kernels (ddmpc_rr2.hpp): fixed-first component order [perm | iperm]; per instance
@@ -358,6 +360,27 @@ static int upload_params(ddmpc_handle* h) {
     for (int i = 0; i + h->nF < k.r; ++i) { wz[i] = td[3 * (size_t)RP + pm[h->nF + i]]; wz[rv + i] = td[2 * (size_t)RP + pm[h->nF + i]]; }
     if ((rc = h->d_wz.ensure(wz.size() * sizeof(double)))) return rc;
     HIP_TRY(hipMemcpy(h->d_wz.p, wz.data(), wz.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (dense) {
+      // W of the free components in position order (controller.py:708-710: R couples the inputs of the prediction steps, Q the
+      // outputs, nothing couples the two), nR x nR row-major, shared by the batch
+      const size_t nR = (size_t)k.r - (size_t)h->nF;
+      std::vector<double> wd(nR * nR, 0.0);
+      const int ml = p.m * p.L, pl = p.p * p.L;
+      auto widx = [&](int rho, bool& is_u) -> int {                  // row of R (inputs) or Q (outputs) of component rho
+        const int kk = rho / k.nch, ch = rho % k.nch, kp = kk - p.n;
+        is_u = ch < p.m;
+        return is_u ? kp * p.m + ch : kp * p.p + (ch - p.m);
+      };
+      for (size_t i = 0; i < nR; ++i) {
+        bool ui; const int ai = widx(pm[h->nF + i], ui);
+        for (size_t j = 0; j < nR; ++j) {
+          bool uj; const int aj = widx(pm[h->nF + j], uj);
+          if (ui == uj) wd[i * nR + j] = ui ? h->Rh[(size_t)ai * ml + aj] : h->Qh[(size_t)ai * pl + aj];
+        }
+      }
+      if ((rc = h->d_wd.ensure(wd.size() * sizeof(double)))) return rc;
+      HIP_TRY(hipMemcpy(h->d_wd.p, wd.data(), wd.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
   }
   if (h->large && !h->large_nominal) {
     // ROBUST beyond the register-resident kernels on the phase kernels (ddmpc_rr3.hpp): the components the slack box acts on
@@ -551,11 +574,8 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
     // global-workspace kernels (plain VALU code): ROBUST controllers by
     // ddmpc_large_solve_kernel, NOMINAL ones by the rank-revealing kernel (accurate only to the extent the Gram
     // route allows at that size).  Dense weights are unsupported here.
-    if (p.weight_kind == DDMPC_WEIGHT_DENSE && p.controller_type != DDMPC_ROBUST) {
-      delete h;
-      return fail(DDMPC_ERR_UNSUPPORTED, "problem too large for the single-workgroup kernels: (m+p)(L+n) = %d rows "
-                  "(dense weighting matrices of a NOMINAL controller are limited to 271 rows)", k.r);
-    }
+    // (dense weighting matrices of a NOMINAL controller at this size: phase kernels only -- rr2_wc_kernel / rr2_wapply_kernel --,
+    //  the one-workgroup pipeline refuses them in ddmpc_set_option)
     {   // r-vectors and the Cholesky panel of the global-workspace kernels live in LDS (launch_cold / launch_nominal_rescue)
       const size_t rv = ((size_t)k.r + 1) & ~(size_t)1;
       const size_t lds = 10 * rv * sizeof(double) + 4 * rv * sizeof(int) + (size_t)PSD_PAN * sizeof(double);
@@ -683,7 +703,7 @@ int ddmpc_destroy(ddmpc_handle* h) {
   DevBuf* bufs[] = {&h->d_tabd, &h->d_tabi, &h->d_ud, &h->d_yd, &h->d_up, &h->d_yp, &h->d_uopt,
                     &h->d_cost, &h->d_status, &h->d_iters, &h->d_beta, &h->d_act, &h->d_out, &h->d_stamps,
                     &h->d_pl, &h->d_x, &h->d_w, &h->d_usys, &h->d_ysys, &h->d_stacc,
-                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_gpre, &h->d_perm, &h->d_rr2d, &h->d_rr2res, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz, &h->d_gz, &h->d_gres, &h->d_zvirt, &h->d_rr3w, &h->d_rr3k, &h->d_rr_fb, &h->d_rrmeta_fb, &h->d_rr2cand, &h->d_rr2tol, &h->d_rr2rank};
+                    &h->d_lfac, &h->d_lfacT, &h->d_gain, &h->d_prep_status, &h->d_zero, &h->d_dmat, &h->d_need, &h->d_io, &h->d_rr, &h->d_alpha, &h->d_zws, &h->d_resc, &h->d_xws, &h->d_rflag, &h->d_rrmeta, &h->d_gpre, &h->d_perm, &h->d_rr2d, &h->d_rr2res, &h->d_rr2mt, &h->d_rr2v, &h->d_rr2zp, &h->d_rr2sc, &h->d_wz, &h->d_gz, &h->d_gres, &h->d_zvirt, &h->d_rr3w, &h->d_rr3k, &h->d_rr_fb, &h->d_rrmeta_fb, &h->d_rr2cand, &h->d_rr2tol, &h->d_rr2rank, &h->d_wd, &h->d_rr2y};
   for (DevBuf* b : bufs) b->release();
   h->h_io.release();
   h->h_flag.release();
@@ -1099,7 +1119,7 @@ static int launch_rr2_solve(ddmpc_handle* h, double* scratch, long long ndbl, co
                             double* cost, int32_t* status, int32_t* iters, double feas_tol);
 static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double* yp, double* uo, double* cost,
                                  int32_t* status, int32_t* iters, int rr_mode = 0) {
-  if (h->prm.controller_type != DDMPC_NOMINAL || h->prm.weight_kind == DDMPC_WEIGHT_DENSE) return DDMPC_OK;
+  if (h->prm.controller_type != DDMPC_NOMINAL || (h->prm.weight_kind == DDMPC_WEIGHT_DENSE && !h->large_nominal)) return DDMPC_OK;
   const size_t r = (size_t)h->kp.r, nR = (size_t)h->n_free;
   size_t ndbl = pk_size(r) + pk_size(nR);                         // packed rows on 128-byte boundaries (ddmpc_aux_kernels.hpp)
   const size_t rv = (r + 1) & ~(size_t)1;
@@ -1150,11 +1170,15 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
   if (!scratch) rcl = launch(ddmpc_nominal_rr_kernel<0>);                 // matrices in LDS: one launch
   else {                                                                  // global workspace: factors, then the solve on them
     const bool phases = h->large_pipeline == DDMPC_PIPELINE_PHASES && h->large_nominal && h->batch <= 65535 && !h->stamps_on;
+    const bool wdense = h->prm.weight_kind == DDMPC_WEIGHT_DENSE;
+    if (wdense && !phases)
+      return fail(DDMPC_ERR_UNSUPPORTED, "dense weighting matrices of a NOMINAL controller beyond 271 rows run on the phase kernels only "
+                  "(batches up to 65535, no diagnostic stamps)");
     if (rr_mode != 2) rcl = phases ? launch_rr2_factors(h, scratch, (long long)ndbl, 1e-8) : launch(ddmpc_nominal_rr_kernel<1>);
     if (!rcl && rr_mode != 1) {
       h->rr2_x_pending = false;
       rcl = phases ? launch_rr2_solve(h, scratch, (long long)ndbl, up, yp, uo, cost, status, iters, 1e-7) : launch(ddmpc_nominal_rr_kernel<2>);
-      if (!rcl && phases && h->kp.refine_max > 1) rcl = launch(ddmpc_nominal_rr_kernel<2>);      // the instances the phase solve marked 4 (more passes)
+      if (!rcl && phases && h->kp.refine_max > 1 && !wdense) rcl = launch(ddmpc_nominal_rr_kernel<2>);      // the instances the phase solve marked 4 (more passes)
     }
   }
   if (rcl) return rcl;
@@ -1211,11 +1235,20 @@ static int launch_rr2_factors(ddmpc_handle* h, double* scratch, long long ndbl, 
     hipLaunchKernelGGL(rr2_meta_kernel, dim3((unsigned)B), dim3(256), 0, h->stream, meta, mstride, rv, r, nF, nR);
     if (nR > 0) {
       const int ldw = ((nR16 + 31) / 32) * 32 + 16;                         // LDS row of the C'WC kernel: 16 mod 32 doubles
-      const size_t cwlds = ((size_t)16 * ldw + 16) * sizeof(double);
+      const size_t cwlds = ((size_t)(h->d_wd.p ? 32 : 16) * ldw + 16) * sizeof(double);
       if (cwlds > 64 * 1024)
         HIP_TRY(raise_lds_limit((const void*)rr2_cwc_kernel, cwlds));
+      const double* Yd = nullptr;
+      const long long ystride = (long long)nR16 * nR16;
+      if (h->d_wd.p) {                                      // dense weighting matrices: Y = W C first
+        int rcy = h->d_rr2y.ensure(B * (size_t)ystride * sizeof(double));
+        if (rcy) return rcy;
+        Yd = (const double*)h->d_rr2y.p;
+        hipLaunchKernelGGL(rr2_wc_kernel, dim3((unsigned)(nR16 / 16), (unsigned)B), dim3(256), 0, h->stream, (const double*)h->d_wd.p, (const double*)scratch,
+                           ndbl, (const int*)meta, mstride, rv, nF, nR, (double*)h->d_rr2y.p, ystride, nR16);
+      }
       hipLaunchKernelGGL(rr2_cwc_kernel, dim3((unsigned)B), dim3(1024), cwlds, h->stream, k, 16 * h->kc.NT, perm, scratch, ndbl,
-                         (long long)pk_size((size_t)n16), (const int*)meta, mstride, rv, nF, nR, dd + 1, ldw);
+                         (long long)pk_size((size_t)n16), (const int*)meta, mstride, rv, nF, nR, dd + 1, ldw, Yd, ystride, nR16);
       Rr2Chol FT{};
       FT.ws = scratch; FT.stride = ndbl; FT.off = (long long)pk_size((size_t)n16); FT.n16 = nR16;
       FT.n_inst = meta + 2 * rv + 1; FT.n_stride = mstride;
@@ -1288,6 +1321,7 @@ static int rr2_solve_desc(ddmpc_handle* h, double* scratch, long long ndbl, Rr2S
   S.dd = (const unsigned long long*)h->d_rr2d.p;
   S.perm = (const int*)h->d_perm.p;
   S.wz = (const double*)h->d_wz.p;
+  S.wd = (const double*)h->d_wd.p;
   S.rankrec = (const int*)h->d_rr2rank.p;
   S.noise = h->d_rr2tol.p ? (const double*)h->d_rr2tol.p + h->batch : nullptr;
   S.V = (double*)h->d_rr2v.p; S.vstride = (long long)V_NV * VL; S.VL = VL;
@@ -1328,6 +1362,7 @@ static int rr2_solve_sequence(ddmpc_handle* h, const Rr2Solve& S, unsigned B, co
   };
   hipLaunchKernelGGL(rr2_s1_kernel, dim3(B), dim3(RR2_TS), 0, st, S, k, RPs, up, yp);
   hipLaunchKernelGGL(rr2_rows_kernel<0>, dim3(grp(nF + nR, 32), B), dim3(256), 0, st, S, k, RPs, (double*)nullptr, (double*)nullptr, 0);
+  if (S.wd) hipLaunchKernelGGL(rr2_wapply_kernel<0>, dim3(B), dim3(RR2_TS), 0, st, S, 0);
   hipLaunchKernelGGL(rr2_cols_kernel<0>, dim3(grp(nR, 64), B), dim3(512), 0, st, S, 0);
   {
     // one refinement pass for everybody; an instance whose correction says another pass would still pay (rr2_s13_kernel: the
@@ -1336,15 +1371,20 @@ static int rr2_solve_sequence(ddmpc_handle* h, const Rr2Solve& S, unsigned B, co
     hipLaunchKernelGGL(rr2_s4_kernel, dim3(B), dim3(RR2_TS), 0, st, S, pass);
     hankel((int)V_X, pass);
     hipLaunchKernelGGL(rr2_rows_kernel<1>, dim3(grp(nR, 32), B), dim3(256), 0, st, S, k, RPs, (double*)nullptr, (double*)nullptr, pass);
+    if (S.wd) hipLaunchKernelGGL(rr2_wapply_kernel<1>, dim3(B), dim3(RR2_TS), 0, st, S, pass);
     hipLaunchKernelGGL(rr2_cols_kernel<1>, dim3(grp(nF, 64), B), dim3(512), 0, st, S, pass);
     hipLaunchKernelGGL(rr2_s8_kernel, dim3(B), dim3(RR2_TS), 0, st, S, pass);
     hankel((int)V_VC, pass);
     hipLaunchKernelGGL(rr2_rows_kernel<2>, dim3(grp(nR, 32), B), dim3(256), 0, st, S, k, RPs, (double*)nullptr, (double*)nullptr, pass);
     hipLaunchKernelGGL(rr2_s11_kernel, dim3(B), dim3(RR2_TS), 0, st, S, pass);
+    if (S.wd) hipLaunchKernelGGL(rr2_wapply_kernel<2>, dim3(B), dim3(RR2_TS), 0, st, S, pass);
     hipLaunchKernelGGL(rr2_cols_kernel<2>, dim3(grp(nR, 64), B), dim3(512), 0, st, S, pass);
-    hipLaunchKernelGGL(rr2_s13_kernel, dim3(B), dim3(RR2_TS), 0, st, S, pass, k.refine_max);
+    // (dense weighting matrices: no instance is handed to ddmpc_nominal_rr_kernel<2> for further passes -- that kernel knows
+    //  diagonal weights only)
+    hipLaunchKernelGGL(rr2_s13_kernel, dim3(B), dim3(RR2_TS), 0, st, S, pass, S.wd ? 1 : k.refine_max);
   }
   hipLaunchKernelGGL(rr2_rows_kernel<3>, dim3(grp(nR, 32), B), dim3(256), 0, st, S, k, RPs, uo, zws, 0);
+  if (S.wd) hipLaunchKernelGGL(rr2_wapply_kernel<3>, dim3(B), dim3(RR2_TS), 0, st, S, 0);
   hipLaunchKernelGGL(rr2_s15_kernel, dim3(B), dim3(RR2_TS), 0, st, S, k, RPs, feas_tol, uo, cost, (int*)status, (int*)iters, zws, resc);
   HIP_TRY(hipGetLastError());
   return DDMPC_OK;
@@ -1838,6 +1878,8 @@ int ddmpc_set_option(ddmpc_handle* h, int option, int value) {
     case DDMPC_OPT_LARGE_PIPELINE:
       if (value != DDMPC_PIPELINE_ONE_WORKGROUP && value != DDMPC_PIPELINE_PHASES)
         return fail(DDMPC_ERR_INVALID, "pipeline must be DDMPC_PIPELINE_ONE_WORKGROUP or DDMPC_PIPELINE_PHASES");
+      if (value == DDMPC_PIPELINE_ONE_WORKGROUP && h->large_nominal && h->prm.weight_kind == DDMPC_WEIGHT_DENSE)
+        return fail(DDMPC_ERR_UNSUPPORTED, "dense weighting matrices of a NOMINAL controller beyond 271 rows run on the phase kernels only");
       h->large_pipeline = value;
       h->prepared = false;
       return DDMPC_OK;

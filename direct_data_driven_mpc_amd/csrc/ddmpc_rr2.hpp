@@ -845,6 +845,43 @@ __global__ __launch_bounds__(256) void rr2_meta_kernel(int* __restrict__ meta, l
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Dense weighting matrices: Y = W C for the lower-triangular block C(j, c) = L(nF + j, nF + c), c <= j < nR, leading ncol columns;
+// W (nR x nR, row-major, position order) is shared by the batch.  Y: [16 ceil(nR / 16)][ldy] doubles per instance, row-major.
+// grid = (row tiles of 16, batch), 256 threads: the four waves of a workgroup take the column tiles in turn; per tile one MFMA
+// chain over j from the tile's first column on (C is zero above its diagonal), both operands straight from global memory / L2.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rr2_wc_kernel(const double* __restrict__ Wd, const double* __restrict__ ws, long long stride,
+                                                     const int* __restrict__ meta, long long mstride, int rv, int nF, int nR,
+                                                     double* __restrict__ Y, long long ystride, int ldy) {
+  const long long b = blockIdx.y;
+  const int ncol = meta[b * mstride + 2 * rv + 1];
+  const int nct = (ncol + 15) >> 4;
+  const double* Lm = ws + b * stride;
+  double* Yb = Y + b * ystride;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = blockDim.x >> 6;
+  const int i0 = 16 * (int)blockIdx.x;
+  const int ia = (i0 + l15 < nR) ? i0 + l15 : nR - 1;                       // row of W this lane feeds (clamped: rows past nR are not stored)
+  const double* wr = Wd + (long long)ia * nR;
+  for (int ct = wave; ct < nct; ct += nwave) {
+    const int c0 = 16 * ct, cc = c0 + l15;
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+    for (int j0 = c0; j0 < nR; j0 += 4) {
+      const int j = j0 + l4;
+      const bool jok = j < nR;
+      const double a = jok ? wr[j] : 0.0;
+      const double bq = (jok && cc <= j && cc < ncol) ? Lm[pk_row((size_t)(nF + j)) + nF + cc] : 0.0;
+      acc = rr2_mfma(a, bq, acc);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + l4 + 4 * q;
+      Yb[(long long)i * ldy + cc] = (i < nR && cc < ncol) ? acc[q] : 0.0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // T = C' W C for the lower-triangular block C(i, a) = L(nF + i, nF + a), a <= i < nR, W = diag(w) (the cost weights of the free
 // components in the permuted order: tabd[3][perm[nF + i]]), leading nRl columns only; a skipped pivot has a zero column in L:
 // its row and column of T come out zero and the diagonal entry is set to one.  The rows [nRl, 16 ceil(nRl / 16)) are written
@@ -858,10 +895,15 @@ __global__ __launch_bounds__(256) void rr2_meta_kernel(int* __restrict__ meta, l
 constexpr int RR2_CW_TPW = 5;
 __global__ __launch_bounds__(1024) void rr2_cwc_kernel(KParams P, int RPs, const int* __restrict__ perm, double* __restrict__ ws,
                                                          long long stride, long long toff, const int* __restrict__ meta, long long mstride,
-                                                         int rv, int nF, int nR, unsigned long long* __restrict__ tmaxbits, int ldw) {
+                                                         int rv, int nF, int nR, unsigned long long* __restrict__ tmaxbits, int ldw,
+                                                         const double* __restrict__ Y, long long ystride, int ldy) {
+  // Y != nullptr: dense weighting matrices -- T = C' Y with Y = W C (rr2_wc_kernel, [nR16][ldy] per instance) instead of C' diag(w) C;
+  // a second staging buffer for the rows of Y
   extern __shared__ __attribute__((aligned(16))) double rr2_cb[];
   double* cb = rr2_cb;                                   // [16][ldw]
   double* wb = rr2_cb + 16 * ldw;                        // [16]
+  double* yb = wb + 16;                                  // [16][ldw] (dense only)
+  const double* Yb = Y ? Y + blockIdx.x * ystride : nullptr;
   const long long b = blockIdx.x;
   const int* mt = meta + b * mstride;
   const int ncol = mt[2 * rv + 1];
@@ -898,7 +940,12 @@ __global__ __launch_bounds__(1024) void rr2_cwc_kernel(KParams P, int RPs, const
         if (i < nR && cc <= i && cc < ncol) v = Lm[pk_row((size_t)(nF + i)) + nF + cc];
         cb[ii * ldw + cc] = v;
       }
-      if (tid < 16) wb[tid] = (i0 + tid < nR) ? P.tabd[3 * RPs + perm[nF + i0 + tid]] : 0.0;
+      if (tid < 16) wb[tid] = Y ? 1.0 : ((i0 + tid < nR) ? P.tabd[3 * RPs + perm[nF + i0 + tid]] : 0.0);
+      if (Y)
+        for (int e = tid; e < 16 * cw; e += nthr) {
+          const int ii = e / cw, cc = e - ii * cw;
+          yb[ii * ldw + cc] = (i0 + ii < nR && cc < ncol) ? Yb[(long long)(i0 + ii) * ldy + cc] : 0.0;
+        }
       __syncthreads();
 #pragma unroll
       for (int s = 0; s < RR2_CW_TPW; ++s) {
@@ -906,7 +953,7 @@ __global__ __launch_bounds__(1024) void rr2_cwc_kernel(KParams P, int RPs, const
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int k = l4 + 4 * e;
-          acc[s] = rr2_mfma(cb[k * ldw + 16 * tA[s] + l15] * wb[k], cb[k * ldw + 16 * tB[s] + l15], acc[s]);
+          acc[s] = rr2_mfma(cb[k * ldw + 16 * tA[s] + l15] * wb[k], (Y ? yb : cb)[k * ldw + 16 * tB[s] + l15], acc[s]);
         }
       }
     }

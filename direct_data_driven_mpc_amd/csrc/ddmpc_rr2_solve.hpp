@@ -26,7 +26,8 @@ constexpr int RR2_NG = 8;           // workgroups per instance in the Hankel pro
 
 // per-instance vectors in the global workspace (position order unless noted), RR2 vector length VL = r rounded up to 64
 enum : int { V_FV = 0, V_W1, V_Z0, V_VV, V_W2, V_WK, V_X /* component order */, V_RZ, V_RBR, V_RA, V_VC /* component order */,
-             V_RW, V_DW1, V_RDR, V_DW2, V_CP, V_RES /* f_i - L(i,:) w1 on the dependent fixed rows */, V_NV };
+             V_RW, V_DW1, V_RDR, V_DW2, V_CP, V_RES /* f_i - L(i,:) w1 on the dependent fixed rows */,
+             V_WV /* dense weighting matrices: W times a vector of the free components (rr2_wapply_kernel) */, V_NV };
 // per-instance scalars (doubles): [0] max(1, |f|)  [1] rel0  [2] prevrel  [3] cost;  ints: [0] more (another pass)  [1] passes done
 struct Rr2Solve {
   const double* ws; long long stride; long long toff;        // factor of G at +0, factor of T at +toff of an instance's slice
@@ -35,6 +36,8 @@ struct Rr2Solve {
   const unsigned long long* dd;                               // per instance [max diag G | max diag T | live chunks G | live chunks T]
   const int* perm;                                            // position -> component
   const double* wz;                                           // [w (rv) | zs (rv)]: cost weight and target of the free components, position order
+  const double* wd;                                           // dense weighting matrices (controller.py:708-710): W of the free components, position
+                                                              //   order, nR x nR row-major, shared by the batch (nullptr: the diagonal w above)
   double* V; long long vstride; int VL;                       // vectors
   double* ZP;                                                 // Hankel partial sums [batch][RR2_NG][VL], component order
   double* sc; int* si; unsigned long long* resid;             // scalars (4 doubles, 2 ints per instance), max residual of the dependent rows (bits)
@@ -262,13 +265,14 @@ __global__ __launch_bounds__(256) void rr2_rows_kernel(Rr2Solve S, KParams P, in
           if (mt[i]) atomicMax(S.resid + b, (unsigned long long)__double_as_longlong(fabs(res)));
         } else V[V_Z0 * VL + (i - nF)] = sacc;
       } else if (OP == 1) {
-        V[V_RBR * VL + i] = S.wz[i] * (V[V_Z0 * VL + i] + sacc - S.wz[S.rv + i]);
+        const double dz = V[V_Z0 * VL + i] + sacc - S.wz[S.rv + i];
+        V[V_RBR * VL + i] = S.wd ? dz : S.wz[i] * dz;                       // (dense: rr2_wapply_kernel<1> multiplies by W next)
       } else if (OP == 2) {
         V[V_RDR * VL + i] = sacc;
       } else {
         const double z = V[V_RZ * VL + nF + i] + V[V_RDR * VL + i] + sacc;
         const double dlt = z - S.wz[S.rv + i];
-        V[V_CP * VL + i] = S.wz[i] * dlt * dlt;
+        V[V_CP * VL + i] = S.wd ? dlt : S.wz[i] * dlt * dlt;               // (dense: rr2_wapply_kernel<3> turns it into dlt_i (W dlt)_i)
         const int rho = S.perm[nF + i];
         const int oidx = P.tabi[2 * RPs + rho];
         if (oidx >= 0 && u_opt) u_opt[b * (long long)((P.Ln - P.npu / P.m) * P.m) + oidx] = z;
@@ -304,7 +308,9 @@ __global__ __launch_bounds__(512) void rr2_cols_kernel(Rr2Solve S, int pass) {
   const int k0 = (int)blockIdx.x * 64;
   if (k0 >= ncols) return;
   for (int i = tid; i < nR; i += nthr)
-    vs[i] = (OP == 0) ? S.wz[i] * (S.wz[S.rv + i] - V[V_Z0 * VL + i]) : (OP == 1) ? V[V_RBR * VL + i] : S.wz[i] * V[V_RDR * VL + i];
+    vs[i] = (OP == 1) ? V[V_RBR * VL + i]
+            : S.wd ? V[V_WV * VL + i]                                       // dense: W (zs - z0) resp. W rdR, formed by rr2_wapply_kernel
+                   : (OP == 0) ? S.wz[i] * (S.wz[S.rv + i] - V[V_Z0 * VL + i]) : S.wz[i] * V[V_RDR * VL + i];
   __syncthreads();
   const int cl = tid & 63, rg = tid >> 6;
   const int k = k0 + cl;
@@ -589,9 +595,25 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s8_kernel(Rr2Solve S, int pass) {
   for (int i = tid; i < ((nF + 63) & ~63); i += nthr) { va[i] = (i < nF) ? V[V_RA * VL + i] : 0.0; vb[i] = 0.0; }
   __syncthreads();
   rr2_trsv_bwd(G, mG, nF, S.dd[4 * bf + 2], va, vb, red, tmp);               // vb = mu
-  for (int k = tid; k < r; k += nthr) {
-    const double v = (k < nF) ? (mt[k] ? 0.0 : vb[k]) : S.wz[k - nF] * (V[V_RZ * VL + k] - S.wz[S.rv + k - nF]);
-    V[V_VC * VL + S.perm[k]] = v;
+  if (S.wd) {                                                               // (kernel-uniform) dense weighting matrices: W (z_ex,R - zs)
+    const int nR = S.nR;
+    for (int i = tid; i < nR; i += nthr) red[i] = V[V_RZ * VL + nF + i] - S.wz[S.rv + i];
+    for (int k = tid; k < nF; k += nthr) V[V_VC * VL + S.perm[k]] = mt[k] ? 0.0 : vb[k];
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63, nwave = nthr >> 6;
+    for (int i = wave; i < nR; i += nwave) {
+      const double* wr = S.wd + (long long)i * nR;
+      double s0 = 0.0;
+      for (int c = lane; c < nR; c += 64) s0 = fma(wr[c], red[c], s0);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s0 += __shfl_xor(s0, off, 64);
+      if (lane == 0) V[V_VC * VL + S.perm[nF + i]] = s0;
+    }
+  } else {
+    for (int k = tid; k < r; k += nthr) {
+      const double v = (k < nF) ? (mt[k] ? 0.0 : vb[k]) : S.wz[k - nF] * (V[V_RZ * VL + k] - S.wz[S.rv + k - nF]);
+      V[V_VC * VL + S.perm[k]] = v;
+    }
   }
   __syncthreads();
   for (int i = tid; i < ((nF + 63) & ~63); i += nthr) { va[i] = (i < nF) ? V[V_FV * VL + i] - V[V_RZ * VL + i] : 0.0; vb[i] = 0.0; }
@@ -665,6 +687,43 @@ __global__ __launch_bounds__(RR2_TS) void rr2_s13_kernel(Rr2Solve S, int pass, i
       if (k >= nF) V[V_W2 * VL + (k - nF)] += dl;
     }
   if (tid == 0) { S.sc[4 * b + 1] = rel0; S.sc[4 * b + 2] = rel; S.si[2 * b] = more ? 1 : 0; S.si[2 * b + 1] = pass + 1; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Dense weighting matrices (Rr2Solve::wd): the products with W that the diagonal case does entry by entry inside the rows / cols
+// kernels.  One workgroup per (virtual) instance, the vector in LDS, a wave per row of W with its lanes on consecutive columns
+// (W is shared by the batch: L2).  grid = batch.
+//   OP 0 (before cols<0>):  V_WV  = W (zs - z0)
+//   OP 1 (after rows<1>):   V_RBR = W V_RBR                (rows<1> left z0 + C w2 - zs there)
+//   OP 2 (before cols<2>):  V_WV  = W rdR
+//   OP 3 (after rows<3>):   V_CP_i = dlt_i (W dlt)_i       (rows<3> left dlt = z - zs there; S15 sums the cost)
+// ---------------------------------------------------------------------------------------------------------------
+template <int OP>
+__global__ __launch_bounds__(RR2_TS) void rr2_wapply_kernel(Rr2Solve S, int pass) {
+  __shared__ double x[RR2_VMAX];
+  const long long b = blockIdx.x;
+  if ((OP == 1 || OP == 2) && pass > 0 && S.si[2 * b] == 0) return;
+  const int tid = threadIdx.x, nthr = blockDim.x, nR = S.nR, VL = S.VL;
+  double* V = S.V + b * S.vstride;
+  for (int i = tid; i < nR; i += nthr)
+    x[i] = (OP == 0) ? S.wz[S.rv + i] - V[V_Z0 * VL + i] : (OP == 1) ? V[V_RBR * VL + i] : (OP == 2) ? V[V_RDR * VL + i] : V[V_CP * VL + i];
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63, nwave = nthr >> 6;
+  for (int i = wave; i < nR; i += nwave) {
+    const double* wr = S.wd + (long long)i * nR;
+    double s0 = 0.0, s1 = 0.0;
+    int c = lane;
+    for (; c + 64 < nR; c += 128) { s0 = fma(wr[c], x[c], s0); s1 = fma(wr[c + 64], x[c + 64], s1); }
+    if (c < nR) s0 = fma(wr[c], x[c], s0);
+    double sacc = s0 + s1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
+    if (lane == 0) {
+      if (OP == 0 || OP == 2) V[V_WV * VL + i] = sacc;
+      else if (OP == 1) V[V_RBR * VL + i] = sacc;
+      else V[V_CP * VL + i] = x[i] * sacc;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

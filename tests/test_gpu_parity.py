@@ -1350,10 +1350,20 @@ def test_config5_size_nominal_runs_on_the_rank_revealing_kernel(gpu):
     _check(specr, dn["u_d"], dn["y_d"], upn, ypn, ur, costr, statusr, range(B))
     for b in range(B):
         assert int(itr[b]) == orc.solve_fullspace(specr, dn["u_d"][b], dn["y_d"][b], upn[b], ypn[b]).iters
-    # dense weighting matrices of a NOMINAL controller stay limited to the register-resident kernels
-    with pytest.raises(L.DDMPCError, match="too large"):
-        BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=3.0 * np.eye(p * Lh) + 0.01, R=1e-4 * np.eye(m * Lh), u_s=u_s, y_s=y_s,
-                     batch=1, controller_type=L.NOMINAL)
+    # dense weighting matrices of a NOMINAL controller at this size: refused until round 5, now on the phase kernels
+    # (tests/test_gpu_round5.py::test_dense_weighting_matrices_of_nominal_controllers_beyond_the_register_resident_kernels); here the
+    # configs[4] plant itself with Q = 3 I + 0.01 (all ones) against the model-based solution
+    Qd = 3.0 * np.eye(p * Lh) + 0.01
+    specd = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=Qd, R=1e-4 * np.eye(m * Lh), u_s=u_s, y_s=y_s, robust=False, eps_max=0.0, lamb_alpha=0.0,
+                       lamb_sigma=0.0, c=0.0, slack="none", tec=True)
+    with BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=Qd, R=1e-4 * np.eye(m * Lh), u_s=u_s, y_s=y_s, batch=4, controller_type=L.NOMINAL) as eng:
+        eng.set_data(d["u_d"][:4], d["y_d"][:4])
+        ud_, cd_, sd_, _ = eng.solve(up[:4], yp[:4])
+    assert np.all(sd_ == 0)
+    for b in range(2):
+        modd = solve_nominal_model_based(specd, plant, up[b], yp[b])
+        assert np.max(np.abs(ud_[b] - modd["optimal_u"])) / np.max(np.abs(modd["optimal_u"])) < TOL_U
+        assert abs(cd_[b] - modd["cost"]) <= TOL_COST * abs(modd["cost"])
     # a shape whose trajectory chunks would not fit the kernels' LDS scratch (hundreds of channels, three time steps) is
     # refused when the controller is created, not discovered on the device
     with pytest.raises(L.DDMPCError, match="not supported by the global-workspace kernels"):

@@ -517,3 +517,54 @@ def test_refinement_on_trajectories_beyond_the_lds(gpu, m, p, N):
         if mode != "off":
             assert err[mode] < TOL_U and ec < TOL_COST, (mode, err[mode], ec)
     assert err["always"] <= err["off"]
+
+
+# ------------------------------------------------------------------ dense weighting matrices, NOMINAL beyond 271 rows
+@pytest.mark.parametrize("shape", [(2, 3, 3, 60, 900), (2, 2, 4, 70, 700), (5, 4, 5, 40, 1200)], ids=["5ch-315rows", "4ch-296rows", "9ch-405rows"])
+def test_dense_weighting_matrices_of_nominal_controllers_beyond_the_register_resident_kernels(gpu, shape):
+    """controller.py:708-710 takes any PSD Q, R; until the second half of round 5 a NOMINAL controller beyond 271 rows with dense
+    matrices was refused.  On the phase kernels the reduced normal matrix is T = C'(W C) (rr2_wc_kernel, rr2_cwc_kernel) and the
+    products with W in the solve are launches of their own (rr2_wapply_kernel).  Exact data of seeded plants against the model-based
+    solution of the QP (oracle/nominal_exact.py, dense matrices: tests/test_oracle.py), the warm step on the kept factors, the
+    diagonal case given as dense matrices against the diagonal path, and the one-workgroup pipeline refusing."""
+    from oracle.nominal_exact import solve_nominal_model_based
+    from test_gpu_round4 import _exact_plant_case
+    m, p, n, Lh, N = shape
+    B = 3
+    spec, plant, d, up, yp = _exact_plant_case({9: 4, 5: 125, 4: 142}[m + p], m, p, n, Lh, N, B)
+    rng = np.random.default_rng(77 + m)
+
+    def spd(k, s):
+        X = rng.normal(size=(k, k))
+        return s * (np.eye(k) + 0.3 * (X @ X.T) / k)
+    Qd, Rd = spd(p * Lh, 3.0), spd(m * Lh, 1e-2)
+    spec_d = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=Qd, R=Rd, u_s=spec.u_s, y_s=spec.y_s, robust=False, eps_max=0.0, lamb_alpha=0.0,
+                        lamb_sigma=0.0, c=0.0, slack="none", tec=True)
+    with _spec_engine(spec_d, N, B) as eng:
+        assert (m + p) * (Lh + n) > 271 and "nominal_rr" in eng.kernel_name()
+        with pytest.raises(L.DDMPCError, match="phase kernels only"):
+            eng.set_large_pipeline("one_workgroup")
+        eng.set_data(d["u_d"], d["y_d"])
+        u, cost, status, iters = (x.copy() for x in eng.solve(up, yp))
+        ub = eng.get_solution("ubar")
+        eng.set_data(d["u_d"], d["y_d"])
+        uw = eng.step(up, yp)
+    assert np.all(status == 0), status
+    assert np.array_equal(uw[0], u) and np.array_equal(uw[1], cost) and np.array_equal(ub[:, n * m:], u)
+    for b in range(B):
+        mod = solve_nominal_model_based(spec_d, plant, up[b], yp[b])
+        assert mod["feas_residual"] < 1e-10
+        assert np.max(np.abs(u[b] - mod["optimal_u"])) / np.max(np.abs(mod["optimal_u"])) < TOL_U, b
+        assert abs(cost[b] - mod["cost"]) <= TOL_COST * abs(mod["cost"]), b
+    # a diagonal weighting handed over as dense matrices: the dense code path against the diagonal one
+    qd, rd = rng.uniform(1.0, 4.0, p * Lh), rng.uniform(0.01, 0.1, m * Lh)
+    res = {}
+    for kind in ("diag", "dense"):
+        sp = orc.QPSpec(n=n, m=m, p=p, L=Lh, Q=np.diag(qd) + (1e-300 if kind == "dense" else 0.0), R=np.diag(rd), u_s=spec.u_s, y_s=spec.y_s,
+                        robust=False, eps_max=0.0, lamb_alpha=0.0, lamb_sigma=0.0, c=0.0, slack="none", tec=True)
+        with _spec_engine(sp, N, B) as eng:
+            eng.set_data(d["u_d"], d["y_d"])
+            res[kind] = tuple(x.copy() for x in eng.solve(up, yp))
+    assert np.array_equal(res["diag"][2], res["dense"][2])
+    assert np.max(np.abs(res["diag"][0] - res["dense"][0])) <= 1e-9 * np.max(np.abs(res["diag"][0]))
+    assert np.max(np.abs(res["diag"][1] - res["dense"][1]) / np.abs(res["diag"][1])) <= 1e-9
