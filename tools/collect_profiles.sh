@@ -95,6 +95,7 @@ timeout -k 10 200 python tools/long_data_time.py > "$OUT/long_data_time.log" 2>&
 bash tools/gram_launches.sh "gpurun_out/$TAG/gram_launches" > "$OUT/gram_launches.log" 2>&1
 timeout -k 10 600 python tools/config3_full_parity.py --slack convex > "$OUT/cfg3_convex_full_parity.log" 2>&1
 timeout -k 10 900 python tools/small_fuzz.py --cases 96 --refine auto > "$OUT/small_fuzz_auto.log" 2>&1
+timeout -k 10 300 python tools/dense_nominal_time.py > "$OUT/dense_nominal_time.log" 2>&1
 echo "[collect] cfg5b done"
 fi
 if [ "$PART" = "calib" ] || [ "$PART" = "all" ]; then

@@ -34,7 +34,7 @@ shutil.copy(os.path.join(src, "other_configs.log"), os.path.join(dst, tag + "_ot
 for name in ("cfg5_time.log", "cfg5_phase_stamps.log", "cfg5_parity.log", "cfg5size_robust_parity.log", "large_kernel_fuzz.log",
              "refine_calib.log", "refine_modes.log", "convex_time.log", "host_pipeline.log", "substep_probe.log",
              "cfg5r_pmc_totals.txt", "cfg5r_schedule.log", "pivot_gap_study.log", "long_data_time.log", "gram_launches.log",
-             "cfg3_convex_full_parity.log", "small_fuzz_auto.log"):
+             "cfg3_convex_full_parity.log", "small_fuzz_auto.log", "dense_nominal_time.log"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, tag.replace("_final", "") + "_" + name))
 if glob.glob(os.path.join(src, "cfg5r_stats/*/*_kernel_stats.csv")):
