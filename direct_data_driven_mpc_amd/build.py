@@ -50,7 +50,7 @@ def instances():
 # and of its command line differs from the one recorded next to it (content-based: immune to
 # checkouts and copies that only change modification times)
 INST_DEPS = ["ddmpc_inst.hip", "ddmpc_kernels.hpp", "ddmpc_cold2.hpp"]
-API_DEPS = ["ddmpc_api.hip", "ddmpc_rr2.hpp", "ddmpc_rr2_solve.hpp", "ddmpc_rr3.hpp", "ddmpc_aux_kernels.hpp", "ddmpc_kernels.hpp", "ddmpc_cold2.hpp", "ddmpc_instances.inc"]
+API_DEPS = ["ddmpc_api.hip", "ddmpc_rr2.hpp", "ddmpc_rr2_solve.hpp", "ddmpc_rr3.hpp", "ddmpc_aux_kernels.hpp", "ddmpc_workspace_kernels.hpp", "ddmpc_kernels.hpp", "ddmpc_cold2.hpp", "ddmpc_instances.inc"]
 ONLY_NT = int(os.environ.get("DDMPC_ONLY_NT", "0") or 0)          # development: build just this instance of the kernels
 
 

@@ -1,4 +1,4 @@
-// ddmpc_api.hip -- C ABI (include/ddmpc.h) over the gfx950 kernels in ddmpc_cold2.hpp / ddmpc_aux_kernels.hpp.
+// ddmpc_api.hip -- C ABI (include/ddmpc.h) over the gfx950 kernels in ddmpc_cold2.hpp, ddmpc_aux_kernels.hpp, ddmpc_workspace_kernels.hpp and the phase pipelines (ddmpc_rr2*.hpp, ddmpc_rr3.hpp).
 // Host-side responsibilities: parameter validation with the reference's error
 // conditions (direct_data_driven_mpc_controller.py:165-168,211-222,298-343,664-670),
 // device buffer ownership, kernel-instance selection, launch.
@@ -1121,7 +1121,7 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
                                  int32_t* status, int32_t* iters, int rr_mode = 0) {
   if (h->prm.controller_type != DDMPC_NOMINAL || (h->prm.weight_kind == DDMPC_WEIGHT_DENSE && !h->large_nominal)) return DDMPC_OK;
   const size_t r = (size_t)h->kp.r, nR = (size_t)h->n_free;
-  size_t ndbl = pk_size(r) + pk_size(nR);                         // packed rows on 128-byte boundaries (ddmpc_aux_kernels.hpp)
+  size_t ndbl = pk_size(r) + pk_size(nR);                         // packed rows on 128-byte boundaries (ddmpc_workspace_kernels.hpp)
   const size_t rv = (r + 1) & ~(size_t)1;
   const size_t vec_bytes = 10 * rv * sizeof(double) + 4 * rv * sizeof(int) +    // the kernel's r-vectors, always in LDS,
                            (size_t)PSD_PAN * sizeof(double);                        // and the scratch of its Cholesky / Gram

@@ -1,7 +1,7 @@
 // ddmpc_rr2.hpp -- problems beyond the register-resident kernels ((m+p)(L+n) > 271, BASELINE configs[4]): the part of a
 // solve that depends on the DATA alone, as PHASE KERNELS that run the whole batch in lock step.
 //
-// ddmpc_nominal_rr_kernel<1> (ddmpc_aux_kernels.hpp) does all of this inside ONE workgroup per instance: a chain of dependent
+// ddmpc_nominal_rr_kernel<1> (ddmpc_workspace_kernels.hpp) does all of this inside ONE workgroup per instance: a chain of dependent
 // steps on a workspace in HBM, one register allocation for every phase (219 spilled VGPRs), two co-resident workgroups that
 // queue on the same memory path.  Here every phase is a kernel of its own -- its own register budget, no scratch -- and an
 // instance is worked on by as many workgroups as the phase has independent tiles; the dependency between panel steps is the
@@ -21,7 +21,7 @@
 // The workspace they leave -- the factor of G in place, the factor of T behind it, pivot flags and live counts in `meta` -- is
 // exactly what ddmpc_nominal_rr_kernel<2> (the solve on the factors) expects.
 #pragma once
-#include "ddmpc_aux_kernels.hpp"
+#include "ddmpc_workspace_kernels.hpp"
 
 namespace ddmpc {
 

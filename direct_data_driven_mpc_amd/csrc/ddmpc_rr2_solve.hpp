@@ -1,6 +1,6 @@
 // ddmpc_rr2_solve.hpp -- NOMINAL controllers beyond the register-resident kernels: the solve on the factors the phase kernels of
 // ddmpc_rr2.hpp leave (what changes from control step to control step, controller.py:389-407), itself as phase kernels over
-// the whole batch.  Same mathematics as ddmpc_nominal_rr_kernel<2> (ddmpc_aux_kernels.hpp):
+// the whole batch.  Same mathematics as ddmpc_nominal_rr_kernel<2> (ddmpc_workspace_kernels.hpp):
 //
 //   hard constraints      L_FF w1 = f                                   z0 = L_RF w1
 //   reduced normal eq.    T w2 = C' W (zs - z0)                          T = C' W C

@@ -1,6 +1,6 @@
 // ddmpc_rr3.hpp -- ROBUST controllers beyond the register-resident kernels ((m+p)(L+n) > 271) on the phase kernels (round 5).
 //
-// Until round 4 this size ran on ddmpc_large_solve_kernel (ddmpc_aux_kernels.hpp): ONE 512-thread workgroup per instance, every
+// Until round 4 this size ran on ddmpc_large_solve_kernel (ddmpc_workspace_kernels.hpp): ONE 512-thread workgroup per instance, every
 // phase inside one 128-VGPR allocation with 524 B of scratch per lane, the slack box re-factoring a |B| x |B| Schur block per
 // active-set iteration.  Here the same reduced system (controller.py:506-547, 631-677, 679-722)
 //
