@@ -577,11 +577,15 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
     // (dense weighting matrices of a NOMINAL controller at this size: phase kernels only -- rr2_wc_kernel / rr2_wapply_kernel --,
     //  the one-workgroup pipeline refuses them in ddmpc_set_option)
     {   // r-vectors and the Cholesky panel of the global-workspace kernels live in LDS (launch_cold / launch_nominal_rescue)
+      // NOMINAL (ten r-vectors, 512 threads; its phase pipeline: 64-bit chunk masks): 1024 rows.  ROBUST (six r-vectors): 1024 rows on
+      // the phase kernels and with 512 threads, up to 2048 on the 1024-thread instance of ddmpc_large_solve_kernel (round 5)
+      const bool rob = p.controller_type == DDMPC_ROBUST;
       const size_t rv = ((size_t)k.r + 1) & ~(size_t)1;
-      const size_t lds = 10 * rv * sizeof(double) + 4 * rv * sizeof(int) + (size_t)PSD_PAN * sizeof(double);
-      if (lds + 1024 > 160 * 1024 || k.r > PSD_RPT * 512) {     // the blocked substitutions keep PSD_RPT entries per thread (512 threads)
+      const size_t lds = (rob ? 6 : 10) * rv * sizeof(double) + 4 * rv * sizeof(int) + (size_t)PSD_PAN * sizeof(double);
+      const int rmax = PSD_RPT * (rob ? 1024 : 512);            // the blocked substitutions keep PSD_RPT entries per thread
+      if (lds + 1024 > 160 * 1024 || k.r > rmax) {
         delete h;
-        return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: (m+p)(L+n) = %d rows (the global-workspace kernels hold %d)", k.r, PSD_RPT * 512);
+        return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: (m+p)(L+n) = %d rows (the global-workspace kernels hold %d)", k.r, rmax);
       }
     }
     {   // the trajectory is streamed through the PSD_PAN doubles of LDS scratch in chunks of time steps: a chunk must hold
@@ -773,7 +777,7 @@ int ddmpc_set_data(ddmpc_handle* h, const double* u_d, const double* y_d, int me
 }
 
 static unsigned large_threads(size_t r) {   // workgroup size of the global-workspace kernels: the packed Cholesky keeps
-  return r <= 256 ? 256u : 512u;           // r <= PSD_RPT * threads (blocked substitutions)
+  return r <= 256 ? 256u : (r <= 1024 ? 512u : 1024u);           // r <= PSD_RPT * threads (blocked substitutions)
 }
 
 // want_ws: also write the beta / active-set workspace (what ddmpc_get_solution, the gain kernel and the slack-box warm
@@ -985,8 +989,8 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)status, 4, (size_t)h->batch, h->stream));
     return DDMPC_OK;
   }
-  if (h->large && h->large_pipeline == DDMPC_PIPELINE_PHASES && h->batch <= 65535 && !h->stamps_on) {
-    // ... on the phase kernels (ddmpc_rr3.hpp): lock-step factorisation of the whole batch, then one workgroup per instance
+  if (h->large && h->large_pipeline == DDMPC_PIPELINE_PHASES && h->batch <= 65535 && !h->stamps_on && h->kp.r <= 1024) {
+    // ... on the phase kernels (ddmpc_rr3.hpp; up to 1024 rows: 64-bit chunk masks): lock-step factorisation of the whole batch, then one workgroup per instance
     // that streams the factor twice and runs the active-set iterations on its trailing block
     if (large_mode != 2 && (rc = launch_rr3_factors(h))) return rc;
     if (large_mode != 1 && (rc = launch_rr3_solve(h, kp_override ? *kp_override : h->kp, up, yp, uo, cost, status, iters))) return rc;
@@ -1011,9 +1015,13 @@ static int launch_cold(ddmpc_handle* h, const double* up, const double* yp, doub
                          (int*)h->d_rrmeta.p, 0, (long long)h->batch);
       return DDMPC_OK;
     };
-    if ((rc = large_mode == 1 ? launch(ddmpc_large_solve_kernel<1>) : large_mode == 2 ? launch(ddmpc_large_solve_kernel<2>)
-                                                                                     : launch(ddmpc_large_solve_kernel<0>)))
-      return rc;
+    if (r > 1024)                  // 1025 .. 2048 rows: the 1024-thread instance
+      rc = large_mode == 1 ? launch(ddmpc_large_solve_wide_kernel<1>) : large_mode == 2 ? launch(ddmpc_large_solve_wide_kernel<2>)
+                                                                                       : launch(ddmpc_large_solve_wide_kernel<0>);
+    else
+      rc = large_mode == 1 ? launch(ddmpc_large_solve_kernel<1>) : large_mode == 2 ? launch(ddmpc_large_solve_kernel<2>)
+                                                                                   : launch(ddmpc_large_solve_kernel<0>);
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return DDMPC_OK;
   }

@@ -1639,4 +1639,23 @@ __global__ __launch_bounds__(512, 4) void ddmpc_large_solve_kernel(KParams P, in
   }
 }
 
+// The same with 1024 threads per workgroup: ROBUST controllers of 1025 .. 2048 rows (hankel_matrix.py:47 has no size bound).  The
+// routines keep PSD_RPT = 2 entries of an r-vector per thread, so the row count a workgroup holds doubles with its size; the register
+// budget per thread halves (this kernel spills either way: a set-up-size path, not a throughput kernel).  grid = batch.
+template <int MODE>
+__global__ __launch_bounds__(1024) void ddmpc_large_solve_wide_kernel(KParams P, int RPs, const double* __restrict__ u_d,
+                                                                     const double* __restrict__ y_d,
+                                                                     const double* __restrict__ u_past,
+                                                                     const double* __restrict__ y_past,
+                                                                     double* __restrict__ u_opt, double* __restrict__ cost,
+                                                                     int* __restrict__ status, int* __restrict__ iters,
+                                                                     double* __restrict__ beta_ws,
+                                                                     signed char* __restrict__ act_ws, double* scratch,
+                                                                     long long scratch_stride, int* __restrict__ meta_ws, int only_status,
+                                                                     long long nbatch) {
+  (void)only_status; (void)nbatch;
+  ddmpc_large_solve_body<MODE>(P, RPs, u_d, y_d, u_past, y_past, u_opt, cost, status, iters, beta_ws, act_ws, scratch, scratch_stride,
+                               meta_ws, (long long)blockIdx.x, (long long)blockIdx.x);
+}
+
 }  // namespace ddmpc

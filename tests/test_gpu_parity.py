@@ -396,9 +396,9 @@ def test_robust_scheme_beyond_the_register_resident_kernels(gpu, slack):
         assert np.max(np.abs(sg[b] - ref.sigma.ravel())) <= 1e-9 * max(1.0, np.max(np.abs(ref.sigma)))
         assert np.max(np.abs(yb[b] - ref.ybar.ravel())) <= 1e-9
         assert np.max(np.abs(al[b] - ref.alpha.ravel())) <= 1e-8 * max(1e-3, np.max(np.abs(ref.alpha)))
-    if slack == 0:      # beyond what the global-workspace kernels hold (1024 rows): reported when the controller is created
-        with pytest.raises(L.DDMPCError, match="too large"):
-            _engine(orc.spec_from_params(L=300, N=1000), 1000, 1)
+    if slack == 0:      # beyond what the global-workspace kernels hold (ROBUST: 2048 rows since round 5, tests/test_gpu_round5.py::
+        with pytest.raises(L.DDMPCError, match="too large"):      # test_robust_scheme_beyond_1024_rows): reported when the controller is created
+            _engine(orc.spec_from_params(L=520, N=2700), 2700, 1)
 
 
 @pytest.mark.parametrize("pipeline", ["phases", "one_workgroup"])

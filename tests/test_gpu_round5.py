@@ -568,3 +568,37 @@ def test_dense_weighting_matrices_of_nominal_controllers_beyond_the_register_res
     assert np.array_equal(res["diag"][2], res["dense"][2])
     assert np.max(np.abs(res["diag"][0] - res["dense"][0])) <= 1e-9 * np.max(np.abs(res["diag"][0]))
     assert np.max(np.abs(res["diag"][1] - res["dense"][1]) / np.abs(res["diag"][1])) <= 1e-9
+
+
+# ------------------------------------------------------------------ more than 1024 rows (ROBUST)
+@pytest.mark.parametrize("slack", ["none", "convex"])
+def test_robust_scheme_beyond_1024_rows(gpu, slack):
+    """hankel_matrix.py:47 has no size bound.  ROBUST controllers of 1025 .. 2048 rows -- here the four-tank plant with L = 271,
+    1100 rows -- run on the 1024-thread instance of ddmpc_large_solve_kernel (the phase kernels address 16-column chunks with
+    64-bit masks: 1024 rows): cold solve, the solve on the kept factors and the variables against the full-space oracle."""
+    B = 2
+    L_, N = 271, 1400
+    spec = orc.spec_from_params(L=L_, N=N, slack_var_constraint_type=1 if slack == "convex" else 0)
+    d = harness.generate_batch(range(B), N=N)
+    n = spec.n
+    up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
+    with _spec_engine(spec, N, B) as eng:
+        assert (spec.m + spec.p) * (L_ + n) == 1100 and "large_solve" in eng.kernel_name()
+        eng.set_data(d["u_d"], d["y_d"])
+        u, cost, status, iters = (x.copy() for x in eng.solve(up, yp))
+        sg = eng.get_solution("sigma")
+        eng.set_data(d["u_d"], d["y_d"])
+        uw = eng.step(up, yp)
+    assert np.all(status == 0) and np.array_equal(uw[0], u) and np.array_equal(uw[2], status)
+    for b in range(B):
+        sol = orc.solve_fullspace(spec, d["u_d"][b], d["y_d"][b], up[b], yp[b])
+        assert sol.status == "optimal" and (slack == "none" or int(iters[b]) == sol.iters)
+        assert np.max(np.abs(u[b] - sol.optimal_u)) / np.max(np.abs(sol.optimal_u)) < TOL_U, b
+        assert abs(cost[b] - sol.cost) <= TOL_COST * abs(sol.cost), b
+        assert np.max(np.abs(sg[b] - sol.sigma.ravel())) <= 1e-9 * max(1.0, np.max(np.abs(sol.sigma)))
+    # NOMINAL controllers stay at 1024 rows, and nothing goes beyond 2048
+    with pytest.raises(L.DDMPCError, match="too large"):
+        BatchedDDMPC(n=4, m=2, p=2, L_=L_, N=N, Q=3.0, R=1e-4, u_s=spec.u_s, y_s=spec.y_s, batch=1, controller_type=L.NOMINAL)
+    with pytest.raises(L.DDMPCError, match="too large"):
+        BatchedDDMPC(n=4, m=2, p=2, L_=520, N=2700, Q=3.0, R=1e-4, u_s=spec.u_s, y_s=spec.y_s, batch=1, controller_type=L.ROBUST,
+                     eps_max=0.002, lamb_alpha=50.0, lamb_sigma=1000.0, c=1.0)
