@@ -577,12 +577,13 @@ int ddmpc_create(const ddmpc_params* params, int64_t batch, int device, ddmpc_ha
     // (dense weighting matrices of a NOMINAL controller at this size: phase kernels only -- rr2_wc_kernel / rr2_wapply_kernel --,
     //  the one-workgroup pipeline refuses them in ddmpc_set_option)
     {   // r-vectors and the Cholesky panel of the global-workspace kernels live in LDS (launch_cold / launch_nominal_rescue)
-      // NOMINAL (ten r-vectors, 512 threads; its phase pipeline: 64-bit chunk masks): 1024 rows.  ROBUST (six r-vectors): 1024 rows on
-      // the phase kernels and with 512 threads, up to 2048 on the 1024-thread instance of ddmpc_large_solve_kernel (round 5)
+      // Up to 1024 rows: the phase kernels (64-bit masks over 16-column chunks) or the 512-thread one-workgroup kernels.  Beyond
+      // (round 5): the 1024-thread instances of the one-workgroup kernels -- ROBUST (six r-vectors in LDS) up to 2048 rows, NOMINAL
+      // (ten) up to 1524
       const bool rob = p.controller_type == DDMPC_ROBUST;
       const size_t rv = ((size_t)k.r + 1) & ~(size_t)1;
       const size_t lds = (rob ? 6 : 10) * rv * sizeof(double) + 4 * rv * sizeof(int) + (size_t)PSD_PAN * sizeof(double);
-      const int rmax = PSD_RPT * (rob ? 1024 : 512);            // the blocked substitutions keep PSD_RPT entries per thread
+      const int rmax = PSD_RPT * 1024;                          // the blocked substitutions keep PSD_RPT entries per thread (1024 threads at most)
       if (lds + 1024 > 160 * 1024 || k.r > rmax) {
         delete h;
         return fail(DDMPC_ERR_UNSUPPORTED, "problem too large: (m+p)(L+n) = %d rows (the global-workspace kernels hold %d)", k.r, rmax);
@@ -1177,15 +1178,20 @@ static int launch_nominal_rescue(ddmpc_handle* h, const double* up, const double
   int rcl = DDMPC_OK;
   if (!scratch) rcl = launch(ddmpc_nominal_rr_kernel<0>);                 // matrices in LDS: one launch
   else {                                                                  // global workspace: factors, then the solve on them
-    const bool phases = h->large_pipeline == DDMPC_PIPELINE_PHASES && h->large_nominal && h->batch <= 65535 && !h->stamps_on;
+    // (the phase kernels address 16-column chunks with 64-bit masks: 1024 rows; beyond that the 1024-thread instance of the
+    //  one-workgroup kernel)
+    const bool wide = r > 1024;
+    const bool phases = h->large_pipeline == DDMPC_PIPELINE_PHASES && h->large_nominal && h->batch <= 65535 && !h->stamps_on && !wide;
     const bool wdense = h->prm.weight_kind == DDMPC_WEIGHT_DENSE;
     if (wdense && !phases)
       return fail(DDMPC_ERR_UNSUPPORTED, "dense weighting matrices of a NOMINAL controller beyond 271 rows run on the phase kernels only "
                   "(batches up to 65535, no diagnostic stamps)");
-    if (rr_mode != 2) rcl = phases ? launch_rr2_factors(h, scratch, (long long)ndbl, 1e-8) : launch(ddmpc_nominal_rr_kernel<1>);
+    if (rr_mode != 2) rcl = phases ? launch_rr2_factors(h, scratch, (long long)ndbl, 1e-8)
+                                   : (wide ? launch(ddmpc_nominal_rr_wide_kernel<1>) : launch(ddmpc_nominal_rr_kernel<1>));
     if (!rcl && rr_mode != 1) {
       h->rr2_x_pending = false;
-      rcl = phases ? launch_rr2_solve(h, scratch, (long long)ndbl, up, yp, uo, cost, status, iters, 1e-7) : launch(ddmpc_nominal_rr_kernel<2>);
+      rcl = phases ? launch_rr2_solve(h, scratch, (long long)ndbl, up, yp, uo, cost, status, iters, 1e-7)
+                   : (wide ? launch(ddmpc_nominal_rr_wide_kernel<2>) : launch(ddmpc_nominal_rr_kernel<2>));
       if (!rcl && phases && h->kp.refine_max > 1 && !wdense) rcl = launch(ddmpc_nominal_rr_kernel<2>);      // the instances the phase solve marked 4 (more passes)
     }
   }
@@ -1686,7 +1692,7 @@ int ddmpc_prepare(ddmpc_handle* h) {
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)h->d_prep_status.p, 4, (size_t)h->batch, h->stream));
     h->large_gain_ready = false;
     if ((rc = launch_nominal_rescue(h, h->ud, h->yd, nullptr, nullptr, (int32_t*)h->d_prep_status.p, nullptr, 1))) return rc;
-    if (h->large_affine && h->large_pipeline == DDMPC_PIPELINE_PHASES && h->batch <= 65535 && !h->stamps_on && h->d_rr.p) {
+    if (h->large_affine && h->large_pipeline == DDMPC_PIPELINE_PHASES && h->batch <= 65535 && !h->stamps_on && h->kp.r <= 1024 && h->d_rr.p) {
       const size_t r_ = (size_t)h->kp.r, nR_ = (size_t)h->n_free;
       const long long ndbl_ = (long long)(pk_size((r_ + 15) & ~(size_t)15) + pk_size((nR_ + 15) & ~(size_t)15));
       if ((rc = launch_rr2_gain_build(h, (double*)h->d_rr.p, ndbl_))) return rc;

@@ -1055,17 +1055,17 @@ __device__ __forceinline__ void stable_partition(int r, ClsF&& cls, int* perm, i
 }
 
 template <int MODE>
-__global__ __launch_bounds__(512, DDMPC_RR_WAVES) void ddmpc_nominal_rr_kernel(KParams P, int RPs, const double* __restrict__ u_d,
-                                                               const double* __restrict__ y_d,
-                                                               const double* __restrict__ u_past,
-                                                               const double* __restrict__ y_past,
-                                                               double* __restrict__ u_opt, double* __restrict__ cost,
-                                                               int* __restrict__ status, int* __restrict__ iters,
-                                                               double rank_tol, double feas_tol, double* scratch,
-                                                               long long scratch_stride, double* w_ws,
-                                                               unsigned long long* dbg, double* __restrict__ z_ws,
-                                                               int* __restrict__ rescued, double* __restrict__ x_ws,
-                                                               int* __restrict__ meta_ws) {
+__device__ __forceinline__ void ddmpc_nominal_rr_body(const KParams& P, int RPs, const double* __restrict__ u_d,
+                                                      const double* __restrict__ y_d,
+                                                      const double* __restrict__ u_past,
+                                                      const double* __restrict__ y_past,
+                                                      double* __restrict__ u_opt, double* __restrict__ cost,
+                                                      int* __restrict__ status, int* __restrict__ iters,
+                                                      double rank_tol, double feas_tol, double* scratch,
+                                                      long long scratch_stride, double* w_ws,
+                                                      unsigned long long* dbg, double* __restrict__ z_ws,
+                                                      int* __restrict__ rescued, double* __restrict__ x_ws,
+                                                      int* __restrict__ meta_ws) {
   // MODE: 0 = the whole solve in one launch (matrices in LDS: the four-tank sizes); with the matrices in the global
   // workspace the solve is two launches -- 1 = the part that depends on the DATA alone (Gram, its rank-revealing factor,
   // the reduced normal matrix C'WC and its factor), 2 = a solve on the factors a MODE-1 launch left in the workspace --
@@ -1344,6 +1344,39 @@ __global__ __launch_bounds__(512, DDMPC_RR_WAVES) void ddmpc_nominal_rr_kernel(K
     if (iters) iters[b] = 1;
     if (dbg) dbg[b * 16 + 7] = __builtin_amdgcn_s_memrealtime();
   }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, DDMPC_RR_WAVES) void ddmpc_nominal_rr_kernel(KParams P, int RPs, const double* __restrict__ u_d,
+                                                               const double* __restrict__ y_d,
+                                                               const double* __restrict__ u_past,
+                                                               const double* __restrict__ y_past,
+                                                               double* __restrict__ u_opt, double* __restrict__ cost,
+                                                               int* __restrict__ status, int* __restrict__ iters,
+                                                               double rank_tol, double feas_tol, double* scratch,
+                                                               long long scratch_stride, double* w_ws,
+                                                               unsigned long long* dbg, double* __restrict__ z_ws,
+                                                               int* __restrict__ rescued, double* __restrict__ x_ws,
+                                                               int* __restrict__ meta_ws) {
+  ddmpc_nominal_rr_body<MODE>(P, RPs, u_d, y_d, u_past, y_past, u_opt, cost, status, iters, rank_tol, feas_tol, scratch, scratch_stride, w_ws,
+                              dbg, z_ws, rescued, x_ws, meta_ws);
+}
+// The same with 1024 threads per workgroup: NOMINAL controllers of 1025 .. 1524 rows (ten r-vectors + the panel scratch in
+// 160 KB of LDS; the routines keep two entries of an r-vector per thread).  MODE 1 / 2 only (matrices in the global workspace).
+template <int MODE>
+__global__ __launch_bounds__(1024) void ddmpc_nominal_rr_wide_kernel(KParams P, int RPs, const double* __restrict__ u_d,
+                                                                    const double* __restrict__ y_d,
+                                                                    const double* __restrict__ u_past,
+                                                                    const double* __restrict__ y_past,
+                                                                    double* __restrict__ u_opt, double* __restrict__ cost,
+                                                                    int* __restrict__ status, int* __restrict__ iters,
+                                                                    double rank_tol, double feas_tol, double* scratch,
+                                                                    long long scratch_stride, double* w_ws,
+                                                                    unsigned long long* dbg, double* __restrict__ z_ws,
+                                                                    int* __restrict__ rescued, double* __restrict__ x_ws,
+                                                                    int* __restrict__ meta_ws) {
+  ddmpc_nominal_rr_body<MODE>(P, RPs, u_d, y_d, u_past, y_past, u_opt, cost, status, iters, rank_tol, feas_tol, scratch, scratch_stride, w_ws,
+                              dbg, z_ws, rescued, x_ws, meta_ws);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

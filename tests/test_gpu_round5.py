@@ -596,9 +596,35 @@ def test_robust_scheme_beyond_1024_rows(gpu, slack):
         assert np.max(np.abs(u[b] - sol.optimal_u)) / np.max(np.abs(sol.optimal_u)) < TOL_U, b
         assert abs(cost[b] - sol.cost) <= TOL_COST * abs(sol.cost), b
         assert np.max(np.abs(sg[b] - sol.sigma.ravel())) <= 1e-9 * max(1.0, np.max(np.abs(sol.sigma)))
-    # NOMINAL controllers stay at 1024 rows, and nothing goes beyond 2048
+    # NOMINAL controllers stop at 1524 rows (test_nominal_scheme_beyond_1024_rows), and nothing goes beyond 2048
     with pytest.raises(L.DDMPCError, match="too large"):
-        BatchedDDMPC(n=4, m=2, p=2, L_=L_, N=N, Q=3.0, R=1e-4, u_s=spec.u_s, y_s=spec.y_s, batch=1, controller_type=L.NOMINAL)
+        BatchedDDMPC(n=4, m=2, p=2, L_=400, N=2000, Q=3.0, R=1e-4, u_s=spec.u_s, y_s=spec.y_s, batch=1, controller_type=L.NOMINAL)
     with pytest.raises(L.DDMPCError, match="too large"):
         BatchedDDMPC(n=4, m=2, p=2, L_=520, N=2700, Q=3.0, R=1e-4, u_s=spec.u_s, y_s=spec.y_s, batch=1, controller_type=L.ROBUST,
                      eps_max=0.002, lamb_alpha=50.0, lamb_sigma=1000.0, c=1.0)
+
+
+def test_nominal_scheme_beyond_1024_rows(gpu):
+    """NOMINAL controllers of 1025 .. 1524 rows (ten r-vectors of the one-workgroup kernel + its panel scratch in 160 KB of LDS) run on
+    the 1024-thread instance of ddmpc_nominal_rr_kernel: a SISO plant with L = 600 (1206 rows, exact data) against the model-based
+    solution, the step on the kept factors; more than 1524 rows are refused when the controller is created."""
+    from oracle.nominal_exact import solve_nominal_model_based
+    from test_gpu_round4 import _exact_plant_case
+    m, p, n, Lh, N = 1, 1, 3, 600, 1500
+    B = 2
+    spec, plant, d, up, yp = _exact_plant_case(11, m, p, n, Lh, N, B)
+    with _spec_engine(spec, N, B) as eng:
+        assert (m + p) * (Lh + n) == 1206 and "nominal_rr" in eng.kernel_name()
+        eng.set_data(d["u_d"], d["y_d"])
+        u, cost, status, _ = (x.copy() for x in eng.solve(up, yp))
+        eng.set_data(d["u_d"], d["y_d"])
+        uw = eng.step(up, yp)
+    assert np.all(status == 0), status
+    assert np.max(np.abs(uw[0] - u)) <= 1e-9 * np.max(np.abs(u)) and np.array_equal(uw[2], status)
+    for b in range(B):
+        mod = solve_nominal_model_based(spec, plant, up[b], yp[b])
+        assert mod["feas_residual"] < 1e-10
+        assert np.max(np.abs(u[b] - mod["optimal_u"])) / np.max(np.abs(mod["optimal_u"])) < TOL_U, b
+        assert abs(cost[b] - mod["cost"]) <= TOL_COST * abs(mod["cost"]), b
+    with pytest.raises(L.DDMPCError, match="too large"):
+        BatchedDDMPC(n=3, m=1, p=1, L_=800, N=1900, Q=3.0, R=1e-4, u_s=spec.u_s, y_s=spec.y_s, batch=1, controller_type=L.NOMINAL)
