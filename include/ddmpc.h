@@ -174,8 +174,10 @@ int ddmpc_device_count(void);
  * factor reuse -- ddmpc_prepare forms what depends on the data and the weights alone (NOMINAL: Gram, its rank-revealing
  * factor, the reduced normal matrix and its factor; ROBUST: Gram + lam D, the factor of the columns outside the slack
  * box, the Schur complement of the boxed block), ddmpc_step and the per-step closed loop solve on what it kept, with
- * results bit-equal to ddmpc_solve's.  Dense weighting matrices of a NOMINAL controller beyond 271 rows, and any problem beyond
- * 1024 rows, are DDMPC_ERR_UNSUPPORTED (reported by ddmpc_create).
+ * results bit-equal to ddmpc_solve's.  Both schemes run on phase kernels over the whole batch by default up to 1024 rows
+ * (round 5: also ROBUST controllers, and dense weighting matrices of either scheme; NOMINAL + dense: phase kernels only);
+ * ROBUST controllers of 1025 .. 2048 rows and NOMINAL ones of 1025 .. 1524 (diagonal weights) run on 1024-thread instances of
+ * the one-workgroup kernels.  Anything larger is DDMPC_ERR_UNSUPPORTED (reported by ddmpc_create).
  *
  * Replaces DirectDataDrivenMPCController.__init__ parameter validation
  * (controller.py:165-168,211-222,298-343,664-670) for a batch of instances on
