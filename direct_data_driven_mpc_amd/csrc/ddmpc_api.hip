@@ -1874,6 +1874,9 @@ int ddmpc_set_option(ddmpc_handle* h, int option, int value) {
       h->prepared = false;
       return DDMPC_OK;
     case DDMPC_OPT_LARGE_AFFINE_LAW:
+      // (the law's step kernel evaluates the cost with the diagonal weights, and the law is built by the phase kernels: 1024 rows)
+      if (value != 0 && h->large_nominal && (h->prm.weight_kind == DDMPC_WEIGHT_DENSE || h->kp.r > 1024))
+        return fail(DDMPC_ERR_UNSUPPORTED, "the affine law of NOMINAL controllers beyond 271 rows takes scalar / diagonal weights and at most 1024 rows");
       h->large_affine = value != 0;
       h->prepared = false;
       h->large_gain_ready = false;

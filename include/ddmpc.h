@@ -119,7 +119,8 @@ extern "C" {
                                          once per data set) and ddmpc_step evaluates it in one HBM-bound launch; ddmpc_get_gain then
                                          returns it as [batch][n(m+p)+1][(m+p)(L+n)], z = [ubar; ybar] per component = gain[0] +
                                          gain[1:]' [u_past; y_past].  0 (default): ddmpc_step repeats the solve on the kept factors,
-                                         bit-equal to ddmpc_solve (controller.py:389-407) */
+                                         bit-equal to ddmpc_solve (controller.py:389-407).  Scalar / diagonal weights, at most 1024
+                                         rows (DDMPC_ERR_UNSUPPORTED otherwise) */
 #define DDMPC_OPT_CONVEX_UPDATE 8      /* ROBUST controllers with the CONVEX slack box on the register-resident kernels
                                          (controller.py:631-677): 1 (default) = active-set iterations after the first keep the factor
                                          of the empty active set and treat the <= 4 switched slack components as a diagonal modification

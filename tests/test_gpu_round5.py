@@ -544,6 +544,8 @@ def test_dense_weighting_matrices_of_nominal_controllers_beyond_the_register_res
         assert (m + p) * (Lh + n) > 271 and "nominal_rr" in eng.kernel_name()
         with pytest.raises(L.DDMPCError, match="phase kernels only"):
             eng.set_large_pipeline("one_workgroup")
+        with pytest.raises(L.DDMPCError, match="scalar / diagonal weights"):
+            eng.set_large_affine_law(True)
         eng.set_data(d["u_d"], d["y_d"])
         u, cost, status, iters = (x.copy() for x in eng.solve(up, yp))
         ub = eng.get_solution("ubar")
