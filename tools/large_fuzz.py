@@ -25,7 +25,13 @@ for case in range(a.cases):
     eps = 0.002
     slack = "convex" if case % 2 == 1 else "none"
     tec = case % 5 != 4
-    if case % 3 == 0:
+    dense = case % 4 == 3                                        # dense SPD weighting matrices (round 5: on the phase kernels too)
+    if dense:
+        def spd(k, sc):
+            X = rng.normal(size=(k, k))
+            return sc * (np.eye(k) + 0.3 * (X @ X.T) / k)
+        Q = spd(p * Lh, 2.0); R = spd(m * Lh, 0.05)
+    elif case % 3 == 0:
         Q = 2.0 * np.eye(p * Lh); R = 0.05 * np.eye(m * Lh)
     else:
         Q = np.diag(rng.uniform(1.0, 4.0, p * Lh)); R = np.diag(rng.uniform(0.01, 0.1, m * Lh))
@@ -36,7 +42,7 @@ for case in range(a.cases):
     B = 2
     d = generate_batch(range(case * 10, case * 10 + B), N=N, plant=plant)
     up = d["u_d"][:, -n:, :].reshape(B, -1).copy(); yp = d["y_d"][:, -n:, :].reshape(B, -1).copy()
-    Qa = np.diag(Q) if case % 3 else Q; Ra = np.diag(R) if case % 3 else R
+    Qa = Q if (dense or case % 3 == 0) else np.diag(Q); Ra = R if (dense or case % 3 == 0) else np.diag(R)
     with BatchedDDMPC(n=n, m=m, p=p, L_=Lh, N=N, Q=Qa, R=Ra, u_s=spec.u_s, y_s=spec.y_s, batch=B, controller_type=L.ROBUST,
                       slack_type=L.SLACK_CONVEX if slack == "convex" else L.SLACK_NONE, eps_max=eps, lamb_alpha=20.0,
                       lamb_sigma=500.0, c=1.0, use_terminal_constraint=tec) as eng:
@@ -53,7 +59,7 @@ for case in range(a.cases):
         ec = max(ec, abs(cost[b] - sol.cost) / max(abs(sol.cost), 1e-6))
     worst_u, worst_c = max(worst_u, eu), max(worst_c, ec)
     print("case %2d m=%d p=%d n=%d L=%3d N=%4d r=%3d slack %-6s tec %d weights %-6s %s: status/iterations %s, iters %s, "
-          "rel err u %.1e cost %.1e" % (case, m, p, n, Lh, N, r, slack, tec, "scalar" if case % 3 == 0 else "diag", name,
+          "rel err u %.1e cost %.1e" % (case, m, p, n, Lh, N, r, slack, tec, "dense" if dense else ("scalar" if case % 3 == 0 else "diag"), name,
                                          "ok" if ok else "MISMATCH", iters.tolist(), eu, ec), flush=True)
     assert ok and "large_solve" in name
 print("worst rel err over %d cases: u %.2e, cost %.2e" % (a.cases, worst_u, worst_c))
